@@ -1,0 +1,70 @@
+"""UNet / scheduler configurations for the attention-controlled denoising path.
+
+The reference never spells the architecture out: it loads it by hub name through diffusers
+(`/root/reference/p2p/sd_mapping.py:1-6`, `/root/reference/p2p/edit_syn.py:60`).  The numbers
+below restate the public SD1.5 `unet/config.json` and the scheduler
+dict every reference script hard-codes (`/root/reference/p2p/edit_syn.py:46-57`).
+"""
+from dataclasses import dataclass, field
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class UNetConfig:
+    sample_size: int = 64
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    # True where the down block (and the mirrored up block) carries transformers
+    down_has_attn: Tuple[bool, ...] = (True, True, True, False)
+    layers_per_block: int = 2
+    cross_attention_dim: int = 768
+    # diffusers' misnamed `attention_head_dim`: for SD1.5 it is the NUMBER of heads
+    num_heads: Tuple[int, ...] = (8, 8, 8, 8)
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    time_embed_dim_mult: int = 4
+    text_max_length: int = 77
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_out_channels[0] * self.time_embed_dim_mult
+
+
+SD15 = UNetConfig()
+
+# A shape family small enough for the CPU oracle to run a whole edit in seconds.  Channel
+# counts stay multiples of 64 (the implicit-GEMM K-tile) and head dims hit 64 and 32.
+TINY = UNetConfig(
+    sample_size=16,
+    block_out_channels=(64, 128, 128, 128),
+    down_has_attn=(True, True, True, False),
+    cross_attention_dim=64,
+    num_heads=(1, 2, 4, 4),
+    text_max_length=77,
+)
+
+# SD1.5 head geometry (d = 40 / 80, C = 320 / 640) on a two-level net: the real channel
+# widths, skip concats and the N<=256 self-replace rule without the full 860 M parameters.
+SMALL = UNetConfig(
+    sample_size=32,
+    block_out_channels=(320, 640),
+    down_has_attn=(True, True),
+    cross_attention_dim=768,
+    num_heads=(8, 8),
+)
+
+SCHEDULER_CONFIG = {
+    "beta_end": 0.012,
+    "beta_schedule": "scaled_linear",
+    "beta_start": 0.00085,
+    "clip_sample": False,
+    "num_train_timesteps": 1000,
+    "set_alpha_to_one": False,
+    "skip_prk_steps": True,
+    "steps_offset": 1,
+    "trained_betas": None,
+    "use_karras_sigmas": False,
+}
+
+CONFIGS = {"sd15": SD15, "tiny": TINY, "small": SMALL}

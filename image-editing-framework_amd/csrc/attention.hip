@@ -1,0 +1,579 @@
+// Fused attention kernels for gfx950 (fp16 operands, fp32 softmax and accumulation).
+//
+// All four kernels share one tiling.  A workgroup = 4 waves = 128 query rows of one
+// (batch, head); each wave owns 32 queries.  Scores are computed TRANSPOSED,
+//     S^T[kv][q] = K[kv][:] . Q[q][:]        v_mfma_f32_32x32x16_f16(A = K rows, B = Q rows)
+// so that a lane holds one query COLUMN: 16 scores per 32-key sub-tile, the other 16 in lane^32.
+// Row max / row sum are then in-lane reductions plus one cross-half shuffle, the online-softmax
+// rescale of the output is a per-lane scalar, and the probability registers ARE the B operand of
+//     O^T[d][q] += V^T[d][kv] . P^T[kv][q]   (A = V^T rows read from LDS, B = P^T from registers)
+// with the k-order permutation of an accumulator-as-operand (element j of lane half h is key
+// 16s + 8(j>>2) + 4h + (j&3)) applied to the V^T fragment reads.  No probability ever touches LDS
+// or HBM in the fused kernels.
+//
+//   attn_flash      softmax(QK^T)V with per-batch Q/K/V source indirection (self-attention; P2P
+//                   self-replace and MasaCtrl mutual attention are pure index remaps)
+//   attn_cross_p2p  L <= 96 keys; Prompt-to-Prompt cross-map edit fused between softmax and PV
+//   attn_probs / attn_apply   materialised maps for the generic Python-controller path
+//
+// Reference call sites: /root/reference/p2p/model/register.py:47-51 (scores, controller, bmm),
+// /root/reference/p2p/model/attention_base.py:113-136 (edit), attention_control.py:15-46.
+#include "ief_common.h"
+#include "ief_params.h"
+
+#define LOG2E 1.4426950408889634f
+
+template <int D>
+struct AttnCfg {
+    static constexpr int D16 = (D + 15) / 16;  // k-steps of the score MFMA
+    static constexpr int DP = D16 * 16;        // padded head dim of the K tile
+    static constexpr int DT = (D + 31) / 32;   // 32-row output tiles of O^T
+    static constexpr int KS = DP + 8;          // K row stride (halves): odd number of 16-B slots
+    static constexpr int CPR = D / 8;          // 16-B chunks per K/V row
+};
+
+__device__ __forceinline__ half8 pack8(const f32x16& p, int base) {
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)p[base + j];
+    return o;
+}
+
+// A-operand fragment with the accumulator k-permutation: 4 + 4 consecutive halves of one LDS row
+__device__ __forceinline__ half8 read_perm_frag(const half_t* row_ptr, int kbase, int h) {
+    const half4 lo = *(const half4*)(row_ptr + kbase + 4 * h);
+    const half4 hi = *(const half4*)(row_ptr + kbase + 8 + 4 * h);
+    half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return o;
+}
+// natural k order: 8 consecutive halves starting at kbase + 8h (8-byte aligned rows)
+__device__ __forceinline__ half8 read_nat_frag(const half_t* row_ptr, int kbase, int h) {
+    const half4 lo = *(const half4*)(row_ptr + kbase + 8 * h);
+    const half4 hi = *(const half4*)(row_ptr + kbase + 8 * h + 4);
+    half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return o;
+}
+
+template <int D>
+__device__ __forceinline__ void load_q_frags(half8 (&qf)[AttnCfg<D>::D16], const half_t* Q, long long row_off,
+                                             bool row_ok, int h) {
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < AttnCfg<D>::D16; ++s) {
+        const int dc = 16 * s + 8 * h;
+        qf[s] = (row_ok && dc < D) ? *(const half8*)(Q + row_off + dc) : zero8;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// flash attention with source indirection
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) {
+    using C = AttnCfg<D>;
+    constexpr int VS = 68;                                   // V^T row stride: 64 keys + 4 pad
+    constexpr int NCH = (64 * C::CPR + 255) / 256;
+    __shared__ __attribute__((aligned(16))) half_t Ks[64 * C::KS];
+    __shared__ __attribute__((aligned(16))) half_t Vt[C::DT * 32 * VS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qs = p.q_src ? p.q_src[b] : b;
+    const int ks = p.k_src ? p.k_src[b] : b;
+    const int vs = p.v_src ? p.v_src[b] : b;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool q_ok = q0 + r < p.N;
+
+    for (int i = tid; i < 64 * C::KS / 8; i += 256) ((half8*)Ks)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < C::DT * 32 * VS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
+
+    half8 qf[C::D16];
+    load_q_frags<D>(qf, p.Q, ((long long)qs * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+
+    const half_t* Kb = p.K + (long long)ks * p.L * p.ldk + head * D;
+    const half_t* Vb = p.V + (long long)vs * p.L * p.ldv + head * D;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8 kreg[NCH], vreg[NCH];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / C::CPR, ch = c - row * C::CPR;
+            const bool ok = c < 64 * C::CPR && kv0 + row < p.L;
+            kreg[i] = ok ? *(const half8*)(Kb + (long long)(kv0 + row) * p.ldk + ch * 8) : zero8;
+            vreg[i] = ok ? *(const half8*)(Vb + (long long)(kv0 + row) * p.ldv + ch * 8) : zero8;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i;
+            if (c < 64 * C::CPR) {
+                const int row = c / C::CPR, ch = c - row * C::CPR;
+                *(half8*)(Ks + row * C::KS + ch * 8) = kreg[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = vreg[i][e];
+            }
+        }
+    };
+
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * LOG2E;
+
+    const int nt = (p.L + 63) / 64;
+    __syncthreads();  // zero fill done
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const int kv0 = j * 64;
+        if (j + 1 < nt) load_tile(kv0 + 64);
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s) {
+            const half8 k0 = *(const half8*)(Ks + r * C::KS + 16 * s + 8 * h);
+            const half8 k1 = *(const half8*)(Ks + (32 + r) * C::KS + 16 * s + 8 * h);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+        }
+        const bool tail = kv0 + 64 > p.L;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
+            float a = s0[i] * sc, c = s1[i] * sc;
+            if (tail) {
+                if (kv0 + kvl >= p.L) a = -INFINITY;
+                if (kv0 + 32 + kvl >= p.L) c = -INFINITY;
+            }
+            s0[i] = a; s1[i] = c;
+            mx = fmaxf(mx, fmaxf(a, c));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = exp2f(s0[i] - m_new);
+            s1[i] = exp2f(s1[i] - m_new);
+            ls += s0[i] + s1[i];
+        }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+        const half8 pb00 = pack8(s0, 0), pb01 = pack8(s0, 8), pb10 = pack8(s1, 0), pb11 = pack8(s1, 8);
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t) {
+            const half_t* vrow = Vt + (t * 32 + r) * VS;
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 0, h), pb00, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 16, h), pb01, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 32, h), pb10, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 48, h), pb11, o[t], 0, 0, 0);
+        }
+        __syncthreads();
+        if (j + 1 < nt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q_ok) {
+        half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int db = t * 32 + 8 * g + 4 * h;
+                if (db < D) {
+                    half4 v = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv),
+                               (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+                    *(half4*)(orow + db) = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cross attention (<= 96 keys) with the P2P edit
+// ------------------------------------------------------------------------------------------
+#define XL 96   // padded key count: 3 sub-tiles of 32
+#define XS 100  // row stride (halves) of the [*, 96]-wide LDS images (V^T, M^T): 200 B
+
+template <int D>
+__device__ __forceinline__ void cross_scores(f32x16 (&s)[3], const half_t* Ks, const half8 (&qf)[AttnCfg<D>::D16],
+                                             int r, int h, float sc, int L) {
+    using C = AttnCfg<D>;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[u][i] = 0.f;
+#pragma unroll
+    for (int st = 0; st < C::D16; ++st) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const half8 k = *(const half8*)(Ks + (32 * u + r) * C::KS + 16 * st + 8 * h);
+            s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k, qf[st], s[u], 0, 0, 0);
+        }
+    }
+    // normalised softmax over the L valid keys (row = this lane's query; other half in lane^32)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kv = 32 * u + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float a = kv < L ? s[u][i] * sc : -INFINITY;
+            s[u][i] = a;
+            mx = fmaxf(mx, a);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float ls = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s[u][i] = exp2f(s[u][i] - mx);
+            ls += s[u][i];
+        }
+    ls += __shfl_xor(ls, 32);
+    const float inv = 1.0f / ls;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[u][i] *= inv;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_cross_p2p_kernel(const IefCrossParams p) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) half_t Ks[XL * C::KS];
+    __shared__ __attribute__((aligned(16))) half_t Vt[C::DT * 32 * XS];
+    __shared__ __attribute__((aligned(16))) half_t Ms[XL * XS];
+    __shared__ float coef_s[2 * XL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int es = p.edit_src ? p.edit_src[b] : -1;
+    const int slot = (es >= 0 && p.edit_slot) ? p.edit_slot[b] : 0;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool q_ok = q0 + r < p.N;
+    const float sc = p.scale * LOG2E;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int i = tid; i < XL * C::KS / 8; i += 256) ((half8*)Ks)[i] = zero8;
+    for (int i = tid; i < C::DT * 32 * XS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
+    __syncthreads();
+
+    auto stage_k = [&](int bsrc) {
+        const half_t* Kb = p.K + (long long)bsrc * p.L * p.ldk + head * D;
+        for (int c = tid; c < XL * C::CPR; c += 256) {
+            const int row = c / C::CPR, ch = c - row * C::CPR;
+            *(half8*)(Ks + row * C::KS + ch * 8) = row < p.L ? *(const half8*)(Kb + (long long)row * p.ldk + ch * 8) : zero8;
+        }
+    };
+
+    half8 qf[C::D16];
+    f32x16 pm[3];
+    if (es >= 0) {  // block-uniform
+        stage_k(es);
+        const half_t* Mg = p.MT + (long long)slot * XL * XL;
+        for (int c = tid; c < XL * XL / 8; c += 256) {
+            const int row = c / (XL / 8), ch = c - row * (XL / 8);
+            const half8 v = *(const half8*)(Mg + row * XL + ch * 8);
+            *(half4*)(Ms + row * XS + ch * 8) = (half4){v[0], v[1], v[2], v[3]};
+            *(half4*)(Ms + row * XS + ch * 8 + 4) = (half4){v[4], v[5], v[6], v[7]};
+        }
+        for (int i = tid; i < 2 * XL; i += 256) coef_s[i] = p.coef[(long long)slot * 2 * XL + i];
+        __syncthreads();
+        load_q_frags<D>(qf, p.Q, ((long long)es * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+        f32x16 ps[3];
+        cross_scores<D>(ps, Ks, qf, r, h, sc, p.L);
+        // PM^T[n][q] = sum_w M^T[n][w] P_src^T[w][q]
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pm[u][i] = 0.f;
+#pragma unroll
+        for (int u2 = 0; u2 < 3; ++u2) {
+            const half8 pb0 = pack8(ps[u2], 0), pb1 = pack8(ps[u2], 8);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const half_t* mrow = Ms + (32 * u + r) * XS;
+                pm[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(mrow, 32 * u2, h), pb0, pm[u], 0, 0, 0);
+                pm[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(mrow, 32 * u2 + 16, h), pb1, pm[u], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // everyone is done with the source K image
+    }
+
+    stage_k(b);
+    {
+        const half_t* Vb = p.V + (long long)b * p.L * p.ldv + head * D;
+        for (int c = tid; c < XL * C::CPR; c += 256) {
+            const int row = c / C::CPR, ch = c - row * C::CPR;
+            if (row < p.L) {
+                const half8 v = *(const half8*)(Vb + (long long)row * p.ldv + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * XS + row] = v[e];
+            }
+        }
+    }
+    __syncthreads();
+    load_q_frags<D>(qf, p.Q, ((long long)b * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    f32x16 ps[3];
+    cross_scores<D>(ps, Ks, qf, r, h, sc, p.L);
+    if (es >= 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = 32 * u + (i & 3) + 8 * (i >> 2) + 4 * h;
+                ps[u][i] = coef_s[n] * pm[u][i] + coef_s[XL + n] * ps[u][i];
+            }
+    }
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const half8 pb0 = pack8(ps[u], 0), pb1 = pack8(ps[u], 8);
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t) {
+            const half_t* vrow = Vt + (t * 32 + r) * XS;
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 32 * u, h), pb0, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 32 * u + 16, h), pb1, o[t], 0, 0, 0);
+        }
+    }
+    if (q_ok) {
+        half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int db = t * 32 + 8 * g + 4 * h;
+                if (db < D) {
+                    half4 v = {(half_t)o[t][4 * g], (half_t)o[t][4 * g + 1], (half_t)o[t][4 * g + 2], (half_t)o[t][4 * g + 3]};
+                    *(half4*)(orow + db) = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic path: materialised probabilities, and probabilities x V
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_probs_kernel(const IefAttnParams p, half_t* __restrict__ probs) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) half_t Ks[64 * C::KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool q_ok = q0 + r < p.N;
+    const float sc = p.scale * LOG2E;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < 64 * C::KS / 8; i += 256) ((half8*)Ks)[i] = zero8;
+    half8 qf[C::D16];
+    load_q_frags<D>(qf, p.Q, ((long long)b * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    const half_t* Kb = p.K + (long long)b * p.L * p.ldk + head * D;
+    half_t* prow = probs + (((long long)b * p.heads + head) * p.N + q0 + r) * p.L;
+    const int nt = (p.L + 63) / 64;
+    float m_run = -INFINITY, l_run = 0.f;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        const float inv = pass ? 1.0f / (l_run + __shfl_xor(l_run, 32)) : 0.f;
+        for (int j = 0; j < nt; ++j) {
+            const int kv0 = j * 64;
+            for (int c = tid; c < 64 * C::CPR; c += 256) {
+                const int row = c / C::CPR, ch = c - row * C::CPR;
+                *(half8*)(Ks + row * C::KS + ch * 8) =
+                    kv0 + row < p.L ? *(const half8*)(Kb + (long long)(kv0 + row) * p.ldk + ch * 8) : zero8;
+            }
+            __syncthreads();
+            f32x16 s0, s1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < C::D16; ++s) {
+                const half8 k0 = *(const half8*)(Ks + r * C::KS + 16 * s + 8 * h);
+                const half8 k1 = *(const half8*)(Ks + (32 + r) * C::KS + 16 * s + 8 * h);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+            }
+            if (pass == 0) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    s0[i] = kv0 + kvl < p.L ? s0[i] * sc : -INFINITY;
+                    s1[i] = kv0 + 32 + kvl < p.L ? s1[i] * sc : -INFINITY;
+                    mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run, mx);
+                float ls = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ls += exp2f(s0[i] - m_new) + exp2f(s1[i] - m_new);
+                l_run = l_run * exp2f(m_run - m_new) + ls;
+                m_run = m_new;
+            } else if (q_ok) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kv = kv0 + 32 * u + 8 * g + 4 * h + e;
+                            const float sv = u ? s1[4 * g + e] : s0[4 * g + e];
+                            if (kv < p.L) prow[kv] = (half_t)(exp2f(sv * sc - m_run) * inv);
+                        }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_apply_kernel(const IefAttnParams p, const half_t* __restrict__ probs) {
+    using C = AttnCfg<D>;
+    constexpr int VS = 68;
+    __shared__ __attribute__((aligned(16))) half_t Vt[C::DT * 32 * VS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool q_ok = q0 + r < p.N;
+    for (int i = tid; i < C::DT * 32 * VS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
+    const half_t* Vb = p.V + (long long)b * p.L * p.ldv + head * D;
+    const half_t* prow = probs + (((long long)b * p.heads + head) * p.N + (q_ok ? q0 + r : 0)) * p.L;
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    const int nt = (p.L + 63) / 64;
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const int kv0 = j * 64;
+        for (int c = tid; c < 64 * C::CPR; c += 256) {
+            const int row = c / C::CPR, ch = c - row * C::CPR;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kv0 + row < p.L) v = *(const half8*)(Vb + (long long)(kv0 + row) * p.ldv + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            half8 pb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kv = kv0 + 16 * s + 8 * h + e;
+                pb[e] = (q_ok && kv < p.L) ? prow[kv] : (half_t)0;
+            }
+#pragma unroll
+            for (int t = 0; t < C::DT; ++t)
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_nat_frag(Vt + (t * 32 + r) * VS, 16 * s, h), pb, o[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (q_ok) {
+        half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int db = t * 32 + 8 * g + 4 * h;
+                if (db < D) {
+                    half4 v = {(half_t)o[t][4 * g], (half_t)o[t][4 * g + 1], (half_t)o[t][4 * g + 2], (half_t)o[t][4 * g + 3]};
+                    *(half4*)(orow + db) = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------
+static int check_attn(int B, int heads, int N, int L, int d, int ldq, int ldk, int ldv, int ldo, const void* Q,
+                      const void* K, const void* V, const void* O) {
+    if (!Q || !K || !V || !O) return IEF_EINVAL;
+    if (B <= 0 || heads <= 0 || N <= 0 || L <= 0) return IEF_ESHAPE;
+    if (d != 32 && d != 40 && d != 64 && d != 80 && d != 160) return IEF_ESHAPE;
+    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3)) return IEF_EALIGN;
+    if (heads * d > ldq || heads * d > ldk || heads * d > ldv || heads * d > ldo) return IEF_ESHAPE;
+    return IEF_OK;
+}
+
+#define DISPATCH_D(d, CALL)                   \
+    switch (d) {                              \
+        case 32: { constexpr int DD = 32; CALL; } break;   \
+        case 40: { constexpr int DD = 40; CALL; } break;   \
+        case 64: { constexpr int DD = 64; CALL; } break;   \
+        case 80: { constexpr int DD = 80; CALL; } break;   \
+        case 160: { constexpr int DD = 160; CALL; } break; \
+        default: return IEF_ESHAPE;           \
+    }
+
+extern "C" int ief_attn_flash_f16(const IefAttnParams* pp, void* stream) {
+    if (!pp) return IEF_EINVAL;
+    const IefAttnParams p = *pp;
+    int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldq, p.ldk, p.ldv, p.ldo, p.Q, p.K, p.V, p.Out);
+    if (rc) return rc;
+    dim3 grid((p.N + 127) / 128, p.heads, p.B);
+    DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+extern "C" int ief_attn_cross_p2p_f16(const IefCrossParams* pp, void* stream) {
+    if (!pp) return IEF_EINVAL;
+    const IefCrossParams p = *pp;
+    int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldq, p.ldk, p.ldv, p.ldo, p.Q, p.K, p.V, p.Out);
+    if (rc) return rc;
+    if (p.L > XL) return IEF_ESHAPE;
+    if (p.edit_src && (!p.MT || !p.coef)) return IEF_EINVAL;
+    dim3 grid((p.N + 127) / 128, p.heads, p.B);
+    DISPATCH_D(p.d, hipLaunchKernelGGL((attn_cross_p2p_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+extern "C" int ief_attn_probs_f16(const IefAttnParams* pp, ief_half* probs, void* stream) {
+    if (!pp || !probs) return IEF_EINVAL;
+    const IefAttnParams p = *pp;
+    int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldq, p.ldk, p.ldk, p.ldq, p.Q, p.K, p.K, probs);
+    if (rc) return rc;
+    dim3 grid((p.N + 127) / 128, p.heads, p.B);
+    DISPATCH_D(p.d, hipLaunchKernelGGL((attn_probs_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p, probs));
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+extern "C" int ief_attn_apply_f16(const IefAttnParams* pp, const ief_half* probs, void* stream) {
+    if (!pp || !probs) return IEF_EINVAL;
+    const IefAttnParams p = *pp;
+    int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldv, p.ldv, p.ldv, p.ldo, probs, probs, p.V, p.Out);
+    if (rc) return rc;
+    dim3 grid((p.N + 127) / 128, p.heads, p.B);
+    DISPATCH_D(p.d, hipLaunchKernelGGL((attn_apply_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p, probs));
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}

@@ -1,0 +1,127 @@
+// Boundary convolutions of the UNet: they also carry the layout / dtype change between the
+// sampler's fp32 NCHW latents and the network's fp16 NHWC activations, so no separate
+// transpose or cast kernel runs at either end.
+//   conv_in : [B,Cin<=8,H,W] fp32 NCHW -> [B,H,W,Cout] fp16        (K = 9*Cin, too thin for MFMA)
+//   conv_out: [B,H,W,C] fp16 -> [B,Cout<=8,H,W] fp32 NCHW           (N = Cout, too thin for MFMA)
+// Both are small (0.4 GFLOP at 64x64, B=4) and bandwidth/latency-bound.
+#include "ief_common.h"
+#include "ief_params.h"
+
+#define CIN_MAX 8
+#define COUT_MAX 8
+
+// block: 256 threads = PIX pixels x (Cout/8) channel chunks; weights staged in LDS as fp32 [9*Cin][Cout]
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const half_t* __restrict__ w,
+                                                      const float* __restrict__ bias, half_t* __restrict__ out,
+                                                      int B, int Cin, int H, int Wd, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout]
+    const int K = 9 * Cin;
+    for (int i = threadIdx.x; i < K * Cout; i += 256) {
+        const int co = i / K, k = i - co * K;          // w is [Cout][3][3][Cin] -> k = (ky*3+kx)*Cin + ci
+        wl[k * Cout + co] = (float)w[i];
+    }
+    __syncthreads();
+    const int C8 = Cout >> 3;
+    const int pix_per_block = 256 / C8 > 0 ? 256 / C8 : 1;
+    const int tp = threadIdx.x / C8, c8 = threadIdx.x - tp * C8;
+    if (tp >= pix_per_block) return;
+    const long long pix = (long long)blockIdx.x * pix_per_block + tp;
+    const long long total = (long long)B * H * Wd;
+    if (pix >= total) return;
+    const int b = (int)(pix / (H * Wd));
+    const int rem = (int)(pix - (long long)b * H * Wd);
+    const int oy = rem / Wd, ox = rem - oy * Wd;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            if ((unsigned)ix >= (unsigned)Wd) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float v = x[(((long long)b * Cin + ci) * H + iy) * Wd + ix];
+                const float* wr = wl + ((ky * 3 + kx) * Cin + ci) * Cout + c8 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v * wr[e];
+            }
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    *(half8*)(out + pix * Cout + c8 * 8) = o;
+}
+
+extern "C" int ief_conv_in_f32(const float* x, const ief_half* w, const float* bias, ief_half* out,
+                               int B, int Cin, int H, int Wd, int Cout, void* stream) {
+    if (!x || !w || !out) return IEF_EINVAL;
+    if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cin > CIN_MAX || Cout <= 0 || (Cout & 7) || Cout > 2048) return IEF_ESHAPE;
+    const size_t lds = (size_t)9 * Cin * Cout * sizeof(float);
+    if (lds > 64 * 1024) return IEF_ESHAPE;
+    const int C8 = Cout / 8;
+    const int ppb = 256 / C8 > 0 ? 256 / C8 : 1;
+    const long long total = (long long)B * H * Wd;
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), lds, (hipStream_t)stream, x, w,
+                       bias, out, B, Cin, H, Wd, Cout);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// 16 lanes per output pixel split the 9*C reduction (8-channel chunks round-robin), shuffle-reduce.
+__global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       int B, int C, int H, int Wd, int Cout) {
+    const int sub = threadIdx.x & 15;
+    const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long total = (long long)B * H * Wd;
+    const bool live = pix < total;
+    const long long pc = live ? pix : 0;
+    const int b = (int)(pc / (H * Wd));
+    const int rem = (int)(pc - (long long)b * H * Wd);
+    const int oy = rem / Wd, ox = rem - oy * Wd;
+    const int C8 = C >> 3;
+    float acc[COUT_MAX];
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+    if (live) {
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
+            const half_t* xp = x + (((long long)b * H + iy) * Wd + ix) * C;
+            for (int c8 = sub; c8 < C8; c8 += 16) {
+                const half8 v = *(const half8*)(xp + c8 * 8);
+#pragma unroll
+                for (int o = 0; o < COUT_MAX; ++o) {
+                    if (o < Cout) {
+                        const half8 wv = *(const half8*)(w + ((long long)o * 9 + tap) * C + c8 * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[o] += (float)v[e] * (float)wv[e];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+    }
+    if (live && sub == 0) {
+        for (int o = 0; o < Cout; ++o)
+            out[(((long long)b * Cout + o) * H + oy) * Wd + ox] = acc[o] + (bias ? bias[o] : 0.f);
+    }
+}
+
+extern "C" int ief_conv_out_f32(const ief_half* x, const ief_half* w, const float* bias, float* out,
+                                int B, int C, int H, int Wd, int Cout, void* stream) {
+    if (!x || !w || !out) return IEF_EINVAL;
+    if (B <= 0 || H <= 0 || Wd <= 0 || C <= 0 || (C & 7) || Cout <= 0 || Cout > COUT_MAX) return IEF_ESHAPE;
+    const long long total = (long long)B * H * Wd;
+    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       out, B, C, H, Wd, Cout);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}

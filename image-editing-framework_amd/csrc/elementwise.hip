@@ -1,0 +1,127 @@
+// Small latency-bound kernels of the sampler loop: CFG + DDIM update, timestep embedding,
+// SiLU, casts, and the per-step table select that lets ONE captured graph serve all 50 steps.
+#include "ief_common.h"
+#include "ief_params.h"
+
+// eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-a_f) eps) / sqrt(a_f);  x' = sqrt(a_t) x0 + sqrt(1-a_t) eps
+// Same operation order as the reference's scheduler.step / ddim_reverse so fp32 results stay
+// within an ulp or two of the eager formula (/root/reference/p2p/model/sd_utils.py:74-76,
+// /root/reference/p2p/inversion/ddim.py:14-17).
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ eu, const float* __restrict__ ec,
+                                                       const float* __restrict__ x, float* __restrict__ xo,
+                                                       float* __restrict__ x0o, const float* __restrict__ coef,
+                                                       long long n) {
+    const float a_f = coef[0], a_t = coef[1], g = coef[2];
+    const float sb_f = sqrtf(1.0f - a_f), sa_f = sqrtf(a_f), sa_t = sqrtf(a_t), sb_t = sqrtf(1.0f - a_t);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float e = ec[i];
+        if (eu) { const float u = eu[i]; e = u + g * (e - u); }
+        const float x0 = (x[i] - sb_f * e) / sa_f;
+        if (x0o) x0o[i] = x0;
+        xo[i] = sa_t * x0 + sb_t * e;
+    }
+}
+
+extern "C" int ief_cfg_ddim_step_f32(const float* eps_u, const float* eps_c, const float* x, float* x_out,
+                                     float* x0_out, const float* coef, long long n, void* stream) {
+    if (!eps_c || !x || !x_out || !coef) return IEF_EINVAL;
+    if (n <= 0) return IEF_ESHAPE;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, eps_u, eps_c, x, x_out, x0_out,
+                       coef, n);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) [ext]: [cos | sin]
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, half_t* __restrict__ out, int B, int dim) {
+    const int half_dim = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half_dim) return;
+    const int b = i / half_dim, k = i - b * half_dim;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half_dim);  // ln(10000)
+    const float a = t[b] * freq;
+    out[(long long)b * dim + k] = (half_t)cosf(a);
+    out[(long long)b * dim + half_dim + k] = (half_t)sinf(a);
+}
+
+extern "C" int ief_timestep_embedding_f16(const float* t, ief_half* out, int B, int dim, void* stream) {
+    if (!t || !out) return IEF_EINVAL;
+    if (B <= 0 || dim <= 0 || (dim & 1)) return IEF_ESHAPE;
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, dim);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = (half_t)silu_f((float)x[i]);
+}
+extern "C" int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void* stream) {
+    if (!x || !out) return IEF_EINVAL;
+    if (n <= 0) return IEF_ESHAPE;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(silu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, half_t* __restrict__ o, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = (half_t)x[i];
+}
+__global__ __launch_bounds__(256) void cast_f16_f32_kernel(const half_t* __restrict__ x, float* __restrict__ o, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = (float)x[i];
+}
+extern "C" int ief_cast_f32_to_f16(const float* x, ief_half* out, long long n, void* stream) {
+    if (!x || !out) return IEF_EINVAL;
+    if (n <= 0) return IEF_ESHAPE;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+extern "C" int ief_cast_f16_to_f32(const ief_half* x, float* out, long long n, void* stream) {
+    if (!x || !out) return IEF_EINVAL;
+    if (n <= 0) return IEF_ESHAPE;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// out[:] = table[step[0]][:]   (4-byte words).  Step-dependent inputs of the UNet (time-embedding
+// projections, P2P gate coefficients, self-replace source maps, DDIM alphas) live in per-step
+// tables; this copy runs INSIDE the captured graph and reads the step index from device memory.
+__global__ __launch_bounds__(256) void select_step_kernel(const uint32_t* __restrict__ table, uint32_t* __restrict__ out,
+                                                          const int* __restrict__ step, long long words) {
+    const long long base = (long long)step[0] * words;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256)
+        out[i] = table[base + i];
+}
+extern "C" int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, void* stream) {
+    if (!table || !out || !step) return IEF_EINVAL;
+    if (bytes_per_step <= 0 || (bytes_per_step & 3)) return IEF_EALIGN;
+    const long long words = bytes_per_step / 4;
+    int grid = (int)((words + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(select_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)table,
+                       (uint32_t*)out, step, words);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+__global__ void advance_step_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+extern "C" int ief_advance_step(int* step, void* stream) {
+    if (!step) return IEF_EINVAL;
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+extern "C" int ief_abi_version(void) { return IEF_ABI_VERSION; }
+extern "C" const char* ief_target_arch(void) { return "gfx950"; }

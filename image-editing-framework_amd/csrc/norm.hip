@@ -1,0 +1,223 @@
+// HBM-bound normalisation kernels (fp16 storage, fp32 statistics), 16-byte vector accesses.
+//
+//   GroupNorm(32) [+ SiLU] over NHWC      ResnetBlock2D.norm1/norm2 + nonlinearity
+//                                          (/root/reference/pnp/model/register.py:105-110,149-158)
+//   LayerNorm over C                       BasicTransformerBlock.norm1/2/3 [ext diffusers]
+//   GEGLU                                  FeedForward.net[0] [ext diffusers]
+//
+// GroupNorm is two launches: (1) per-(batch, pixel-split) partial sums per group, written to a
+// scratch slab (no atomics: deterministic, nothing to zero), (2) normalise + affine + SiLU.
+// A thread always owns the same 8-channel chunk, so group membership is resolved once.
+#include "ief_common.h"
+#include "ief_params.h"
+
+#define GN_MAX_GROUPS 64
+
+static inline int gn_splits_host(int HW) {
+    int s = HW / 64;
+    if (s < 1) s = 1;
+    if (s > 32) s = 32;
+    return s;
+}
+extern "C" int ief_gn_splits(int HW) { return gn_splits_host(HW); }
+
+__device__ __forceinline__ half8 load_cat8(const half_t* x, const half_t* x2, int C1, int C2, long long pix, int c) {
+    // channel chunk c..c+7 of pixel `pix` of the virtual concat [C1 | C2]; C1 % 8 == 0
+    if (c < C1) return *(const half8*)(x + pix * C1 + c);
+    return *(const half8*)(x2 + pix * C2 + (c - C1));
+}
+
+// grid (splits, B); block (C/8 rounded up to 64, PY) with PY pixel lanes
+__global__ void gn_stats_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int C1, int C2,
+                                float* __restrict__ partial, int HW, int groups, int splits) {
+    const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    __shared__ float gsum[GN_MAX_GROUPS], gsq[GN_MAX_GROUPS];
+    const int t = py * blockDim.x + cx;
+    if (t < GN_MAX_GROUPS) { gsum[t] = 0.f; gsq[t] = 0.f; }
+    __syncthreads();
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = sp * per, p1 = min(HW, p0 + per);
+    if (cx < C8) {
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (int p = p0 + py; p < p1; p += PY) {
+            const half8 v = load_cat8(x, x2, C1, C2, (long long)b * HW + p, cx * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+        }
+        // fold the 8 channels into (at most 2..8) groups, then LDS atomics (few per thread)
+        int g_prev = (cx * 8) / cpg;
+        float as = 0.f, aq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (cx * 8 + e) / cpg;
+            if (g != g_prev) { atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq); as = 0.f; aq = 0.f; g_prev = g; }
+            as += s[e]; aq += q[e];
+        }
+        atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq);
+    }
+    __syncthreads();
+    if (t < groups) {
+        float* o = partial + (((long long)b * splits + sp) * groups + t) * 2;
+        o[0] = gsum[t]; o[1] = gsq[t];
+    }
+}
+
+// grid (ceil(HW / PIX_PER_BLOCK), B); block 256; each thread walks (pixel, chunk) pairs
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2,
+                                                       int C1, int C2, half_t* __restrict__ out,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ partial, int HW, int groups,
+                                                       int splits, float eps, int apply_silu, int pix_per_block) {
+    const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y;
+    __shared__ float mean_s[GN_MAX_GROUPS], rstd_s[GN_MAX_GROUPS];
+    if (threadIdx.x < groups) {
+        float s = 0.f, q = 0.f;
+        for (int sp = 0; sp < splits; ++sp) {
+            const float* o = partial + (((long long)b * splits + sp) * groups + threadIdx.x) * 2;
+            s += o[0]; q += o[1];
+        }
+        const float inv = 1.0f / ((float)cpg * (float)HW);
+        const float m = s * inv;
+        const float var = fmaxf(q * inv - m * m, 0.f);
+        mean_s[threadIdx.x] = m;
+        rstd_s[threadIdx.x] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    const long long total = (long long)(p1 - p0) * C8;
+    for (long long i = threadIdx.x; i < total; i += 256) {
+        const int p = p0 + (int)(i / C8), c = (int)(i % C8) * 8;
+        const long long pix = (long long)b * HW + p;
+        const half8 v = load_cat8(x, x2, C1, C2, pix, c);
+        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / cpg;
+            const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+            float y = ((float)v[e] - mean_s[g]) * rstd_s[g] * ga + be;
+            if (apply_silu) y = silu_f(y);
+            o[e] = (half_t)y;
+        }
+        *(half8*)(out + pix * C + c) = o;
+    }
+}
+
+extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int C1, int C2, ief_half* out,
+                                      const float* gamma, const float* beta, float* partial,
+                                      int B, int HW, int groups, float eps, int apply_silu, void* stream) {
+    if (!x || !out || !gamma || !beta || !partial) return IEF_EINVAL;
+    if (C2 > 0 && !x2) return IEF_EINVAL;
+    const int C = C1 + C2;
+    if (B <= 0 || HW <= 0 || groups <= 0 || groups > GN_MAX_GROUPS) return IEF_ESHAPE;
+    if ((C1 & 7) || (C2 & 7) || (C % groups) || C > 8 * 1024) return IEF_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = gn_splits_host(HW);
+    const int C8 = C / 8;
+    int bx = ((C8 + 63) / 64) * 64;
+    int by = 1024 / bx;
+    if (by < 1) by = 1;
+    if (by > 8) by = 8;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, B), dim3(bx, by), 0, st, x, x2, C1, C2, partial, HW, groups, splits);
+    IEF_LAUNCH_CHECK();
+    // ~2048 blocks over the chip: pixels per block so that grid.x * B is about that
+    int ppb = (int)(((long long)HW * B + 2047) / 2048);
+    if (ppb < 1) ppb = 1;
+    const int gx = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, x2, C1, C2, out, gamma, beta, partial, HW,
+                       groups, splits, eps, apply_silu, ppb);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// one wave per row; row kept in registers (C <= 8 * 64 * LN_MAXCH)
+#define LN_MAXCH 4
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, C8 = C >> 3;
+    half8 v[LN_MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < C8) {
+            v[i] = *(const half8*)(x + (long long)row * C + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int c8 = lane + 64 * i;
+        if (c8 < C8) {
+            const int c = c8 * 8;
+            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+                o[e] = (half_t)(((float)v[i][e] - mean) * rstd * ga + be);
+            }
+            *(half8*)(out + (long long)row * C + c) = o;
+        }
+    }
+}
+
+extern "C" int ief_layernorm_f16(const ief_half* x, ief_half* out, const float* gamma, const float* beta,
+                                 int rows, int C, float eps, void* stream) {
+    if (!x || !out || !gamma || !beta) return IEF_EINVAL;
+    if (rows <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * LN_MAXCH) return IEF_ESHAPE;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, gamma, beta,
+                       rows, C, eps);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+__global__ __launch_bounds__(256) void geglu_kernel(const half_t* __restrict__ in, half_t* __restrict__ out,
+                                                    long long rows, int Ch) {
+    const int C8 = Ch >> 3;
+    const long long total = rows * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C8;
+        const int c = (int)(i % C8) * 8;
+        const half8 h = *(const half8*)(in + r * 2 * Ch + c);
+        const half8 g = *(const half8*)(in + r * 2 * Ch + Ch + c);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)h[e] * gelu_f((float)g[e]));
+        *(half8*)(out + r * Ch + c) = o;
+    }
+}
+
+extern "C" int ief_geglu_f16(const ief_half* in, ief_half* out, int rows, int Ch, void* stream) {
+    if (!in || !out) return IEF_EINVAL;
+    if (rows <= 0 || Ch <= 0 || (Ch & 7)) return IEF_ESHAPE;
+    const long long total = (long long)rows * (Ch / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(geglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, (long long)rows, Ch);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}

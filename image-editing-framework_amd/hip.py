@@ -1,0 +1,460 @@
+"""ctypes binding of `libief_hip.so` (C-ABI in `include/ief_hip.h`).
+
+This is the ONLY route from the host code to compute: every function below launches a
+hand-written gfx950 kernel on torch's current HIP stream, with torch tensors used purely as
+device-memory handles (`data_ptr()`).  There is no CPU or eager-PyTorch fallback: if the library
+is missing, or a tensor is not an fp16/fp32 device tensor of the documented layout, the call raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_longlong, c_void_p
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libief_hip.so")
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class IefGemmParams(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("A2", c_void_p), ("W", c_void_p), ("Out", c_void_p),
+        ("bias", c_void_p), ("rowvec", c_void_p), ("residual", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldw", c_int), ("ldo", c_int), ("ldr", c_int),
+        ("strideA", c_longlong), ("strideW", c_longlong), ("strideO", c_longlong), ("strideR", c_longlong),
+        ("H", c_int), ("Wd", c_int), ("C1", c_int), ("C2", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("stride", c_int), ("ups", c_int), ("batch_images", c_int),
+        ("rows_per_batch", c_int), ("out_scale", c_float), ("tile_hint", c_int),
+    ]
+
+
+class IefAttnParams(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("Out", c_void_p),
+        ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int),
+        ("scale", c_float),
+        ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p),
+    ]
+
+
+class IefCrossParams(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("Out", c_void_p),
+        ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int),
+        ("scale", c_float),
+        ("edit_src", c_void_p), ("edit_slot", c_void_p), ("MT", c_void_p), ("coef", c_void_p),
+    ]
+
+
+EXPORTS = [
+    "ief_abi_version", "ief_target_arch", "ief_gemm_f16", "ief_conv3x3_f16", "ief_conv_in_f32",
+    "ief_conv_out_f32", "ief_gn_splits", "ief_groupnorm_silu_f16", "ief_layernorm_f16", "ief_geglu_f16",
+    "ief_attn_flash_f16", "ief_attn_cross_p2p_f16", "ief_attn_probs_f16", "ief_attn_apply_f16",
+    "ief_cfg_ddim_step_f32", "ief_timestep_embedding_f16", "ief_silu_f16", "ief_cast_f32_to_f16",
+    "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step",
+]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once).  Raises HipExtensionMissing when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipExtensionMissing(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C image-editing-framework_amd/csrc`).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError here = header / library mismatch
+    lib.ief_abi_version.restype = c_int
+    lib.ief_target_arch.restype = c_char_p
+    lib.ief_gn_splits.restype = c_int
+    lib.ief_gn_splits.argtypes = [c_int]
+    lib.ief_gemm_f16.argtypes = [POINTER(IefGemmParams), c_int, c_void_p]
+    lib.ief_conv3x3_f16.argtypes = [POINTER(IefGemmParams), c_void_p]
+    lib.ief_conv_in_f32.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p]
+    lib.ief_conv_out_f32.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p]
+    lib.ief_groupnorm_silu_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_float, c_int, c_void_p]
+    lib.ief_layernorm_f16.argtypes = [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]
+    lib.ief_geglu_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.ief_attn_flash_f16.argtypes = [POINTER(IefAttnParams), c_void_p]
+    lib.ief_attn_cross_p2p_f16.argtypes = [POINTER(IefCrossParams), c_void_p]
+    lib.ief_attn_probs_f16.argtypes = [POINTER(IefAttnParams), c_void_p, c_void_p]
+    lib.ief_attn_apply_f16.argtypes = [POINTER(IefAttnParams), c_void_p, c_void_p]
+    lib.ief_cfg_ddim_step_f32.argtypes = [c_void_p] * 6 + [c_longlong, c_void_p]
+    lib.ief_timestep_embedding_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.ief_silu_f16.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_cast_f32_to_f16.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_cast_f16_to_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_select_step.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_advance_step.argtypes = [c_void_p, c_void_p]
+    if lib.ief_abi_version() != 1:
+        raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "IEF_EINVAL (null / missing pointer)", -2: "IEF_ESHAPE (unsupported shape)", -3: "IEF_EALIGN (alignment)"}
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, f'hipError {rc}')}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev16(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float16):
+        raise TypeError(f"{name}: expected an fp16 device tensor, got "
+                        f"{type(t).__name__ if not isinstance(t, torch.Tensor) else (t.dtype, t.device)}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+    return t
+
+
+def _dev32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError(f"{name}: expected a contiguous fp32 device tensor")
+    return t
+
+
+def _devi32(t, name):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise TypeError(f"{name}: expected a contiguous int32 device tensor")
+    return t
+
+
+def _rows_ld(t, name):
+    """(rows, cols, ld) of a 2-D/3-D tensor whose leading dims collapse to rows with one stride."""
+    _dev16(t, name)
+    cols = t.shape[-1]
+    ld = t.stride(-2) if t.dim() >= 2 else cols
+    rows = 1
+    for s in t.shape[:-1]:
+        rows *= s
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld:
+        raise ValueError(f"{name}: batch stride must equal rows * ld")
+    return rows, cols, ld
+
+
+# ------------------------------------------------------------------------------- GEMM / conv
+def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0):
+    """out[..., n] = (a[..., :] . w[n, :] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale
+
+    a: fp16 [..., K] (last dim contiguous, uniform row stride); w: fp16 [N, K]; bias/rowvec fp32.
+    """
+    lib = load()
+    M, K, lda = _rows_ld(a, "a")
+    _dev16(w, "w")
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: K mismatch {w.shape[1]} vs {K}")
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, dtype=torch.float16, device=a.device)
+    Mo, No, ldo = _rows_ld(out, "out")
+    if (Mo, No) != (M, N):
+        raise ValueError("gemm: out shape mismatch")
+    p = IefGemmParams()
+    p.A, p.W, p.Out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
+    p.rowvec = _ptr(_dev32(rowvec, "rowvec")) if rowvec is not None else None
+    if residual is not None:
+        Mr, Nr, ldr = _rows_ld(residual, "residual")
+        if (Mr, Nr) != (M, N):
+            raise ValueError("gemm: residual shape mismatch")
+        p.residual, p.ldr = residual.data_ptr(), ldr
+    p.M, p.N, p.K = M, N, K
+    p.lda, p.ldw, p.ldo = lda, w.stride(0), ldo
+    p.rows_per_batch = rows_per_batch
+    p.out_scale = out_scale
+    p.tile_hint = tile_hint
+    _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
+    return out
+
+
+def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0):
+    """3x3 / pad 1 convolution over NHWC fp16.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat),
+    w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather."""
+    lib = load()
+    _dev16(x, "x")
+    _dev16(w, "w")
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()) or not w.is_contiguous():
+        raise ValueError("conv3x3: x, x2, w must be contiguous")
+    B, Hp, Wp, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    if x2 is not None and tuple(x2.shape[:3]) != (B, Hp, Wp):
+        raise ValueError("conv3x3: x2 spatial shape mismatch")
+    Cout = w.shape[0]
+    if tuple(w.shape[1:]) != (3, 3, C1 + C2):
+        raise ValueError(f"conv3x3: weight shape {tuple(w.shape)} does not match C1+C2={C1 + C2}")
+    H, Wd = (Hp * 2, Wp * 2) if upsample else (Hp, Wp)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16, device=x.device)
+    p = IefGemmParams()
+    p.A, p.A2, p.W, p.Out = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
+    p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
+    p.rowvec = _ptr(_dev32(rowvec, "rowvec")) if rowvec is not None else None
+    if residual is not None:
+        _dev16(residual, "residual")
+        if tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
+            raise ValueError("conv3x3: residual must match the output and be contiguous")
+        p.residual, p.ldr = residual.data_ptr(), Cout
+    p.N, p.ldo = Cout, Cout
+    p.H, p.Wd, p.C1, p.C2 = H, Wd, C1, C2
+    p.stride, p.ups, p.batch_images = stride, 1 if upsample else 0, B
+    p.out_scale = 1.0
+    p.tile_hint = tile_hint
+    _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
+    return out
+
+
+def conv_in(x, w, bias, out=None):
+    """latent fp32 NCHW [B,Cin,H,W] -> fp16 NHWC [B,H,W,Cout]; w fp16 [Cout,3,3,Cin]."""
+    lib = load()
+    _dev32(x, "x")
+    _dev16(w, "w")
+    B, Cin, H, Wd = x.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty(B, H, Wd, Cout, dtype=torch.float16, device=x.device)
+    _check(lib.ief_conv_in_f32(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), B, Cin, H, Wd, Cout, _stream()),
+           "ief_conv_in_f32")
+    return out
+
+
+def conv_out(x, w, bias, out=None):
+    """fp16 NHWC [B,H,W,C] -> fp32 NCHW [B,Cout,H,W]; w fp16 [Cout,3,3,C]."""
+    lib = load()
+    _dev16(x, "x")
+    _dev16(w, "w")
+    B, H, Wd, C = x.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty(B, Cout, H, Wd, dtype=torch.float32, device=x.device)
+    _check(lib.ief_conv_out_f32(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), B, C, H, Wd, Cout, _stream()),
+           "ief_conv_out_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------- norms
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
+    """GroupNorm over NHWC / tokens-major fp16 [B, ..., C] (+ optional channel-concat x2), optional SiLU."""
+    lib = load()
+    _dev16(x, "x")
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("groupnorm: inputs must be contiguous")
+    B, C1 = x.shape[0], x.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    HW = x.numel() // (B * C1)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float16, device=x.device)
+    splits = lib.ief_gn_splits(HW)
+    partial = torch.empty(B * splits * groups * 2, dtype=torch.float32, device=x.device)
+    _check(lib.ief_groupnorm_silu_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                      _dev32(beta, "beta").data_ptr(), partial.data_ptr(), B, HW, groups, eps,
+                                      1 if silu else 0, _stream()), "ief_groupnorm_silu_f16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    lib = load()
+    _dev16(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("layernorm: x must be contiguous")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib.ief_layernorm_f16(x.data_ptr(), out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                 _dev32(beta, "beta").data_ptr(), rows, C, eps, _stream()), "ief_layernorm_f16")
+    return out
+
+
+def geglu(x, out=None):
+    lib = load()
+    _dev16(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("geglu: x must be contiguous")
+    Ch = x.shape[-1] // 2
+    rows = x.numel() // (2 * Ch)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], Ch, dtype=torch.float16, device=x.device)
+    _check(lib.ief_geglu_f16(x.data_ptr(), out.data_ptr(), rows, Ch, _stream()), "ief_geglu_f16")
+    return out
+
+
+# ------------------------------------------------------------------------------- attention
+def _attn_common(p, q, k, v, out, heads):
+    B, N, _ = q.shape
+    L = k.shape[1]
+    d = out.shape[-1] // heads
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        _dev16(t, nm)
+        if t.dim() != 3:
+            raise ValueError(f"{nm}: expected [B, rows, heads*d]")
+        if t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1):
+            raise ValueError(f"{nm}: batch stride must equal rows * ld")
+    p.Q, p.K, p.V, p.Out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    p.B, p.heads, p.N, p.L, p.d = B, heads, N, L, d
+    p.ldq, p.ldk, p.ldv, p.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+
+
+def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None):
+    """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok)."""
+    lib = load()
+    if out is None:
+        out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)
+    p = IefAttnParams()
+    _attn_common(p, q, k, v, out, heads)
+    p.scale = scale
+    p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
+    _check(lib.ief_attn_flash_f16(byref(p), _stream()), "ief_attn_flash_f16")
+    return out
+
+
+def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None, coef=None, out=None):
+    """Cross-attention (<= 96 keys) with the fused Prompt-to-Prompt map edit (see include/ief_hip.h)."""
+    lib = load()
+    if out is None:
+        out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)
+    p = IefCrossParams()
+    _attn_common(p, q, k, v, out, heads)
+    p.scale = scale
+    p.edit_src, p.edit_slot = _ptr(_devi32(edit_src, "edit_src")), _ptr(_devi32(edit_slot, "edit_slot"))
+    if edit_src is not None:
+        _dev16(mt, "mt")
+        _dev32(coef, "coef")
+        if tuple(mt.shape[-2:]) != (96, 96) or not mt.is_contiguous() or coef.shape[-1] != 96:
+            raise ValueError("attn_cross_p2p: mt must be [slots,96,96] fp16, coef [slots,2,96] fp32")
+        p.MT, p.coef = mt.data_ptr(), coef.data_ptr()
+    _check(lib.ief_attn_cross_p2p_f16(byref(p), _stream()), "ief_attn_cross_p2p_f16")
+    return out
+
+
+def attn_probs(q, k, heads, scale):
+    """materialised maps [B*heads, N, L] fp16 for the generic controller path."""
+    lib = load()
+    B, N, C = q.shape
+    L = k.shape[1]
+    probs = torch.empty(B * heads, N, L, dtype=torch.float16, device=q.device)
+    p = IefAttnParams()
+    _attn_common(p, q, k, k, q, heads)
+    p.scale = scale
+    _check(lib.ief_attn_probs_f16(byref(p), probs.data_ptr(), _stream()), "ief_attn_probs_f16")
+    return probs
+
+
+def attn_apply(probs, v, heads, out=None):
+    """out [B,N,h*d] = probs [B*heads,N,L] @ v [B,L,h*d]."""
+    lib = load()
+    _dev16(probs, "probs")
+    if not probs.is_contiguous():
+        raise ValueError("attn_apply: probs must be contiguous")
+    B = v.shape[0]
+    N, L = probs.shape[1], probs.shape[2]
+    if probs.shape[0] != B * heads or v.shape[1] != L:
+        raise ValueError("attn_apply: shape mismatch")
+    if out is None:
+        out = torch.empty(B, N, v.shape[2], dtype=torch.float16, device=v.device)
+    p = IefAttnParams()
+    _attn_common(p, out, v, v, out, heads)
+    p.N, p.L = N, L
+    _check(lib.ief_attn_apply_f16(byref(p), probs.data_ptr(), _stream()), "ief_attn_apply_f16")
+    return out
+
+
+# ------------------------------------------------------------------------------- sampler
+def cfg_ddim_step(eps_u, eps_c, x, coef, out=None, x0_out=None):
+    """x' from (eps_u, eps_c, x) with coef = device fp32 [a_from, a_to, guidance]; eps_u None => no CFG."""
+    lib = load()
+    _dev32(eps_c, "eps_c")
+    _dev32(x, "x")
+    _dev32(coef, "coef")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib.ief_cfg_ddim_step_f32(_ptr(eps_u), eps_c.data_ptr(), x.data_ptr(), out.data_ptr(), _ptr(x0_out),
+                                     coef.data_ptr(), x.numel(), _stream()), "ief_cfg_ddim_step_f32")
+    return out
+
+
+def ddim_step(eps, x, a_from: float, a_to: float):
+    """scheduler.step on device tensors: returns (x_prev, x0)."""
+    coef = torch.tensor([a_from, a_to, 1.0], dtype=torch.float32, device=x.device)
+    x0 = torch.empty_like(x, dtype=torch.float32)
+    xf = x.float().contiguous()
+    out = cfg_ddim_step(None, eps.float().contiguous(), xf, coef, x0_out=x0)
+    return out, x0
+
+
+def timestep_embedding(t, dim):
+    lib = load()
+    _dev32(t, "t")
+    out = torch.empty(t.shape[0], dim, dtype=torch.float16, device=t.device)
+    _check(lib.ief_timestep_embedding_f16(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream()),
+           "ief_timestep_embedding_f16")
+    return out
+
+
+def silu(x):
+    lib = load()
+    _dev16(x, "x")
+    out = torch.empty_like(x)
+    _check(lib.ief_silu_f16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ief_silu_f16")
+    return out
+
+
+def to_f16(x, out=None):
+    lib = load()
+    _dev32(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _check(lib.ief_cast_f32_to_f16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ief_cast_f32_to_f16")
+    return out
+
+
+def to_f32(x, out=None):
+    lib = load()
+    _dev16(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _check(lib.ief_cast_f16_to_f32(x.contiguous().data_ptr(), out.data_ptr(), x.numel(), _stream()), "ief_cast_f16_to_f32")
+    return out
+
+
+def select_step(table, out, step):
+    """out[...] = table[step[0], ...] inside the stream (graph-capturable); step: device int32 [1]."""
+    lib = load()
+    nbytes = out.numel() * out.element_size()
+    if table[0].numel() * table.element_size() != nbytes or not table.is_contiguous() or not out.is_contiguous():
+        raise ValueError("select_step: table[step] and out must have identical contiguous byte size")
+    _check(lib.ief_select_step(table.data_ptr(), out.data_ptr(), _devi32(step, "step").data_ptr(), nbytes, _stream()),
+           "ief_select_step")
+    return out
+
+
+def advance_step(step):
+    lib = load()
+    _check(lib.ief_advance_step(_devi32(step, "step").data_ptr(), _stream()), "ief_advance_step")

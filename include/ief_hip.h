@@ -1,0 +1,157 @@
+/* C-ABI of libief_hip.so — the native boundary under the attention-controlled denoising path.
+ *
+ * The reference (AY-Liu/Image-Editing-Framework) has no native code and no FFI: its per-step
+ * compute is PyTorch/diffusers eager CUDA (last row).  This header is therefore
+ * the boundary a maintainer binds INSTEAD of those eager calls; each entry point cites the
+ * reference call site whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors in our host
+ *     code); outputs are caller-allocated; no entry point allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it (graph-capturable);
+ *   - return 0 on success, <0 for rejected arguments (IEF_E*), >0 = hipError_t of the launch;
+ *     nothing throws;
+ *   - ief_half = IEEE fp16 storage; all accumulation and statistics are fp32;
+ *   - activations are channels-last: [B, H, W, C] == tokens-major [B, H*W, C].
+ */
+#ifndef IEF_HIP_H
+#define IEF_HIP_H
+#include <stdint.h>
+
+#ifdef __HIPCC__
+typedef _Float16 ief_half;
+#else
+typedef uint16_t ief_half;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IEF_ABI_VERSION 1
+int ief_abi_version(void);
+/* name of the code object's target, e.g. "gfx950" */
+const char* ief_target_arch(void);
+
+/* ------------------------------------------------------------------ GEMM / conv3x3
+ * Out[m][n] = ( sum_k A(m,k) W[n][k] + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n] ) * out_scale
+ * replaces: Attention.to_q/to_k/to_v/to_out, proj_in/proj_out, FF linears
+ *           (/root/reference/p2p/model/register.py:33,40,41,54) and ResnetBlock2D.conv1/conv2/
+ *           conv_shortcut + temb add + skip add (/root/reference/pnp/model/register.py:139-175).
+ */
+typedef struct IefGemmParams {
+    const ief_half* A;        /* dense: [M][lda];  conv: NHWC source 1, C1 channels      */
+    const ief_half* A2;       /* conv only: NHWC source 2 (channel concat), C2 channels  */
+    const ief_half* W;        /* [N][ldw], K contiguous; conv: [Cout][3][3][C1+C2]        */
+    ief_half* Out;            /* [M][ldo]                                                 */
+    const float* bias;        /* [N] or NULL                                              */
+    const float* rowvec;      /* [M / rows_per_batch][N] or NULL                          */
+    const ief_half* residual; /* [M][ldr] or NULL                                         */
+    int M, N, K;
+    int lda, ldw, ldo, ldr;
+    long long strideA, strideW, strideO, strideR; /* per batch index (dense, blockIdx.z) */
+    /* conv3x3 geometry (pad 1): logical input H x Wd (after the optional 2x upsample) */
+    int H, Wd, C1, C2, Ho, Wo, stride, ups, batch_images;
+    int rows_per_batch;
+    float out_scale;
+    int tile_hint;            /* 0 auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64       */
+} IefGemmParams;
+
+int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);
+/* fills M, K, ldw, Ho, Wo, rows_per_batch itself from the geometry fields */
+int ief_conv3x3_f16(const IefGemmParams* p, void* stream);
+
+/* conv_in: latent NCHW fp32 [B,Cin,H,W] (Cin<=8) -> NHWC fp16 [B,H,W,Cout]; W [Cout][3][3][Cin] fp16.
+ * conv_out: NHWC fp16 [B,H,W,C] -> NCHW fp32 [B,Cout,H,W] (Cout<=8); W [Cout][3][3][C] fp16.
+ * (UNet2DConditionModel.conv_in / conv_out, called at /root/reference/p2p/model/sd_utils.py:73) */
+int ief_conv_in_f32(const float* x, const ief_half* w, const float* bias, ief_half* out,
+                    int B, int Cin, int H, int Wd, int Cout, void* stream);
+int ief_conv_out_f32(const ief_half* x, const ief_half* w, const float* bias, float* out,
+                     int B, int C, int H, int Wd, int Cout, void* stream);
+
+/* ------------------------------------------------------------------ normalisation
+ * GroupNorm over NHWC (+ optional SiLU): ResnetBlock2D.norm1/norm2 + nonlinearity
+ * (/root/reference/pnp/model/register.py:105-110,149-158), Transformer2DModel.norm, conv_norm_out.
+ * `partial` is scratch of >= B * splits * groups * 2 floats (splits = ief_gn_splits(HW)).
+ * Two sources (x, x2) = channel concat [C1 | C2] normalised as one tensor, written to out [.., C1+C2].
+ */
+int ief_gn_splits(int HW);
+int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int C1, int C2, ief_half* out,
+                           const float* gamma, const float* beta, float* partial,
+                           int B, int HW, int groups, float eps, int apply_silu, void* stream);
+/* LayerNorm over the last dim of [rows][C] (BasicTransformerBlock.norm1/2/3) */
+int ief_layernorm_f16(const ief_half* x, ief_half* out, const float* gamma, const float* beta,
+                      int rows, int C, float eps, void* stream);
+/* GEGLU: in [rows][2*Ch] = [hidden | gate] -> out [rows][Ch] = hidden * gelu(gate) (erf form) */
+int ief_geglu_f16(const ief_half* in, ief_half* out, int rows, int Ch, void* stream);
+
+/* ------------------------------------------------------------------ attention
+ * Fused softmax(Q K^T * scale) V, never materialising the map (flash-style), with per-batch
+ * indirection of the Q / K / V source rows.  Identity maps = plain attention
+ * (/root/reference/p2p/model/register.py:47-50 when the controller leaves the map alone).
+ * q_src/k_src/v_src: DEVICE int32 [B] or NULL; out[b] = softmax(Q[q_src[b]] K[k_src[b]]^T) V[v_src[b]]:
+ *   - P2P self-attention replace (attention_base.py:123,132-136): target rows take q_src = k_src = source row;
+ *   - MasaCtrl mutual self-attention (/root/reference/masactrl/model/attention_control.py:59-66): k_src = v_src = source row.
+ * Q [B][N][ldq], K/V [B][L][ldk/ldv], head h at columns [h*d, (h+1)*d); out [B][N][ldo].  d in {32,40,64,80,160}.
+ */
+typedef struct IefAttnParams {
+    const ief_half* Q; const ief_half* K; const ief_half* V; ief_half* Out;
+    int B, heads, N, L, d;
+    int ldq, ldk, ldv, ldo;
+    float scale;
+    const int* q_src; const int* k_src; const int* v_src;
+} IefAttnParams;
+int ief_attn_flash_f16(const IefAttnParams* p, void* stream);
+
+/* Cross-attention with the Prompt-to-Prompt edit fused in (L <= 96 keys):
+ *   P = softmax(Q K^T scale);  for batch rows b with edit_src[b] >= 0:
+ *   P'[q][n] = c1[n] * sum_w P_src[q][w] M[w][n] + c2[n] * P_b[q][n];   out = P' V_b
+ * which covers AttentionControlEdit.forward's cross branch (attention_base.py:118-121) for
+ * replace (M = mapper, c1 = alpha_t, c2 = 1 - alpha_t; attention_control.py:15-16),
+ * refine  (M = one-hot gather of mapper, c1 = alpha_t a, c2 = 1 - alpha_t a; :28-31) and
+ * reweight (M = diag(equalizer) [x prev edit]; :42-46).
+ * edit_src/edit_slot: DEVICE int32 [B]; MT: fp16 [slots][96][96] = M transposed, zero padded;
+ * coef: fp32 [slots][2][96] = c1 | c2 of the CURRENT step.  All device memory so a captured
+ * graph follows the step-dependent gates without re-capture.
+ */
+typedef struct IefCrossParams {
+    const ief_half* Q; const ief_half* K; const ief_half* V; ief_half* Out;
+    int B, heads, N, L, d;
+    int ldq, ldk, ldv, ldo;
+    float scale;
+    const int* edit_src; const int* edit_slot;
+    const ief_half* MT; const float* coef;
+} IefCrossParams;
+int ief_attn_cross_p2p_f16(const IefCrossParams* p, void* stream);
+
+/* Generic hook path (materialised maps for arbitrary Python controllers / AttentionStore):
+ * probs [B*heads][N][L] fp16 = softmax(Q K^T scale)  (Attention.get_attention_scores,
+ * register.py:47) and out = probs V (torch.bmm + batch_to_head_dim, register.py:50-51). */
+int ief_attn_probs_f16(const IefAttnParams* p, ief_half* probs, void* stream);
+int ief_attn_apply_f16(const IefAttnParams* p, const ief_half* probs, void* stream);
+
+/* ------------------------------------------------------------------ sampler step
+ * Classifier-free guidance + DDIM update (or its inverse) in one launch:
+ *   eps = eps_u + g (eps_c - eps_u);  x0 = (x - sqrt(1-a_from) eps)/sqrt(a_from);
+ *   x' = sqrt(a_to) x0 + sqrt(1-a_to) eps
+ * (/root/reference/p2p/model/sd_utils.py:74-76; inverse: /root/reference/p2p/inversion/ddim.py:9-18).
+ * eps_u/eps_c/x/x_out fp32, n elements each; eps_u == NULL => eps = eps_c (no guidance).
+ * coef: DEVICE fp32 [3] = {a_from, a_to, guidance}; x0_out optional.
+ */
+int ief_cfg_ddim_step_f32(const float* eps_u, const float* eps_c, const float* x, float* x_out,
+                          float* x0_out, const float* coef, long long n, void* stream);
+/* sinusoidal timestep embedding, flip_sin_to_cos, shift 0: out fp16 [B][dim] = [cos | sin] */
+int ief_timestep_embedding_f16(const float* t, ief_half* out, int B, int dim, void* stream);
+/* y = silu(x) elementwise on fp16 (ResnetBlock2D time_emb_proj input) */
+int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void* stream);
+/* fp16 <-> fp32 casts and row gather used to stage per-step tables inside a captured graph:
+ * out[r][:] = table[idx[0] (device int32)][r][:], element size `esize` bytes, row bytes `rowbytes` */
+int ief_cast_f32_to_f16(const float* x, ief_half* out, long long n, void* stream);
+int ief_cast_f16_to_f32(const ief_half* x, float* out, long long n, void* stream);
+int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, void* stream);
+int ief_advance_step(int* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IEF_HIP_H */

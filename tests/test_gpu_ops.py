@@ -1,0 +1,341 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, called through the C-ABI, against the
+fp32 CPU oracle evaluated on the SAME fp16-rounded inputs.
+
+Tolerances (stated per op, relative to the output's own scale):
+  fp16 output rounding is 2^-11 = 4.9e-4 relative; fp32 accumulation order adds ~1e-6 * sqrt(K).
+  GEMM / conv / norms:   max|err| <= 2e-3 * max|ref| + 1e-3
+  attention (P in fp16): max|err| <= 4e-3 * max|ref| + 1e-3
+  DDIM/CFG (fp32):       max|err| <= 2e-6 * max|ref|
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from ief_amd import hip  # noqa: E402
+
+
+def dev(t):
+    return t.cuda()
+
+
+def h16(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+def f32(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, rel, abs_):
+    got = got.float().cpu()
+    ref = ref.float()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    bound = rel * ref.abs().max().item() + abs_
+    assert err <= bound, f"max err {err:.3e} > bound {bound:.3e}"
+    return err
+
+
+# ----------------------------------------------------------------------------- MFMA layout pin
+def test_gemm_identity_asymmetric():
+    """A = I with an ASYMMETRIC W catches swapped row/col fragment maps (guide §3)."""
+    K = N = 128
+    a = torch.eye(K).half()
+    w = (torch.arange(N)[:, None] * 0.01 + torch.arange(K)[None, :] * 1.0).half()  # w[n][k]
+    out = hip.gemm(dev(a), dev(w))
+    ref = a.float() @ w.float().t()
+    close(out, ref, 0, 1e-6 + 0.0)
+
+
+@pytest.mark.parametrize("M,N,K,hint", [
+    (256, 128, 64, 0), (16384, 320, 320, 0), (1024, 1280, 1280, 0), (308, 320, 768, 0),
+    (4096, 5120, 640, 0), (256, 1280, 5120, 0), (200, 136, 72, 1), (200, 136, 72, 2),
+    (200, 136, 72, 3), (200, 136, 72, 4), (4, 1280, 320, 0),
+])
+def test_gemm(M, N, K, hint):
+    a, w = h16(M, K, seed=1), h16(N, K, seed=2, scale=K ** -0.5)
+    bias = f32(N, seed=3, scale=0.1)
+    res = h16(M, N, seed=4)
+    out = hip.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res), tile_hint=hint)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    close(out, ref, 2e-3, 1e-3)
+
+
+def test_gemm_rowvec_scale_strided():
+    B, R, N, K = 3, 50, 64, 128
+    a_full = h16(B * R, K + 64, seed=5)
+    a = a_full[:, 32:32 + K]                       # row stride K+64, 64-byte aligned start
+    w = h16(N, K, seed=6, scale=K ** -0.5)
+    rv = f32(B, N, seed=7)
+    out_full = torch.zeros(B * R, 3 * N, dtype=torch.float16)
+    o_dev = dev(out_full)
+    hip.gemm(dev(a_full)[:, 32:32 + K], dev(w), rowvec=dev(rv), rows_per_batch=R, out=o_dev[:, N:2 * N], out_scale=0.5)
+    ref = (a.float() @ w.float().t() + rv.repeat_interleave(R, 0)) * 0.5
+    close(o_dev[:, N:2 * N], ref, 2e-3, 1e-3)
+    assert o_dev[:, :N].abs().max().item() == 0 and o_dev[:, 2 * N:].abs().max().item() == 0
+
+
+def _conv_ref(x, w, bias, stride=1, ups=False, x2=None, rowvec=None, res=None):
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    wt = w.float().permute(0, 3, 1, 2)  # [Cout,3,3,Cin] -> OIHW
+    y = F.conv2d(xin, wt, bias, stride=stride, padding=1)
+    if rowvec is not None:
+        y = y + rowvec[:, :, None, None]
+    y = y.permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + res.float()
+    return y
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,stride,ups", [
+    (2, 16, 16, 64, 0, 64, 1, False), (4, 64, 64, 320, 0, 320, 1, False), (2, 32, 32, 640, 320, 640, 1, False),
+    (2, 32, 32, 320, 0, 320, 2, False), (2, 8, 8, 1280, 0, 1280, 1, True), (1, 8, 8, 1280, 1280, 1280, 1, False),
+    (1, 12, 20, 128, 64, 192, 1, False), (1, 13, 9, 64, 0, 128, 2, False),
+])
+def test_conv3x3(B, H, W, C1, C2, Cout, stride, ups):
+    x = h16(B, H, W, C1, seed=1)
+    x2 = h16(B, H, W, C2, seed=2) if C2 else None
+    w = h16(Cout, 3, 3, C1 + C2, seed=3, scale=(9 * (C1 + C2)) ** -0.5)
+    bias = f32(Cout, seed=4, scale=0.1)
+    rv = f32(B, Cout, seed=5)
+    ref0 = _conv_ref(x, w, bias, stride, ups, x2, rv)
+    res = h16(*ref0.shape, seed=6)
+    out = hip.conv3x3(dev(x), dev(w), dev(bias), x2=None if x2 is None else dev(x2), stride=stride, upsample=ups,
+                      rowvec=dev(rv), residual=dev(res))
+    close(out, ref0 + res.float(), 2e-3, 1e-3)
+
+
+def test_conv_in_out():
+    B, H, W = 2, 24, 16
+    x = f32(B, 4, H, W, seed=1)
+    w = h16(320, 3, 3, 4, seed=2, scale=1 / 6)
+    b = f32(320, seed=3, scale=0.1)
+    y = hip.conv_in(dev(x), dev(w), dev(b))
+    ref = F.conv2d(x, w.float().permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    close(y, ref, 2e-3, 1e-3)
+    xa = h16(B, H, W, 320, seed=4)
+    wo = h16(4, 3, 3, 320, seed=5, scale=(9 * 320) ** -0.5)
+    bo = f32(4, seed=6, scale=0.1)
+    z = hip.conv_out(dev(xa), dev(wo), dev(bo))
+    refz = F.conv2d(xa.float().permute(0, 3, 1, 2), wo.float().permute(0, 3, 1, 2), bo, padding=1)
+    assert z.dtype == torch.float32
+    close(z, refz, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [
+    (2, 4096, 320, 0, True, 1e-5), (2, 1024, 640, 320, True, 1e-5), (4, 64, 1280, 1280, False, 1e-6),
+    (1, 256, 64, 0, True, 1e-5), (3, 100, 1920, 0, True, 1e-5), (1, 36, 960, 0, False, 1e-5),
+])
+def test_groupnorm(B, HW, C1, C2, silu, eps):
+    x = h16(B, HW, C1, seed=1, scale=2.0) + 0.5
+    x2 = (h16(B, HW, C2, seed=2) - 1.0) if C2 else None
+    C = C1 + C2
+    gamma, beta = 1 + f32(C, seed=3, scale=0.1), f32(C, seed=4, scale=0.1)
+    out = hip.groupnorm(dev(x), dev(gamma), dev(beta), 32, eps, silu=silu, x2=None if x2 is None else dev(x2))
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    ref = F.group_norm(xin.permute(0, 2, 1), 32, gamma, beta, eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    close(out, ref, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (77, 1280), (5, 64)])
+def test_layernorm(rows, C):
+    x = h16(rows, C, seed=1, scale=3.0) + 1.0
+    gamma, beta = 1 + f32(C, seed=2, scale=0.1), f32(C, seed=3, scale=0.1)
+    out = hip.layernorm(dev(x), dev(gamma), dev(beta), 1e-5)
+    close(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), 2e-3, 2e-3)
+
+
+def test_geglu():
+    x = h16(300, 2 * 1280, seed=1, scale=2.0)
+    out = hip.geglu(dev(x))
+    hdn, gate = x.float().chunk(2, -1)
+    close(out, hdn * F.gelu(gate), 2e-3, 1e-3)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, heads, scale, qs=None, ks=None, vs=None, hook=None):
+    B, N, C = q.shape
+    d = C // heads
+    idx = lambda t, s: t if s is None else t[torch.as_tensor(s).long()]
+    q, k, v = idx(q.float(), qs), idx(k.float(), ks), idx(v.float(), vs)
+    L = k.shape[1]
+    qh = q.reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    if hook is not None:
+        p = hook(p)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, N, C), p
+
+
+@pytest.mark.parametrize("B,heads,N,L,d", [
+    (2, 8, 1024, 1024, 40), (1, 8, 4096, 4096, 40), (2, 8, 256, 256, 80), (4, 8, 64, 64, 160),
+    (2, 4, 256, 256, 160), (2, 2, 200, 144, 64), (1, 3, 96, 77, 32), (1, 8, 130, 70, 40),
+])
+def test_attn_flash(B, heads, N, L, d):
+    C = heads * d
+    q, k, v = h16(B, N, C, seed=1), h16(B, L, C, seed=2), h16(B, L, C, seed=3)
+    scale = d ** -0.5
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, scale)
+    ref, _ = _attn_ref(q, k, v, heads, scale)
+    close(out, ref, 4e-3, 1e-3)
+
+
+def test_attn_flash_peaky_rows():
+    """forces the online-softmax rescale: one key per tile dominates, growing tile by tile."""
+    B, heads, N, d = 1, 2, 128, 64
+    L = 512
+    q, k, v = h16(B, N, heads * d, seed=1), h16(B, L, heads * d, seed=2), h16(B, L, heads * d, seed=3)
+    for t in range(L // 64):
+        k[0, 64 * t + 7, :] = q[0, 5, :] * (0.5 + 0.25 * t)   # rising spikes for query 5 (both heads)
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, d ** -0.5 * 4.0)
+    ref, _ = _attn_ref(q, k, v, heads, d ** -0.5 * 4.0)
+    close(out, ref, 4e-3, 1e-3)
+
+
+def test_attn_flash_fused_qkv_views_and_indirection():
+    B, heads, N, d = 4, 8, 256, 40
+    C = heads * d
+    qkv = h16(B, N, 3 * C, seed=1)
+    qd = dev(qkv)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    # P2P self-replace on the layout [uncond_src, uncond_tgt, cond_src, cond_tgt]: row 3 takes q,k of row 2
+    qs = torch.tensor([0, 1, 2, 2], dtype=torch.int32)
+    vs = torch.tensor([0, 1, 2, 3], dtype=torch.int32)
+    out = hip.attn_flash(qd[..., :C], qd[..., C:2 * C], qd[..., 2 * C:], heads, d ** -0.5, q_src=dev(qs), k_src=dev(qs),
+                         v_src=dev(vs))
+    ref, _ = _attn_ref(q, k, v, heads, d ** -0.5, qs, qs, vs)
+    close(out, ref, 4e-3, 1e-3)
+    # MasaCtrl mutual self-attention: k, v of the source rows
+    ks = torch.tensor([0, 0, 2, 2], dtype=torch.int32)
+    out = hip.attn_flash(qd[..., :C], qd[..., C:2 * C], qd[..., 2 * C:], heads, d ** -0.5, k_src=dev(ks), v_src=dev(ks))
+    ref, _ = _attn_ref(q, k, v, heads, d ** -0.5, None, ks, ks)
+    close(out, ref, 4e-3, 1e-3)
+
+
+@pytest.mark.parametrize("heads,N,d", [(8, 4096, 40), (8, 1024, 80), (8, 256, 160), (8, 64, 160), (2, 100, 64)])
+def test_attn_probs_and_apply(heads, N, d):
+    B, L = 2, 77
+    C = heads * d
+    q, k, v = h16(B, N, C, seed=1), h16(B, L, C, seed=2), h16(B, L, C, seed=3)
+    probs = hip.attn_probs(dev(q), dev(k), heads, d ** -0.5)
+    ref_o, ref_p = _attn_ref(q, k, v, heads, d ** -0.5)
+    assert probs.shape == (B * heads, N, L) and probs.is_contiguous()
+    close(probs, ref_p.reshape(B * heads, N, L), 2e-3, 2e-4)
+    out = hip.attn_apply(probs, dev(v), heads)
+    close(out, ref_o, 4e-3, 1e-3)
+
+
+def test_attn_probs_self():
+    B, heads, N, d = 2, 8, 256, 80
+    q, k = h16(B, N, heads * d, seed=1), h16(B, N, heads * d, seed=2)
+    probs = hip.attn_probs(dev(q), dev(k), heads, d ** -0.5)
+    _, ref_p = _attn_ref(q, k, k, heads, d ** -0.5)
+    close(probs, ref_p.reshape(B * heads, N, N), 2e-3, 2e-4)
+    rows = probs.float().sum(-1)
+    assert (rows - 1).abs().max().item() < 5e-3
+
+
+def _p2p_tables(mode, seed=0):
+    """random but structured edit tables: M [77,77], c1, c2 [77]"""
+    g = torch.Generator().manual_seed(seed)
+    if mode == "refine":
+        mapper = torch.randint(-1, 77, (77,), generator=g)
+        a = (mapper != -1).float()
+        M = torch.zeros(77, 77)
+        M[mapper % 77, torch.arange(77)] = 1.0  # column n gathers source word mapper[n]; -1 wraps to 76 (gated by a = 0)
+        alpha_t = (torch.rand(77, generator=g) > 0.3).float()
+        return M, alpha_t * a, 1 - alpha_t * a
+    M = torch.eye(77)
+    M[5, 5] = 0; M[5, 6] = 0.5; M[5, 7] = 0.5; M[6, 6] = 0; M[6, 8] = 1; M[8, 8] = 0; M[7, 7] = 0
+    alpha_t = (torch.rand(77, generator=g) > 0.3).float()
+    return M, alpha_t, 1 - alpha_t
+
+
+@pytest.mark.parametrize("mode", ["refine", "replace"])
+@pytest.mark.parametrize("heads,N,d", [(8, 1024, 40), (8, 256, 80), (8, 64, 160), (2, 300, 64)])
+def test_attn_cross_p2p(mode, heads, N, d):
+    B, L = 4, 77
+    C = heads * d
+    q, k, v = h16(B, N, C, seed=1), h16(B, L, C, seed=2, scale=1.5), h16(B, L, C, seed=3)
+    M, c1, c2 = _p2p_tables(mode)
+    mt = torch.zeros(1, 96, 96, dtype=torch.float16)
+    mt[0, :77, :77] = M.t().half()
+    coef = torch.zeros(1, 2, 96)
+    coef[0, 0, :77], coef[0, 1, :77] = c1, c2
+    edit_src = torch.tensor([-1, -1, -1, 2], dtype=torch.int32)
+    edit_slot = torch.zeros(4, dtype=torch.int32)
+    out = hip.attn_cross_p2p(dev(q), dev(k), dev(v), heads, d ** -0.5, dev(edit_src), dev(edit_slot), dev(mt), dev(coef))
+
+    def hook(p):  # p [B,h,N,L]
+        p = p.clone()
+        p[3] = c1 * (p[2] @ M.half().float()) + c2 * p[3]
+        return p
+    ref, _ = _attn_ref(q, k, v, heads, d ** -0.5, hook=hook)
+    close(out, ref, 4e-3, 1e-3)
+    # no edit pointers at all == plain cross attention
+    out2 = hip.attn_cross_p2p(dev(q), dev(k), dev(v), heads, d ** -0.5)
+    ref2, _ = _attn_ref(q, k, v, heads, d ** -0.5)
+    close(out2, ref2, 4e-3, 1e-3)
+
+
+# ----------------------------------------------------------------------------- sampler
+def test_cfg_ddim_step_matches_eager_formula():
+    from ief_amd.scheduler import DDIMScheduler
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    eu, ec, x = f32(2, 4, 64, 64, seed=1), f32(2, 4, 64, 64, seed=2), f32(2, 4, 64, 64, seed=3)
+    for t in (981, 501, 21, 1):
+        a_t, a_p = s.step_coeffs(t)
+        coef = torch.tensor([a_t, a_p, 7.5])
+        out = hip.cfg_ddim_step(dev(eu), dev(ec), dev(x), dev(coef))
+        e = eu + 7.5 * (ec - eu)
+        at, ap = s.alphas_cumprod[t], (s.alphas_cumprod[t - 20] if t - 20 >= 0 else s.final_alpha_cumprod)
+        x0 = (x - (1 - at) ** 0.5 * e) / at ** 0.5
+        ref = ap ** 0.5 * x0 + (1 - ap) ** 0.5 * e
+        close(out, ref, 2e-6, 1e-6)
+        out_s = s.step(dev(e), t, dev(x)).prev_sample
+        close(out_s, ref, 2e-6, 1e-6)
+
+
+def test_timestep_embedding_silu_casts_select():
+    t = torch.tensor([981.0, 1.0, 500.0])
+    emb = hip.timestep_embedding(dev(t), 320)
+    half = 160
+    ex = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    ang = t[:, None] * torch.exp(ex)[None]
+    ref = torch.cat([torch.cos(ang), torch.sin(ang)], -1)
+    close(emb, ref, 0, 2e-3)   # fp16 output of values in [-1, 1]; large-angle sincos in fp32
+    x = h16(1000, seed=1, scale=3)
+    close(hip.silu(dev(x)), F.silu(x.float()), 2e-3, 1e-3)
+    xf = f32(777, seed=2)
+    assert torch.equal(hip.to_f16(dev(xf)).cpu(), xf.half())
+    assert torch.equal(hip.to_f32(dev(x)).cpu(), x.float())
+    table = f32(5, 3, 8, seed=3)
+    step = torch.tensor([3], dtype=torch.int32).cuda()
+    out = torch.empty(3, 8, device="cuda")
+    hip.select_step(dev(table), out, step)
+    assert torch.equal(out.cpu(), table[3])
+    hip.advance_step(step)
+    assert step.item() == 4
+
+
+def test_bad_arguments_are_rejected():
+    a = h16(16, 60).cuda()     # K not a multiple of 8
+    w = h16(16, 60).cuda()
+    with pytest.raises(RuntimeError):
+        hip.gemm(a, w)
+    with pytest.raises(TypeError):
+        hip.gemm(torch.zeros(8, 8), torch.zeros(8, 8))  # CPU fp32 tensors: no fallback
