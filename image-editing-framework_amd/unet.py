@@ -1,0 +1,561 @@
+"""SD-family conditional UNet whose every forward is a sequence of hand-written HIP kernels.
+
+The module TREE is shaped like diffusers' `UNet2DConditionModel` because the reference's hooks
+find their targets by class-name strings and attribute paths:
+  - `register_attention_control` walks `unet.named_children()` for names containing
+    "down" / "up" / "mid" and patches modules whose `__class__.__name__ == 'Attention'`
+    (`/root/reference/p2p/model/register.py:78-96`);
+  - the patched forward uses `to_q/to_k/to_v/to_out, head_to_batch_dim, get_attention_scores,
+    batch_to_head_dim, prepare_attention_mask, spatial_norm, group_norm, norm_cross,
+    residual_connection, rescale_output_factor` (register.py:5-62);
+  - PnP addresses `up_blocks[r].attentions[b].transformer_blocks[0].attn1` and
+    `up_blocks[1].resnets[1]` (`/root/reference/pnp/model/register.py:6-19,82-88`).
+`torch.nn.Module` is used only for that tree bookkeeping (children, ModuleList); parameters are
+plain device tensors already packed for the kernels:
+
+  activations  fp16, channels-last  [B, H, W, C] == tokens-major [B, H*W, C]   (no transposes
+               between conv and attention layers)
+  conv 3x3     fp16 [Cout, 3, 3, Cin]      (K-major rows for the implicit GEMM)
+  linear/1x1   fp16 [N, K];  q|k|v of self-attention and k|v of cross-attention concatenated
+  bias/affine  fp32
+
+Two execution paths share these modules:
+  native  (default)  fused kernels; P2P / MasaCtrl control is a device-side plan consumed by the
+          attention kernels (`control.ControlPlan`), no probability map is materialised;
+  generic            a hook replaced `Attention.forward` (any Python controller): maps are
+          materialised by `get_attention_scores` and handed to Python, as the reference does.
+There is no CPU path: tensors must live on the GPU and `libief_hip.so` must be built.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import hip
+from .config import UNetConfig
+
+
+class UNetOutput(dict):
+    """supports `out["sample"]` (sd_utils.py:73) and `out.sample` (ddim.py:29)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _f16(t, dev):
+    return t.detach().to(device=dev, dtype=torch.float16).contiguous()
+
+
+def _f32(t, dev):
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------- leaves
+class Linear(nn.Module):
+    def __init__(self, weight, bias=None):
+        super().__init__()
+        self.weight = weight  # fp16 [N, K] (may be a row-slice view of a fused weight)
+        self.bias = bias      # fp32 [N] or None
+        self.out_features, self.in_features = weight.shape
+
+    def forward(self, x, residual=None):
+        return hip.gemm(x, self.weight, bias=self.bias, residual=residual)
+
+
+class Conv2d(nn.Module):
+    """3x3 (pad 1) or 1x1 convolution over NHWC."""
+
+    def __init__(self, weight, bias, kernel_size, stride=1):
+        super().__init__()
+        self.weight, self.bias = weight, bias
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x, **kw):
+        if self.kernel_size == 1:
+            return hip.gemm(x, self.weight, bias=self.bias, residual=kw.get("residual"))
+        return hip.conv3x3(x, self.weight, self.bias, stride=self.stride, **kw)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, weight, bias, num_groups, eps):
+        super().__init__()
+        self.weight, self.bias, self.num_groups, self.eps = weight, bias, num_groups, eps
+
+    def forward(self, x, silu=False, x2=None):
+        return hip.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, weight, bias, eps=1e-5):
+        super().__init__()
+        self.weight, self.bias, self.eps = weight, bias, eps
+
+    def forward(self, x):
+        return hip.layernorm(x, self.weight, self.bias, self.eps)
+
+
+class SiLU(nn.Module):
+    def forward(self, x):
+        return hip.silu(x)
+
+
+class Dropout(nn.Module):
+    def forward(self, x):
+        return x
+
+
+# ------------------------------------------------------------------------------------- attention
+class Attention(nn.Module):
+    """Hook target.  Native forward = fused kernels; see module docstring for the generic path."""
+
+    def __init__(self, sd, prefix, dim, heads, cross_dim, dev, name):
+        super().__init__()
+        self.heads = heads
+        self.inner_dim = dim
+        self.dim_head = dim // heads
+        self.scale = self.dim_head ** -0.5
+        self.is_cross = cross_dim is not None
+        self.layer_name = name
+        wq, wk, wv = (_f16(sd[f"{prefix}.to_{n}.weight"], dev) for n in "qkv")
+        if self.is_cross:
+            self.w_kv = torch.cat([wk, wv], 0).contiguous()
+            self.to_q = Linear(wq)
+            self.to_k, self.to_v = Linear(self.w_kv[:dim]), Linear(self.w_kv[dim:])
+            self.w_qkv = None
+        else:
+            self.w_qkv = torch.cat([wq, wk, wv], 0).contiguous()
+            self.to_q, self.to_k, self.to_v = (Linear(self.w_qkv[i * dim:(i + 1) * dim]) for i in range(3))
+            self.w_kv = None
+        self.to_out = nn.ModuleList([
+            Linear(_f16(sd[f"{prefix}.to_out.0.weight"], dev), _f32(sd[f"{prefix}.to_out.0.bias"], dev)), Dropout()])
+        # attributes the reference's patched forward reads (register.py:15-62)
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = None
+        self._plan = None          # control.ControlPlan when a lowered controller is registered
+        self._kv_key, self._kv = None, None
+
+    # ---- protocol used by hook closures (generic path)
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are not on the reference path (always None)")
+        return None
+
+    def head_to_batch_dim(self, t, out_dim=3):
+        B, L, _ = t.shape
+        t = t.reshape(B, L, self.heads, self.dim_head).permute(0, 2, 1, 3)
+        return t.reshape(B * self.heads, L, self.dim_head) if out_dim == 3 else t
+
+    def batch_to_head_dim(self, t):
+        BH, L, d = t.shape
+        B = BH // self.heads
+        return t.reshape(B, self.heads, L, d).permute(0, 2, 1, 3).reshape(B, L, self.heads * d)
+
+    def get_attention_scores(self, query, key, attention_mask=None):
+        """[B*h, N, d], [B*h, L, d] -> materialised softmax maps [B*h, N, L] (fp16, contiguous)."""
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are not on the reference path")
+        q = self.batch_to_head_dim(query).contiguous()
+        k = self.batch_to_head_dim(key).contiguous()
+        return hip.attn_probs(q, k, self.heads, self.scale)
+
+    def apply_probs(self, probs, value):
+        """probs [B*h,N,L] x value [B*h,L,d] -> [B,N,h*d] (the bmm + batch_to_head_dim of register.py:50-51)."""
+        v = self.batch_to_head_dim(value).contiguous()
+        return hip.attn_apply(probs.contiguous(), v, self.heads)
+
+    def get_processor(self):
+        return self.processor
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def is_native(self) -> bool:
+        return "forward" not in self.__dict__ and self.processor is None
+
+    # ---- cross-attention K/V of a fixed context are step-invariant: project once per context
+    def context_kv(self, ctx):
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+        if self._kv_key != key:
+            self._kv = hip.gemm(ctx, self.w_kv)
+            self._kv_key = key
+        return self._kv
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, residual=None,
+                **cross_attention_kwargs):
+        if self.processor is not None:  # Pix2Pix-zero style processors own the dataflow
+            return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                  attention_mask=attention_mask, **cross_attention_kwargs)
+        x = hidden_states
+        B, N, C = x.shape
+        plan = self._plan
+        if encoder_hidden_states is None:
+            qkv = hip.gemm(x, self.w_qkv)
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+            qs = ks = vs = None
+            if plan is not None:
+                qs, ks, vs = plan.self_sources(B, N, self)
+            o = hip.attn_flash(q, k, v, self.heads, self.scale, q_src=qs, k_src=ks, v_src=vs)
+        else:
+            q = hip.gemm(x, self.to_q.weight)
+            kv = self.context_kv(encoder_hidden_states)
+            args = plan.cross_edit(B, self) if plan is not None else {}
+            o = hip.attn_cross_p2p(q, kv[..., :C], kv[..., C:], self.heads, self.scale, **args)
+        if plan is not None:
+            plan.layer_done(self)
+        return self.to_out[0](o, residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, sd, prefix, dev):
+        super().__init__()
+        self.proj = Linear(_f16(sd[prefix + ".proj.weight"], dev), _f32(sd[prefix + ".proj.bias"], dev))
+
+    def forward(self, x):
+        return hip.geglu(self.proj(x))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, sd, prefix, dev):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(sd, prefix + ".net.0", dev), Dropout(),
+                                  Linear(_f16(sd[prefix + ".net.2.weight"], dev), _f32(sd[prefix + ".net.2.bias"], dev))])
+
+    def forward(self, x, residual=None):
+        return self.net[2](self.net[0](x), residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, sd, prefix, dim, heads, cross_dim, dev, name):
+        super().__init__()
+        ln = lambda n: LayerNorm(_f32(sd[f"{prefix}.{n}.weight"], dev), _f32(sd[f"{prefix}.{n}.bias"], dev))
+        self.norm1, self.norm2, self.norm3 = ln("norm1"), ln("norm2"), ln("norm3")
+        self.attn1 = Attention(sd, prefix + ".attn1", dim, heads, None, dev, name + ".attn1")
+        self.attn2 = Attention(sd, prefix + ".attn2", dim, heads, cross_dim, dev, name + ".attn2")
+        self.ff = FeedForward(sd, prefix + ".ff", dev)
+
+    @staticmethod
+    def _attend(attn, x, res, ctx):
+        if attn.is_native():
+            return attn(x, encoder_hidden_states=ctx, residual=res)
+        # a hook owns forward: reference signature, residual added here (one extra fp16 rounding)
+        out = attn(x, encoder_hidden_states=ctx)
+        return hip.gemm_free_add(out, res)
+
+    def forward(self, h, ctx):
+        h = self._attend(self.attn1, self.norm1(h), h, None)
+        h = self._attend(self.attn2, self.norm2(h), h, ctx)
+        return self.ff(self.norm3(h), residual=h)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, sd, prefix, dim, heads, cross_dim, groups, dev, name):
+        super().__init__()
+        self.norm = GroupNorm(_f32(sd[prefix + ".norm.weight"], dev), _f32(sd[prefix + ".norm.bias"], dev), groups, 1e-6)
+        c1 = lambda n: Conv2d(_f16(sd[f"{prefix}.{n}.weight"].reshape(dim, dim), dev), _f32(sd[f"{prefix}.{n}.bias"], dev), 1)
+        self.proj_in, self.proj_out = c1("proj_in"), c1("proj_out")
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(sd, prefix + ".transformer_blocks.0", dim, heads, cross_dim, dev, name)])
+
+    def forward(self, x, encoder_hidden_states=None):
+        B, H, W, C = x.shape
+        h = self.proj_in(self.norm(x)).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, encoder_hidden_states)
+        return self.proj_out(h.reshape(B, H, W, C), residual=x)
+
+
+# ------------------------------------------------------------------------------------- resnet
+class ResnetBlock2D(nn.Module):
+    """norm1+SiLU -> conv1 (+bias +time-emb) -> norm2+SiLU -> conv2 (+bias +skip); the 1x1 shortcut of a
+    channel-changing block is folded into conv2's implicit GEMM as an extra K range over the raw input(s).
+    Dataflow: `/root/reference/pnp/model/register.py:102-175`."""
+
+    def __init__(self, sd, prefix, cin, cout, groups, eps, dev, temb_slot):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.norm1 = GroupNorm(_f32(sd[prefix + ".norm1.weight"], dev), _f32(sd[prefix + ".norm1.bias"], dev), groups, eps)
+        self.norm2 = GroupNorm(_f32(sd[prefix + ".norm2.weight"], dev), _f32(sd[prefix + ".norm2.bias"], dev), groups, eps)
+        pack = lambda w: _f16(w.permute(0, 2, 3, 1), dev)  # OIHW -> [O][kh][kw][I]
+        self.conv1 = Conv2d(pack(sd[prefix + ".conv1.weight"]), _f32(sd[prefix + ".conv1.bias"], dev), 3)
+        self.time_emb_proj = Linear(_f16(sd[prefix + ".time_emb_proj.weight"], dev), _f32(sd[prefix + ".time_emb_proj.bias"], dev))
+        self.nonlinearity = SiLU()
+        self.dropout = Dropout()
+        self.upsample = self.downsample = None
+        self.skip_time_act = False
+        self.time_embedding_norm = "default"
+        self.output_scale_factor = 1.0
+        w2 = sd[prefix + ".conv2.weight"].permute(0, 2, 3, 1).reshape(cout, 9 * cout)
+        b2 = sd[prefix + ".conv2.bias"]
+        if cin != cout:
+            ws = sd[prefix + ".conv_shortcut.weight"].reshape(cout, cin)
+            self.conv_shortcut = Conv2d(_f16(ws, dev), _f32(sd[prefix + ".conv_shortcut.bias"], dev), 1)
+            self.w2_fused = _f16(torch.cat([w2, ws], 1), dev)                       # [Cout][9*Cout + Cin]
+            self.b2_fused = _f32(b2 + sd[prefix + ".conv_shortcut.bias"], dev)
+        else:
+            self.conv_shortcut = None
+            self.w2_fused, self.b2_fused = None, None
+        self.conv2 = Conv2d(_f16(w2.reshape(cout, 3, 3, cout), dev), _f32(b2, dev), 3)
+        self.temb_slot = temb_slot  # (offset, width) into the UNet's per-step time-embedding row
+
+    def forward(self, x, temb_row, skip=None):
+        """x [B,H,W,C1] (+ skip [B,H,W,C2] = un-materialised channel concat); temb_row fp32 [B or 1, Cout]."""
+        h = self.norm1(x, silu=True, x2=skip)
+        h = hip.conv3x3(h, self.conv1.weight, self.conv1.bias, rowvec=temb_row)
+        h = self.norm2(h, silu=True)
+        if self.conv_shortcut is None:
+            return hip.conv3x3(h, self.conv2.weight, self.conv2.bias, residual=x)
+        return hip.conv3x3_shortcut(h, self.w2_fused, self.b2_fused, x, skip)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, sd, prefix, dev):
+        super().__init__()
+        self.conv = Conv2d(_f16(sd[prefix + ".conv.weight"].permute(0, 2, 3, 1), dev), _f32(sd[prefix + ".conv.bias"], dev), 3, stride=2)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    """nearest 2x + conv3x3, the interpolation fused into the conv's gather (never materialised)."""
+
+    def __init__(self, sd, prefix, dev):
+        super().__init__()
+        self.conv = Conv2d(_f16(sd[prefix + ".conv.weight"].permute(0, 2, 3, 1), dev), _f32(sd[prefix + ".conv.bias"], dev), 3)
+
+    def forward(self, x):
+        return hip.conv3x3(x, self.conv.weight, self.conv.bias, upsample=True)
+
+
+# ------------------------------------------------------------------------------------- blocks
+class _Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.resnets = nn.ModuleList()
+        self.attentions = nn.ModuleList()
+        self.has_cross_attention = False
+
+
+class CrossAttnDownBlock2D(_Block):
+    pass
+
+
+class DownBlock2D(_Block):
+    pass
+
+
+class CrossAttnUpBlock2D(_Block):
+    pass
+
+
+class UpBlock2D(_Block):
+    pass
+
+
+class UNetMidBlock2DCrossAttn(_Block):
+    pass
+
+
+class Timesteps(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.num_channels = dim
+
+    def forward(self, t):
+        return hip.timestep_embedding(t, self.num_channels)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, sd, dev):
+        super().__init__()
+        self.linear_1 = Linear(_f16(sd["time_embedding.linear_1.weight"], dev), _f32(sd["time_embedding.linear_1.bias"], dev))
+        self.act = SiLU()
+        self.linear_2 = Linear(_f16(sd["time_embedding.linear_2.weight"], dev), _f32(sd["time_embedding.linear_2.bias"], dev))
+
+    def forward(self, x):
+        return self.linear_2(self.act(self.linear_1(x)))
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0"):
+        super().__init__()
+        hip.load()  # fail loudly before touching anything else
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("UNet2DConditionModel runs on the GPU only (no CPU path)")
+        sd = state_dict
+        self.cfg = cfg
+        self.config = _Config(cfg)
+        self._device = dev
+        self.dtype = torch.float16
+        ch = cfg.block_out_channels
+        nlev = len(ch)
+        G, eps = cfg.norm_num_groups, cfg.norm_eps
+        self.conv_in = Conv2d(_f16(sd["conv_in.weight"].permute(0, 2, 3, 1), dev), _f32(sd["conv_in.bias"], dev), 3)
+        self.time_proj = Timesteps(ch[0])
+        self.time_embedding = TimestepEmbedding(sd, dev)
+        self._temb_width = 0
+        self._resnets = []
+
+        def resnet(prefix, cin, cout):
+            r = ResnetBlock2D(sd, prefix, cin, cout, G, eps, dev, (self._temb_width, cout))
+            self._temb_width += cout
+            self._resnets.append(r)
+            return r
+
+        self.down_blocks = nn.ModuleList()
+        cout = ch[0]
+        for i in range(nlev):
+            cin, cout = cout, ch[i]
+            blk = CrossAttnDownBlock2D() if cfg.down_has_attn[i] else DownBlock2D()
+            blk.has_cross_attention = cfg.down_has_attn[i]
+            for j in range(cfg.layers_per_block):
+                blk.resnets.append(resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout))
+                if cfg.down_has_attn[i]:
+                    blk.attentions.append(Transformer2DModel(sd, f"down_blocks.{i}.attentions.{j}", cout, cfg.num_heads[i],
+                                                             cfg.cross_attention_dim, G, dev, f"down{i}.{j}"))
+            blk.downsamplers = nn.ModuleList([Downsample2D(sd, f"down_blocks.{i}.downsamplers.0", dev)]) if i < nlev - 1 else None
+            self.down_blocks.append(blk)
+        self.up_blocks = nn.ModuleList()
+        rev, rev_attn, rev_heads = tuple(reversed(ch)), tuple(reversed(cfg.down_has_attn)), tuple(reversed(cfg.num_heads))
+        out_c = rev[0]
+        up_specs = []
+        for i in range(nlev):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, nlev - 1)]
+            up_specs.append((i, prev, out_c, in_c))
+        cm = ch[-1]
+        self.mid_block = UNetMidBlock2DCrossAttn()
+        self.mid_block.has_cross_attention = True
+        self.mid_block.resnets.append(resnet("mid_block.resnets.0", cm, cm))
+        self.mid_block.attentions.append(Transformer2DModel(sd, "mid_block.attentions.0", cm, cfg.num_heads[-1],
+                                                            cfg.cross_attention_dim, G, dev, "mid"))
+        self.mid_block.resnets.append(resnet("mid_block.resnets.1", cm, cm))
+        for i, prev, out_c, in_c in up_specs:
+            blk = CrossAttnUpBlock2D() if rev_attn[i] else UpBlock2D()
+            blk.has_cross_attention = rev_attn[i]
+            blk.skip_channels = []
+            for j in range(cfg.layers_per_block + 1):
+                skip = in_c if j == cfg.layers_per_block else out_c
+                rin = prev if j == 0 else out_c
+                blk.skip_channels.append(skip)
+                blk.resnets.append(resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, out_c))
+                if rev_attn[i]:
+                    blk.attentions.append(Transformer2DModel(sd, f"up_blocks.{i}.attentions.{j}", out_c, rev_heads[i],
+                                                             cfg.cross_attention_dim, G, dev, f"up{i}.{j}"))
+            blk.upsamplers = nn.ModuleList([Upsample2D(sd, f"up_blocks.{i}.upsamplers.0", dev)]) if i < nlev - 1 else None
+            self.up_blocks.append(blk)
+        self.conv_norm_out = GroupNorm(_f32(sd["conv_norm_out.weight"], dev), _f32(sd["conv_norm_out.bias"], dev), G, eps)
+        self.conv_act = SiLU()
+        self.conv_out = Conv2d(_f16(sd["conv_out.weight"].permute(0, 2, 3, 1), dev), _f32(sd["conv_out.bias"], dev), 3)
+        # all 22 time_emb_proj linears as ONE [sum Cout, temb] GEMM
+        self._temb_w = torch.cat([r.time_emb_proj.weight for r in self._resnets], 0).contiguous()
+        self._temb_b = torch.cat([r.time_emb_proj.bias for r in self._resnets], 0).contiguous()
+        self._temb_table = None   # per-step rows, see precompute_time_table
+        self._temb_static = None  # [1, width] fp32 buffer a captured graph reads
+        self._plan = None
+
+    # ------------------------------------------------------------------ small API
+    @property
+    def device(self):
+        return self._device
+
+    def attention_modules(self):
+        """Attention modules in the order the reference's registration walk counts them."""
+        out = []
+        for name, child in self.named_children():
+            if "down" in name or "up" in name or "mid" in name:
+                out += [m for m in child.modules() if m.__class__.__name__ == "Attention"]
+        return out
+
+    def time_rows(self, timesteps_f32):
+        """fp32 [T, sum Cout]: time_emb_proj(silu(time_embedding(time_proj(t)))) for every resnet at once."""
+        emb = self.time_embedding(self.time_proj(timesteps_f32))
+        rows = hip.gemm(hip.silu(emb), self._temb_w, bias=self._temb_b)
+        return hip.to_f32(rows)
+
+    def precompute_time_table(self, timesteps):
+        """Rows for a whole schedule (one per step); the fused loop then selects a row per step on device."""
+        t = torch.as_tensor(timesteps).to(device=self._device, dtype=torch.float32).reshape(-1).contiguous()
+        self._temb_table = self.time_rows(t).contiguous()
+        self._temb_static = torch.empty(1, self._temb_width, dtype=torch.float32, device=self._device)
+        return self._temb_table
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None,
+                added_cond_kwargs=None, return_dict=True, temb_row=None, **kw):
+        """sample fp32/fp16 NCHW [B,4,H,W]; timestep scalar / 0-d tensor; ctx [B,77,Cc] -> eps fp32 NCHW.
+
+        `temb_row` (fp32 [1, width]) short-circuits the time embedding for the captured-graph loop."""
+        if not sample.is_cuda:
+            raise RuntimeError("UNet input must be a device tensor (no CPU path)")
+        x = sample if sample.dtype == torch.float32 else sample.float()
+        x = x.contiguous()
+        B = x.shape[0]
+        ctx = encoder_hidden_states
+        if ctx.dtype != torch.float16:
+            ctx = self._ctx_f16(ctx)
+        if temb_row is None:
+            t = torch.as_tensor(timestep).to(device=self._device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+            temb_row = self.time_rows(t)
+        trow = lambda r: temb_row[:, r.temb_slot[0]:r.temb_slot[0] + r.temb_slot[1]].contiguous()
+        if self._plan is not None:
+            self._plan.begin_forward(B)
+
+        h = hip.conv_in(x, self.conv_in.weight, self.conv_in.bias)
+        skips = [h]
+        for blk in self.down_blocks:
+            for j, res in enumerate(blk.resnets):
+                h = res(h, trow(res))
+                if blk.has_cross_attention:
+                    h = blk.attentions[j](h, ctx)
+                skips.append(h)
+            if blk.downsamplers is not None:
+                h = blk.downsamplers[0](h)
+                skips.append(h)
+        h = self.mid_block.resnets[0](h, trow(self.mid_block.resnets[0]))
+        h = self.mid_block.attentions[0](h, ctx)
+        h = self.mid_block.resnets[1](h, trow(self.mid_block.resnets[1]))
+        for blk in self.up_blocks:
+            for j, res in enumerate(blk.resnets):
+                h = res(h, trow(res), skip=skips.pop())
+                if blk.has_cross_attention:
+                    h = blk.attentions[j](h, ctx)
+            if blk.upsamplers is not None:
+                h = blk.upsamplers[0](h)
+        h = self.conv_norm_out(h, silu=True)
+        eps = hip.conv_out(h, self.conv_out.weight, self.conv_out.bias)
+        if self._plan is not None:
+            self._plan.end_forward(B)
+        if not return_dict:
+            return (eps,)
+        return UNetOutput(sample=eps)
+
+    def _ctx_f16(self, ctx):
+        """fp32 context -> fp16 once per distinct tensor (keeps the cross-attention K/V cache valid)."""
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+        cache = getattr(self, "_ctx_cache", None)
+        if cache is None or cache[0] != key:
+            self._ctx_cache = (key, hip.to_f16(ctx.contiguous()))
+        return self._ctx_cache[1]
+
+
+class _Config:
+    """`unet.config.in_channels`, `.sample_size` (sd_utils.py:16, pnp/model/sd_utils.py)."""
+
+    def __init__(self, cfg: UNetConfig):
+        self.in_channels = cfg.in_channels
+        self.out_channels = cfg.out_channels
+        self.sample_size = cfg.sample_size
+        self.cross_attention_dim = cfg.cross_attention_dim
+        self.block_out_channels = cfg.block_out_channels
+        self.layers_per_block = cfg.layers_per_block
+        self.attention_head_dim = cfg.num_heads
