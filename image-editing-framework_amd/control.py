@@ -1,0 +1,136 @@
+"""Device-side control plan: a known controller lowered to data the fused attention kernels read.
+
+The reference hands every materialised attention map to Python
+(`/root/reference/p2p/model/register.py:47-48`).  For the controller classes whose arithmetic is
+known (`EmptyControl`, `AttentionReplace / Refine / Reweight`; MasaCtrl's mutual self-attention)
+the same effect is expressed as small device tables, so no map is ever written to HBM:
+
+  cross-attention edit (attention_base.py:118-121, attention_control.py:15-46)
+      P' = c1[step][w] * (P_src @ M)[w] + c2[step][w] * P_tgt[w]
+      M^T fp16 [slots,96,96], coef table fp32 [steps+1, slots, 2, 96]
+  self-attention replace (attention_base.py:123,132-136), only for maps with N <= 16*16 and
+      num_self_replace[0] <= step < num_self_replace[1]:
+      target rows take the source row's Q and K (=> identical map), keep their own V
+      source-row table int32 [steps+1, 2B]  (identity rows outside the window)
+  MasaCtrl mutual self-attention (/root/reference/masactrl/model/attention_control.py:37-68):
+      K,V source rows per (step, layer)
+
+The step index lives in device memory (`step`), the per-step rows are copied into fixed
+"current" buffers by `ief_select_step` at the start of every UNet forward, and the counter is
+bumped by `ief_advance_step` at its end — all stream-ordered kernels, so ONE captured hipGraph
+replays correctly for all 50 steps.  The Python controller's own counters (`cur_step`,
+`cur_att_layer`, `between_steps()`) are advanced exactly as `AttentionControl.__call__` does
+(attention_base.py:23-27) so user code observing them sees reference behaviour.
+"""
+from typing import Optional
+
+import torch
+
+from . import hip
+
+XL = 96  # padded key count of the cross-attention kernel
+
+
+def advance_controller(c):
+    """`attention_base.py:23-27` for any object following the controller protocol."""
+    c.cur_att_layer += 1
+    uncond = c.num_att_layers if getattr(c, "LOW_RESOURCE", False) else 0
+    if c.cur_att_layer == c.num_att_layers + uncond:
+        c.cur_att_layer = 0
+        c.cur_step += 1
+        c.between_steps()
+
+
+class ControlPlan:
+    """kind: 'empty' | 'p2p' | 'masactrl'"""
+
+    def __init__(self, controller, kind: str, device, num_prompts: int = 1, num_steps: int = 0,
+                 mt: Optional[torch.Tensor] = None, coef_table: Optional[torch.Tensor] = None,
+                 self_window=(0, 0), self_max_tokens: int = 256):
+        self.controller = controller
+        self.kind = kind
+        self.device = torch.device(device)
+        self.num_prompts = num_prompts
+        self.batch = 2 * num_prompts
+        self.num_steps = num_steps
+        self.self_window = self_window
+        self.self_max_tokens = self_max_tokens
+        self.captured = False   # True while a hipGraph replays the forward (Python bookkeeping moves to the replay wrapper)
+        self.muted = False      # True during a warm-up forward that must not move any counter
+        dev = self.device
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        B, Bp = self.batch, num_prompts
+        if kind == "p2p":
+            slots = Bp - 1
+            assert mt.shape == (slots, XL, XL) and coef_table.shape == (num_steps + 1, slots, 2, XL)
+            self.mt = mt.to(device=dev, dtype=torch.float16).contiguous()
+            self.coef_table = coef_table.to(device=dev, dtype=torch.float32).contiguous()
+            self.coef_cur = torch.zeros(slots, 2, XL, dtype=torch.float32, device=dev)
+            es = torch.full((B,), -1, dtype=torch.int32)
+            sl = torch.zeros(B, dtype=torch.int32)
+            for k in range(slots):
+                es[Bp + 1 + k] = Bp
+                sl[Bp + 1 + k] = k
+            self.edit_src, self.edit_slot = es.to(dev), sl.to(dev)
+            ident = torch.arange(B, dtype=torch.int32)
+            repl = ident.clone()
+            repl[Bp + 1:] = Bp
+            tab = ident.repeat(num_steps + 1, 1)
+            lo, hi = self_window
+            tab[lo:hi] = repl
+            self.self_table = tab.contiguous().to(dev)
+            self.self_cur = ident.clone().to(dev)
+        self._step_synced = -1
+
+    # ------------------------------------------------------------------ per-forward protocol
+    def applies(self, B: int) -> bool:
+        if self.kind == "empty" or self.muted:
+            return False
+        if B != self.batch:
+            raise RuntimeError(
+                f"controller was built for {self.num_prompts} prompts (UNet batch {self.batch}) but the UNet was "
+                f"called with batch {B}; the reference's AttentionControlEdit.forward would mis-reshape here")
+        return True
+
+    def begin_forward(self, B: int):
+        if not self.applies(B):
+            return
+        if not self.captured:
+            # keep the device counter equal to the controller's (covers reset() / manual edits)
+            cs = int(self.controller.cur_step)
+            if cs > self.num_steps:
+                raise IndexError(f"cur_step {cs} exceeds the controller's {self.num_steps}-step tables")
+            self.step.fill_(cs)
+        if self.kind == "p2p":
+            hip.select_step(self.coef_table, self.coef_cur, self.step)
+            hip.select_step(self.self_table, self.self_cur, self.step)
+
+    def end_forward(self, B: int):
+        if self.kind != "empty" and not self.muted and B == self.batch:
+            hip.advance_step(self.step)
+
+    def layer_done(self, attn):
+        if not self.captured and not self.muted and self.controller is not None:
+            advance_controller(self.controller)
+
+    def sync_step(self):
+        """device step counter <- controller.cur_step (before the first replay of a captured loop)"""
+        self.step.fill_(int(self.controller.cur_step))
+
+    def replay_done(self):
+        """one whole forward was replayed from a graph: num_att_layers controller calls happened"""
+        c = self.controller
+        if c is not None:
+            c.cur_step += 1
+            c.between_steps()
+
+    # ------------------------------------------------------------------ what the kernels read
+    def self_sources(self, B: int, N: int, attn):
+        if self.kind == "p2p" and self.applies(B) and N <= self.self_max_tokens:
+            return self.self_cur, self.self_cur, None
+        return None, None, None
+
+    def cross_edit(self, B: int, attn):
+        if self.kind == "p2p" and self.applies(B):
+            return dict(edit_src=self.edit_src, edit_slot=self.edit_slot, mt=self.mt, coef=self.coef_cur)
+        return {}

@@ -69,6 +69,30 @@ extern "C" int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void*
     return IEF_OK;
 }
 
+__global__ __launch_bounds__(256) void add_f16_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                      half_t* __restrict__ o, long long n8, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const half8 x = ((const half8*)a)[i], y = ((const half8*)b)[i];
+        half8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (half_t)((float)x[e] + (float)y[e]);
+        ((half8*)o)[i] = r;
+    }
+    if (blockIdx.x == 0) for (long long i = n8 * 8 + threadIdx.x; i < n; i += 256) o[i] = (half_t)((float)a[i] + (float)b[i]);
+}
+extern "C" int ief_add_f16(const ief_half* a, const ief_half* b, ief_half* out, long long n, void* stream) {
+    if (!a || !b || !out) return IEF_EINVAL;
+    if (n <= 0) return IEF_ESHAPE;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) return IEF_EALIGN;
+    const long long n8 = n / 8;
+    int grid = (int)((n8 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(add_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, n8, n);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 __global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, half_t* __restrict__ o, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = (half_t)x[i];
 }

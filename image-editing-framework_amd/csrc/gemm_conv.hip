@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
             a_b[i] = b;
             a_y[i] = oy * p.stride - 1;
             a_x[i] = ox * p.stride - 1;
-            a_off[i] = 0;
+            a_off[i] = m;  // output pixel index: the address of the fused-1x1 extra K range
         } else {
             a_off[i] = (long long)m * p.lda + kc * 8;
             a_b[i] = a_y[i] = a_x[i] = 0;
@@ -80,18 +80,28 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
         const int k0 = kt * BK;
         if constexpr (CONV) {
             const int Ctot = p.C1 + p.C2;
-            const int tap = k0 / Ctot, c0 = k0 - tap * Ctot;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const half_t* src = A;
-            int cs = p.C1, cc = c0;
-            if (c0 >= p.C1) { src = A2; cs = p.C2; cc = c0 - p.C1; }
+            if (k0 < 9 * Ctot) {
+                const int tap = k0 / Ctot, c0 = k0 - tap * Ctot;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const half_t* src = A;
+                int cs = p.C1, cc = c0;
+                if (c0 >= p.C1) { src = A2; cs = p.C2; cc = c0 - p.C1; }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                const int py = iy >> p.ups, px = ix >> p.ups;
-                const long long off = ((long long)(a_b[i] * Hp + py) * Wp + px) * cs + cc + kc * 8;
-                ra[i] = ok ? *(const half8*)(src + off) : zero8;
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                    const int py = iy >> p.ups, px = ix >> p.ups;
+                    const long long off = ((long long)(a_b[i] * Hp + py) * Wp + px) * cs + cc + kc * 8;
+                    ra[i] = ok ? *(const half8*)(src + off) : zero8;
+                }
+            } else {  // fused 1x1 over the extra sources, sampled at the output pixel
+                const int ke = k0 - 9 * Ctot;
+                const half_t* src = p.E1;
+                int cs = p.CE1, cc = ke;
+                if (ke >= p.CE1) { src = p.E2; cs = p.CE2; cc = ke - p.CE1; }
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    ra[i] = a_ok[i] ? *(const half8*)(src + a_off[i] * cs + cc + kc * 8) : zero8;
             }
         } else {
             const bool kok = k0 + kc * 8 < p.K;
@@ -259,11 +269,14 @@ extern "C" int ief_conv3x3_f16(const IefGemmParams* pp, void* stream) {
     if (p.ups && ((p.H & 1) || (p.Wd & 1))) return IEF_ESHAPE;
     p.Ho = (p.H + 2 - 3) / p.stride + 1;
     p.Wo = (p.Wd + 2 - 3) / p.stride + 1;
-    p.K = 9 * Ctot;
+    if (p.CE1 < 0 || p.CE2 < 0 || (p.CE1 % 64) || (p.CE2 % 64)) return IEF_ESHAPE;
+    if ((p.CE1 > 0 && !p.E1) || (p.CE2 > 0 && !p.E2) || (p.CE2 > 0 && p.CE1 == 0)) return IEF_EINVAL;
+    if ((p.CE1 + p.CE2) > 0 && (p.stride != 1 || p.ups != 0)) return IEF_ESHAPE;
+    p.K = 9 * Ctot + p.CE1 + p.CE2;
     p.ldw = p.K;
     if (p.batch_images <= 0) return IEF_ESHAPE;
     p.M = p.batch_images * p.Ho * p.Wo;
-    if (p.rowvec) p.rows_per_batch = p.Ho * p.Wo;
+    if (p.rowvec && p.rows_per_batch <= 0) p.rows_per_batch = p.Ho * p.Wo;  // caller may share one row across the batch
     int rc = check_common(p);
     if (rc) return rc;
     p.strideA = p.strideW = p.strideO = p.strideR = 0;

@@ -29,6 +29,7 @@ class IefGemmParams(Structure):
         ("H", c_int), ("Wd", c_int), ("C1", c_int), ("C2", c_int), ("Ho", c_int), ("Wo", c_int),
         ("stride", c_int), ("ups", c_int), ("batch_images", c_int),
         ("rows_per_batch", c_int), ("out_scale", c_float), ("tile_hint", c_int),
+        ("E1", c_void_p), ("E2", c_void_p), ("CE1", c_int), ("CE2", c_int),
     ]
 
 
@@ -57,7 +58,7 @@ EXPORTS = [
     "ief_conv_out_f32", "ief_gn_splits", "ief_groupnorm_silu_f16", "ief_layernorm_f16", "ief_geglu_f16",
     "ief_attn_flash_f16", "ief_attn_cross_p2p_f16", "ief_attn_probs_f16", "ief_attn_apply_f16",
     "ief_cfg_ddim_step_f32", "ief_timestep_embedding_f16", "ief_silu_f16", "ief_cast_f32_to_f16",
-    "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step",
+    "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step", "ief_add_f16",
 ]
 
 
@@ -101,6 +102,7 @@ def load():
     lib.ief_cast_f16_to_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_select_step.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_advance_step.argtypes = [c_void_p, c_void_p]
+    lib.ief_add_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     if lib.ief_abi_version() != 1:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     _lib = lib
@@ -194,9 +196,12 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     return out
 
 
-def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0):
+def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0,
+            extra=None):
     """3x3 / pad 1 convolution over NHWC fp16.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat),
-    w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather."""
+    w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather.
+    extra=(e1, e2|None): fused 1x1 convolution over more NHWC sources sampled at the output pixel; w is
+    then [Cout, 9*(C1+C2) + CE1 + CE2]."""
     lib = load()
     _dev16(x, "x")
     _dev16(w, "w")
@@ -207,7 +212,18 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     if x2 is not None and tuple(x2.shape[:3]) != (B, Hp, Wp):
         raise ValueError("conv3x3: x2 spatial shape mismatch")
     Cout = w.shape[0]
-    if tuple(w.shape[1:]) != (3, 3, C1 + C2):
+    e1 = e2 = None
+    CE1 = CE2 = 0
+    if extra is not None:
+        e1, e2 = extra
+        CE1 = e1.shape[-1]
+        CE2 = 0 if e2 is None else e2.shape[-1]
+        for e in (e1, e2):
+            if e is not None and (not _dev16(e, "extra").is_contiguous() or tuple(e.shape[:3]) != (B, Hp, Wp)):
+                raise ValueError("conv3x3: extra sources must be contiguous NHWC at the output resolution")
+        if tuple(w.shape) != (Cout, 9 * (C1 + C2) + CE1 + CE2):
+            raise ValueError("conv3x3: fused weight must be [Cout, 9*(C1+C2)+CE1+CE2]")
+    elif tuple(w.shape[1:]) != (3, 3, C1 + C2):
         raise ValueError(f"conv3x3: weight shape {tuple(w.shape)} does not match C1+C2={C1 + C2}")
     H, Wd = (Hp * 2, Wp * 2) if upsample else (Hp, Wp)
     Ho, Wo = (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1
@@ -216,7 +232,12 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p = IefGemmParams()
     p.A, p.A2, p.W, p.Out = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
-    p.rowvec = _ptr(_dev32(rowvec, "rowvec")) if rowvec is not None else None
+    if rowvec is not None:
+        _dev32(rowvec, "rowvec")
+        if rowvec.dim() != 2 or rowvec.shape[1] != Cout or rowvec.shape[0] not in (1, B):
+            raise ValueError("conv3x3: rowvec must be [B, Cout] or [1, Cout]")
+        p.rowvec = rowvec.data_ptr()
+        p.rows_per_batch = Ho * Wo if rowvec.shape[0] == B and B > 1 else B * Ho * Wo
     if residual is not None:
         _dev16(residual, "residual")
         if tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous():
@@ -227,7 +248,26 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.stride, p.ups, p.batch_images = stride, 1 if upsample else 0, B
     p.out_scale = 1.0
     p.tile_hint = tile_hint
+    p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
+    return out
+
+
+def conv3x3_shortcut(h, w_fused, bias_fused, x, skip=None):
+    """ResnetBlock2D tail with a channel-changing shortcut in ONE launch:
+    conv3x3(h) + conv1x1([x | skip]) + (b2 + bs); w_fused [Cout, 9*Cout + Cin]."""
+    return conv3x3(h, w_fused, bias_fused, extra=(x, skip))
+
+
+def add(a, b, out=None):
+    lib = load()
+    _dev16(a, "a")
+    _dev16(b, "b")
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add: operands must be contiguous and of equal shape")
+    if out is None:
+        out = torch.empty_like(a)
+    _check(lib.ief_add_f16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "ief_add_f16")
     return out
 
 

@@ -1,0 +1,124 @@
+"""Prompt-to-Prompt editors: the denoising loops around the UNet.
+
+Same classes and call signatures as `/root/reference/p2p/model/sd_utils.py` (`P2P` :9-88,
+`P2P_NTI` :90-140):
+
+    editor = P2P(model=pipe, num_inference_steps=50)
+    images, x_T = editor.text2image_ldm_stable(pipe, prompts, controller, latent=..., num_inference_steps=50,
+                                               guidance_scale=7.5, low_resource=False)
+
+What differs is only HOW a step executes.  When the controller was lowered to a device plan
+(`register.py`), the 50-step loop is a captured hipGraph replayed per step (`denoise.FusedDenoiser`);
+otherwise (`low_resource`, an arbitrary Python controller, a custom `step_callback`) the loop runs
+step by step with the reference's dataflow (:67-79) on the same kernels.
+
+RNG: the reference draws x_T on the CUDA device from the global generator (:15-18).  CUDA, HIP
+and CPU generators produce different streams, so x_T is drawn on the CPU generator
+(`torch.manual_seed(seed)` / an explicit CPU `generator`) and uploaded — the oracle does the same,
+which is what makes seeds comparable (SURVEY.md §7 "RNG").
+"""
+from typing import List, Optional
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from ... import hip
+from ...denoise import FusedDenoiser
+from .register import register_attention_control
+
+
+def _encode_prompts(model, prompt: List[str]):
+    """cond and uncond text embeddings, as `sd_utils.py:42-55` (also `inversion/ddim.py:43-58`)."""
+    tok = model.tokenizer
+    text_input = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
+    text_embeddings = model.text_encoder(text_input.input_ids.to(model.device))[0]
+    max_length = text_input.input_ids.shape[-1]
+    uncond_input = tok([""] * len(prompt), padding="max_length", max_length=max_length, return_tensors="pt")
+    uncond_embeddings = model.text_encoder(uncond_input.input_ids.to(model.device))[0]
+    return uncond_embeddings, text_embeddings
+
+
+def _fusable(model, controller, low_resource) -> bool:
+    if low_resource:
+        return False
+    plan = getattr(model.unet, "_plan", None)
+    if controller is None:
+        return all(m.is_native() for m in model.unet.attention_modules())
+    # a plan exists only for controller classes whose step_callback is the identity (register.lower_controller)
+    return plan is not None and plan.controller is controller
+
+
+class P2P:
+    def __init__(self, model, num_inference_steps) -> None:
+        model.scheduler.set_timesteps(num_inference_steps)
+
+    def init_latent(self, latent, model, height, width, generator, batch_size):
+        C = model.unet.config.in_channels
+        if latent is None:
+            latent = torch.randn((1, C, height // 8, width // 8), generator=generator, dtype=torch.float32).to(model.device)
+        latent = latent * model.scheduler.init_noise_sigma
+        latents = latent.expand(batch_size, C, height // 8, width // 8)
+        return latent, latents
+
+    @torch.no_grad()
+    def text2image_ldm_stable(self, model, prompt: List[str], controller, num_inference_steps: int = 50,
+                              guidance_scale: float = 7.5, generator: Optional[torch.Generator] = None,
+                              latent: Optional[torch.FloatTensor] = None, low_resource: bool = False,
+                              uncond_embeddings_list=None, height: Optional[int] = None, width: Optional[int] = None,
+                              return_latents: bool = False):
+        if controller is not None:
+            register_attention_control(model, controller)
+        if height is None:
+            height = width = model.unet.config.sample_size * model.vae_scale_factor
+        batch_size = len(prompt)
+        uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+        latent, latents = self.init_latent(latent, model, height, width, generator, batch_size)
+        model.scheduler.set_timesteps(num_inference_steps)
+        context = torch.cat([uncond_embeddings, text_embeddings])
+        if _fusable(model, controller, low_resource):
+            loop = FusedDenoiser(model, context, batch_size, (height // 8, width // 8), guidance_scale,
+                                 uncond_list=uncond_embeddings_list)
+            try:
+                latents = loop.run(latents)
+            finally:
+                loop.release()
+        else:
+            for i, t in enumerate(tqdm(model.scheduler.timesteps, desc="Now doing P2P editing")):
+                if uncond_embeddings_list is not None:
+                    context = torch.cat([uncond_embeddings_list[i].expand(*text_embeddings.shape), text_embeddings])
+                latents = self.diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource)
+        if return_latents:
+            return latents, latent
+        image = self.latent2image(model.vae, latents)
+        return image, latent
+
+    def diffusion_step(self, model, controller, latents, context, t, guidance_scale, low_resource=False):
+        """one eager step (`sd_utils.py:67-79`); CFG + DDIM update fused in one kernel."""
+        latents = latents.float().contiguous()
+        if low_resource:
+            bp = latents.shape[0]
+            eps_u = model.unet(latents, t, encoder_hidden_states=context[:bp])["sample"]
+            eps_c = model.unet(latents, t, encoder_hidden_states=context[bp:])["sample"]
+        else:
+            eps = model.unet(torch.cat([latents] * 2), t, encoder_hidden_states=context)["sample"]
+            eps_u, eps_c = eps.chunk(2)
+        a_t, a_p = model.scheduler.step_coeffs(int(t))
+        coef = torch.tensor([a_t, a_p, float(guidance_scale)], dtype=torch.float32, device=latents.device)
+        latents = hip.cfg_ddim_step(eps_u.contiguous(), eps_c.contiguous(), latents, coef)
+        if controller is not None:
+            latents = controller.step_callback(latents)
+        return latents
+
+    @torch.no_grad()
+    def latent2image(self, vae, latents):
+        latents = 1 / vae.config.scaling_factor * latents
+        image = vae.decode(latents)["sample"]
+        image = (image / 2 + 0.5).clamp(0, 1)
+        image = image.cpu().permute(0, 2, 3, 1).numpy()
+        return (image * 255).astype(np.uint8)
+
+
+class P2P_NTI(P2P):
+    """`text2image_ldm_stable(..., uncond_embeddings_list=[50 x [1,77,C]])` (:92-140): the base class
+    already takes the per-step null-text embeddings, selected per step on the device."""

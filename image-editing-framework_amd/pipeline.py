@@ -1,0 +1,179 @@
+"""Duck-typed `StableDiffusionPipeline` — the object the reference's editors call `model` / `pipe`.
+
+The reference dispatches on `pipe.__class__.__name__ == "StableDiffusionPipeline"`
+(`/root/reference/p2p/edit_syn.py:90`) and touches only the attributes listed in SURVEY.md §8b:
+`tokenizer`, `text_encoder`, `unet`, `vae`, `scheduler`, `device`, `_execution_device`,
+`vae_scale_factor`.  `from_pretrained(key, torch_dtype=..., scheduler=...)` accepts
+
+  "synthetic:<cfg>[:seed]"   seeded random weights of a named UNet config (no checkpoints exist
+                             offline) — what tests, smoke and bench use;
+  a local directory          diffusers layout (`unet/diffusion_pytorch_model.safetensors`, optional
+                             `tokenizer/`, `text_encoder/`) — real weights when a user has them.
+Hub names cannot be fetched here and raise a clear error.
+
+Off the per-step path (once per image) and therefore plain PyTorch-ROCm ops for now: the text
+encoder and the VAE (SURVEY.md §8f rank 3 lists the VAE as a "next" row).  Without a checkpoint
+both are small seeded stand-ins with the right interfaces and shapes.
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .config import CONFIGS, UNetConfig
+from .scheduler import DDIMScheduler
+from .tokenizer import WordPieceTokenizer
+from . import weights as _weights
+
+
+class SyntheticTextEncoder(nn.Module):
+    """token ids [B,77] -> ([B,77,C] fp32,): seeded embedding + position table, one mixing layer."""
+
+    def __init__(self, dim: int, vocab: int = 49408, max_len: int = 77, seed: int = 1):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.register_buffer("tok", torch.randn(vocab, dim, generator=g) * 0.1)
+        self.register_buffer("pos", torch.randn(max_len, dim, generator=g) * 0.02)
+        self.register_buffer("mix", torch.eye(max_len) * 0.9 + torch.full((max_len, max_len), 0.1 / max_len))
+        self.dtype = torch.float32
+
+    @property
+    def device(self):
+        return self.tok.device
+
+    def forward(self, input_ids, **kw):
+        x = self.tok[input_ids.to(self.tok.device)] + self.pos[None, : input_ids.shape[1]]
+        x = torch.einsum("ts,bsc->btc", self.mix[: x.shape[1], : x.shape[1]], x)
+        return (x,)
+
+
+class _LatentDist:
+    def __init__(self, moments):
+        self.mean, self.logvar = moments.chunk(2, dim=1)
+
+    def sample(self, generator=None):
+        return self.mean
+
+    def mode(self):
+        return self.mean
+
+
+class SyntheticVAE(nn.Module):
+    """8x down / 8x up convolutional stand-in for AutoencoderKL (same call surface, seeded weights).
+
+    encode(img [B,3,H,W] in [-1,1]) -> {'latent_dist': dist with .mean [B,4,H/8,W/8]}
+    decode(z   [B,4,h,w])           -> {'sample': [B,3,8h,8w]}
+    (`/root/reference/p2p/inversion/ddim.py:39-40`, `/root/reference/p2p/model/sd_utils.py:83-84`)
+    """
+
+    def __init__(self, seed: int = 2, latent_channels: int = 4):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+
+        def conv(cout, cin, k):
+            w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+            return nn.Parameter(w, requires_grad=False)
+
+        self.e1, self.e2, self.e3 = conv(32, 3, 3), conv(64, 32, 3), conv(128, 64, 3)
+        self.e4 = conv(2 * latent_channels, 128, 3)
+        self.d1, self.d2, self.d3 = conv(128, latent_channels, 3), conv(64, 128, 3), conv(32, 64, 3)
+        self.d4 = conv(3, 32, 3)
+        self.config = SimpleNamespace(scaling_factor=0.18215, latent_channels=latent_channels)
+        self.dtype = torch.float32
+
+    def encode(self, x):
+        x = x.to(self.e1.dtype)
+        h = F.silu(F.conv2d(x, self.e1, stride=2, padding=1))
+        h = F.silu(F.conv2d(h, self.e2, stride=2, padding=1))
+        h = F.silu(F.conv2d(h, self.e3, stride=2, padding=1))
+        return {"latent_dist": _LatentDist(F.conv2d(h, self.e4, padding=1))}
+
+    def decode(self, z):
+        z = z.to(self.d1.dtype)
+        h = F.silu(F.conv2d(z, self.d1, padding=1))
+        h = F.silu(F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), self.d2, padding=1))
+        h = F.silu(F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), self.d3, padding=1))
+        h = torch.tanh(F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), self.d4, padding=1))
+        return {"sample": h}
+
+
+class StableDiffusionPipeline:
+    def __init__(self, unet, tokenizer, text_encoder, vae, scheduler, cfg: UNetConfig, state_dict=None):
+        self.unet, self.tokenizer, self.text_encoder, self.vae, self.scheduler = unet, tokenizer, text_encoder, vae, scheduler
+        self.cfg = cfg
+        self.vae_scale_factor = 8
+        self._state_dict = state_dict  # kept on the host only when the caller asked (tests / oracle side)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
+                        keep_state_dict: bool = False, **unused):
+        from .unet import UNet2DConditionModel
+        if model_key.startswith("synthetic:"):
+            parts = model_key.split(":")
+            cfg = CONFIGS[parts[1]]
+            seed = int(parts[2]) if len(parts) > 2 else 0
+            sd = _weights.synthetic_state_dict(cfg, seed)
+            tokenizer = WordPieceTokenizer(cfg.text_max_length)
+            text_encoder = SyntheticTextEncoder(cfg.cross_attention_dim)
+            vae = SyntheticVAE()
+        elif os.path.isdir(model_key):
+            cfg, sd = _load_local_unet(model_key)
+            tokenizer, text_encoder = _load_local_text(model_key, cfg)
+            vae = SyntheticVAE()  # TODO(next row): AutoencoderKL weights from `vae/`
+        else:
+            raise FileNotFoundError(
+                f"'{model_key}' is neither 'synthetic:<cfg>' nor a local directory.  Hub names cannot be fetched "
+                "offline: point sd_mapping.sd_maps at a local diffusers-layout directory (README of the reference, "
+                "lines 30-32) or use 'synthetic:sd15'.")
+        unet = UNet2DConditionModel(cfg, sd, device=device)
+        text_encoder = text_encoder.to(device)
+        vae = vae.to(device)
+        sched = scheduler if scheduler is not None else DDIMScheduler()
+        return cls(unet, tokenizer, text_encoder, vae, sched, cfg, sd if keep_state_dict else None)
+
+    def to(self, device):
+        if torch.device(device) != self.unet.device:
+            raise RuntimeError("the UNet's packed weights were placed at construction; pass device= to from_pretrained")
+        return self
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+
+def _load_local_unet(path):
+    import json
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "unet", "config.json")) as f:
+        c = json.load(f)
+    heads = c["attention_head_dim"]
+    nlev = len(c["block_out_channels"])
+    heads = tuple(heads) if isinstance(heads, (list, tuple)) else (heads,) * nlev
+    cfg = UNetConfig(
+        sample_size=c["sample_size"], in_channels=c["in_channels"], out_channels=c["out_channels"],
+        block_out_channels=tuple(c["block_out_channels"]),
+        down_has_attn=tuple("CrossAttn" in t for t in c["down_block_types"]),
+        layers_per_block=c["layers_per_block"], cross_attention_dim=c["cross_attention_dim"], num_heads=heads,
+        norm_num_groups=c["norm_num_groups"], norm_eps=c.get("norm_eps", 1e-5))
+    if c.get("use_linear_projection", False):
+        raise NotImplementedError("linear proj_in/proj_out (SD2.x) is a next-tier shape family (SURVEY.md §8f-4)")
+    sd = load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
+    missing = [k for k in _weights.unet_param_shapes(cfg) if k not in sd]
+    if missing:
+        raise KeyError(f"checkpoint lacks {len(missing)} UNet tensors, e.g. {missing[:3]}")
+    return cfg, {k: v.float() for k, v in sd.items()}
+
+
+def _load_local_text(path, cfg):
+    tok_dir, te_dir = os.path.join(path, "tokenizer"), os.path.join(path, "text_encoder")
+    if os.path.isdir(tok_dir) and os.path.isdir(te_dir):
+        from transformers import CLIPTextModel, CLIPTokenizer
+        return CLIPTokenizer.from_pretrained(tok_dir), CLIPTextModel.from_pretrained(te_dir)
+    return WordPieceTokenizer(cfg.text_max_length), SyntheticTextEncoder(cfg.cross_attention_dim)

@@ -141,6 +141,7 @@ class Attention(nn.Module):
         self.processor = None
         self._plan = None          # control.ControlPlan when a lowered controller is registered
         self._kv_key, self._kv = None, None
+        self.cache_kv = True       # False when the context changes every step (null-text embeddings)
 
     # ---- protocol used by hook closures (generic path)
     def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
@@ -182,8 +183,12 @@ class Attention(nn.Module):
 
     # ---- cross-attention K/V of a fixed context are step-invariant: project once per context
     def context_kv(self, ctx):
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
-        if self._kv_key != key:
+        if not self.cache_kv:
+            return hip.gemm(ctx, self.w_kv)
+        # identity (not address) of the context tensor: the cache holds a reference, so the allocator
+        # cannot hand the same address to a different context while the entry is alive
+        key = (ctx, ctx._version)
+        if self._kv_key is None or self._kv_key[0] is not ctx or self._kv_key[1] != ctx._version:
             self._kv = hip.gemm(ctx, self.w_kv)
             self._kv_key = key
         return self._kv
@@ -247,7 +252,7 @@ class BasicTransformerBlock(nn.Module):
             return attn(x, encoder_hidden_states=ctx, residual=res)
         # a hook owns forward: reference signature, residual added here (one extra fp16 rounding)
         out = attn(x, encoder_hidden_states=ctx)
-        return hip.gemm_free_add(out, res)
+        return hip.add(out.contiguous(), res)
 
     def forward(self, h, ctx):
         h = self._attend(self.attn1, self.norm1(h), h, None)
@@ -491,7 +496,7 @@ class UNet2DConditionModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None,
-                added_cond_kwargs=None, return_dict=True, temb_row=None, **kw):
+                added_cond_kwargs=None, return_dict=True, temb_row=None, taps=None, **kw):
         """sample fp32/fp16 NCHW [B,4,H,W]; timestep scalar / 0-d tensor; ctx [B,77,Cc] -> eps fp32 NCHW.
 
         `temb_row` (fp32 [1, width]) short-circuits the time embedding for the captured-graph loop."""
@@ -510,9 +515,14 @@ class UNet2DConditionModel(nn.Module):
         if self._plan is not None:
             self._plan.begin_forward(B)
 
+        def tap(name, v):  # debugging / parity aid: same tap points as oracle/unet_ref.py
+            if taps is not None:
+                taps[name] = v.float().permute(0, 3, 1, 2).cpu()
+
         h = hip.conv_in(x, self.conv_in.weight, self.conv_in.bias)
+        tap("conv_in", h)
         skips = [h]
-        for blk in self.down_blocks:
+        for bi, blk in enumerate(self.down_blocks):
             for j, res in enumerate(blk.resnets):
                 h = res(h, trow(res))
                 if blk.has_cross_attention:
@@ -521,16 +531,19 @@ class UNet2DConditionModel(nn.Module):
             if blk.downsamplers is not None:
                 h = blk.downsamplers[0](h)
                 skips.append(h)
+            tap(f"down{bi}", h)
         h = self.mid_block.resnets[0](h, trow(self.mid_block.resnets[0]))
         h = self.mid_block.attentions[0](h, ctx)
         h = self.mid_block.resnets[1](h, trow(self.mid_block.resnets[1]))
-        for blk in self.up_blocks:
+        tap("mid", h)
+        for bi, blk in enumerate(self.up_blocks):
             for j, res in enumerate(blk.resnets):
                 h = res(h, trow(res), skip=skips.pop())
                 if blk.has_cross_attention:
                     h = blk.attentions[j](h, ctx)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0](h)
+            tap(f"up{bi}", h)
         h = self.conv_norm_out(h, silu=True)
         eps = hip.conv_out(h, self.conv_out.weight, self.conv_out.bias)
         if self._plan is not None:
@@ -541,11 +554,10 @@ class UNet2DConditionModel(nn.Module):
 
     def _ctx_f16(self, ctx):
         """fp32 context -> fp16 once per distinct tensor (keeps the cross-attention K/V cache valid)."""
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
         cache = getattr(self, "_ctx_cache", None)
-        if cache is None or cache[0] != key:
-            self._ctx_cache = (key, hip.to_f16(ctx.contiguous()))
-        return self._ctx_cache[1]
+        if cache is None or cache[0] is not ctx or cache[1] != ctx._version:
+            self._ctx_cache = (ctx, ctx._version, hip.to_f16(ctx.float().contiguous()))
+        return self._ctx_cache[2]
 
 
 class _Config:

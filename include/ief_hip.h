@@ -55,6 +55,12 @@ typedef struct IefGemmParams {
     int rows_per_batch;
     float out_scale;
     int tile_hint;            /* 0 auto; 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64       */
+    /* conv only: extra K range appended after the 9 taps, read at the OUTPUT pixel itself
+     * (a fused 1x1 convolution over up to two more NHWC sources, e.g. ResnetBlock2D.conv_shortcut
+     * over the un-concatenated [x | skip]); W rows are then [9*(C1+C2) + CE1 + CE2] long.
+     * Requires stride 1, no upsample. */
+    const ief_half* E1; const ief_half* E2;
+    int CE1, CE2;
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);
@@ -142,6 +148,8 @@ int ief_cfg_ddim_step_f32(const float* eps_u, const float* eps_c, const float* x
                           float* x0_out, const float* coef, long long n, void* stream);
 /* sinusoidal timestep embedding, flip_sin_to_cos, shift 0: out fp16 [B][dim] = [cos | sin] */
 int ief_timestep_embedding_f16(const float* t, ief_half* out, int B, int dim, void* stream);
+/* out = a + b elementwise on fp16 (residual add when a hook owns Attention.forward) */
+int ief_add_f16(const ief_half* a, const ief_half* b, ief_half* out, long long n, void* stream);
 /* y = silu(x) elementwise on fp16 (ResnetBlock2D time_emb_proj input) */
 int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void* stream);
 /* fp16 <-> fp32 casts and row gather used to stage per-step tables inside a captured graph:

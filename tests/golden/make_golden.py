@@ -40,20 +40,8 @@ from inversion import nti as ref_nti  # noqa: E402
 
 CPU = torch.device("cpu")
 
-PROMPT_PAIRS = [
-    ("a photo of a house on a mountain", "a photo of a house on a mountain at fall"),  # edit_syn default
-    ("a gray horse in the field", "a whie horse in the field"),  # edit_real default (typo is the reference's)
-    ("a cat sitting on a bench", "a dog sitting on a bench"),
-    ("a cat sitting on a bench", "a cat sitting on a wooden bench"),
-    ("a extraordinarily fluffy cat", "a fluffy cat"),
-    ("photo of a cat riding on a bicycle", "photo of a cat riding on a motorcycle"),
-    ("a bowl of fruit", "a bowl of strawberries and fruit on the table"),
-    ("soup", "pea soup"),
-    ("the quick brown fox jumps", "the quick red fox leaps"),
-    ("a b c d e f g", "a c e g"),
-    ("children drawing of a castle next to a river", "children drawing of a castle next to a river"),
-    ("interchangeable characteristics", "interchangeable words"),
-]
+sys.path.insert(0, HERE)
+from make_golden_inputs import PROMPT_PAIRS, softmax_maps as _softmax_maps  # noqa: E402
 
 
 def g1_g2(tok):
@@ -79,11 +67,6 @@ def g1_g2(tok):
     out["equalizer"] = ref_aligner.get_equalizer(tok, b, ("fall", "mountain"), (4.0,)).numpy()
     np.savez_compressed(os.path.join(HERE, "p2p_host.npz"), **out)
     print("p2p_host.npz", len(out), "arrays")
-
-
-def _softmax_maps(seed, bh, n, l):
-    g = torch.Generator().manual_seed(seed)
-    return torch.softmax(torch.randn(bh, n, l, generator=g) * 2.0, dim=-1)
 
 
 def g3_g4_g5(tok):

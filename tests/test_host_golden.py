@@ -1,0 +1,218 @@
+"""CPU tests: host-side mirror AND oracle restatement against golden vectors produced by the
+reference's own modules (`tests/golden/make_golden.py`).  Integer outputs bit-exact; float outputs
+exact where the reference arithmetic is reproduced operation for operation, else 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ief_amd.tokenizer import WordPieceTokenizer
+from ief_amd.p2p.model import attention_base, attention_control, ptp_utils, seq_aligner
+from ief_amd.scheduler import DDIMScheduler
+from oracle import p2p_ref
+
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from make_golden_inputs import PROMPT_PAIRS, softmax_maps  # noqa: E402
+
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return WordPieceTokenizer()
+
+
+@pytest.fixture(scope="module")
+def host(golden_dir):
+    return np.load(os.path.join(golden_dir, "p2p_host.npz"))
+
+
+@pytest.fixture(scope="module")
+def ctrl(golden_dir):
+    return np.load(os.path.join(golden_dir, "p2p_ctrl.npz"))
+
+
+@pytest.fixture(scope="module")
+def ddim(golden_dir):
+    return np.load(os.path.join(golden_dir, "ddim_nti.npz"))
+
+
+# ------------------------------------------------------------------------------------ G1 / G2
+def test_tokenizer_ids_stable(tok, host):
+    for k, (a, b) in enumerate(PROMPT_PAIRS):
+        assert np.array_equal(np.array(tok.encode(a)), host[f"ids_a_{k}"])
+        assert np.array_equal(np.array(tok.encode(b)), host[f"ids_b_{k}"])
+
+
+def test_refinement_mapper_bit_exact(tok, host):
+    for k, (a, b) in enumerate(PROMPT_PAIRS):
+        mapper, alphas = seq_aligner.get_refinement_mapper([a, b], tok)
+        assert mapper.dtype == torch.int64
+        assert np.array_equal(mapper.numpy(), host[f"refine_mapper_{k}"]), k
+        assert np.array_equal(alphas.numpy(), host[f"refine_alphas_{k}"]), k
+
+
+def test_replacement_mapper_exact(tok, host):
+    n = 0
+    for k, (a, b) in enumerate(PROMPT_PAIRS):
+        if len(a.split(" ")) == len(b.split(" ")):
+            m = seq_aligner.get_replacement_mapper([a, b], tok)
+            assert np.array_equal(m.numpy(), host[f"replace_mapper_{k}"]), k
+            n += 1
+        else:
+            with pytest.raises(ValueError):
+                seq_aligner.get_replacement_mapper([a, b], tok)
+    assert n >= 4
+
+
+def test_alpha_tables_and_word_inds(tok, host):
+    a, b = PROMPT_PAIRS[0]
+    f = ptp_utils.get_time_words_attention_alpha
+    assert np.array_equal(f([a, b], 50, 0.8, tok).numpy(), host["alpha_f08"])
+    assert np.array_equal(f([a, b], 50, (0.2, 0.9), tok).numpy(), host["alpha_t0209"])
+    assert np.array_equal(f([a, b], 50, {"default_": 1.0, "fall": (0.0, 0.4), "mountain": (0.3, 0.7)}, tok).numpy(),
+                          host["alpha_dict"])
+    assert np.array_equal(f([a, b, "a photo of a castle on a mountain"], 50, 0.6, tok).numpy(), host["alpha_3prompts"])
+    assert np.array_equal(ptp_utils.get_word_inds(b, "mountain", tok), host["word_inds_mountain"])
+    assert np.array_equal(ptp_utils.get_word_inds(b, 5, tok), host["word_inds_5"])
+    assert np.array_equal(ptp_utils.get_word_inds(PROMPT_PAIRS[11][0], "characteristics", tok), host["word_inds_long"])
+    assert np.array_equal(seq_aligner.get_equalizer(tok, b, ("fall", "mountain"), (4.0,)).numpy(), host["equalizer"])
+
+
+# ------------------------------------------------------------------------------------ G3
+def _controllers(tok):
+    a, b = PROMPT_PAIRS[0]
+    a2, b2 = PROMPT_PAIRS[2]
+    third = "a photo of a tree house on a mountain"
+    return {
+        "refine": (2, lambda: attention_control.AttentionRefine([a, b], tok, 50, 0.8, 0.4, device=CPU)),
+        "replace": (2, lambda: attention_control.AttentionReplace([a2, b2], tok, 50, 0.8, 0.4, device=CPU)),
+        "reweight": (2, lambda: attention_control.AttentionReweight(
+            [a, b], tok, 50, 0.8, 0.4, seq_aligner.get_equalizer(tok, b, ("fall",), (3.0,)), device=CPU)),
+        "refine3": (3, lambda: attention_control.AttentionRefine([a, b, third], tok, 50, (0.1, 0.7), (0.1, 0.5), device=CPU)),
+    }
+
+
+SHAPES = [(True, 64, 77), (False, 64, 64), (False, 320, 320), (True, 16, 77)]
+STEPS = (0, 4, 19, 20, 39, 40, 49)
+
+
+def _as_oracle(c, nprompt):
+    name = type(c).__name__
+    return p2p_ref.P2PControlRef(
+        mode={"AttentionRefine": "refine", "AttentionReplace": "replace", "AttentionReweight": "reweight"}[name],
+        num_prompts=nprompt, cross_alpha=c.cross_replace_alpha, num_self_replace=c.num_self_replace,
+        mapper=getattr(c, "mapper", None), alphas=getattr(c, "alphas", None), equalizer=getattr(c, "equalizer", None))
+
+
+@pytest.mark.parametrize("which", ["mirror", "oracle"])
+@pytest.mark.parametrize("name", ["refine", "replace", "reweight", "refine3"])
+def test_controller_sweeps_match_reference(which, name, tok, ctrl):
+    nprompt, make = _controllers(tok)[name]
+    bh = 2 * nprompt * 2
+    for step in STEPS:
+        c = make()
+        if which == "oracle":
+            c = _as_oracle(c, nprompt)
+        c.num_att_layers = 4
+        c.cur_step = step
+        for li, (is_cross, n, l) in enumerate(SHAPES):
+            x = softmax_maps(1000 + li, bh, n, l)
+            y = c(x.clone(), is_cross, "down")
+            key = f"{name}_s{step}_l{li}"
+            assert torch.equal(x[: bh // 2], y[: bh // 2]) == bool(ctrl[key + "_uncond_same"])
+            if not is_cross and n > 256:
+                assert torch.equal(x, y) == bool(ctrl[key + "_unchanged"])
+            else:
+                assert np.array_equal(y[bh // 2:].numpy(), ctrl[key]), key
+        assert [c.cur_step, c.cur_att_layer] == list(ctrl[f"{name}_s{step}_after"])
+
+
+def test_controller_edits_in_place_and_aliases(tok):
+    _, make = _controllers(tok)["refine"]
+    c = make()
+    c.num_att_layers = 10
+    x = softmax_maps(1, 8, 64, 77)
+    y = c(x, True, "up")
+    assert y.data_ptr() == x.data_ptr()          # returned tensor aliases the argument (attention_base.py:22)
+    assert not torch.equal(x, softmax_maps(1, 8, 64, 77))  # ... and was edited in place
+
+
+def test_attention_store_matches_reference(ctrl):
+    st = attention_base.AttentionStore(False)
+    st.num_att_layers = 3
+    for step in range(3):
+        for li, (is_cross, n, l) in enumerate([(True, 64, 77), (False, 64, 64), (False, 1600, 8)]):
+            st(softmax_maps(2000 + 10 * step + li, 4, n, l), is_cross, ["down", "mid", "up"][li])
+    avg = st.get_average_attention()
+    for key, maps in avg.items():
+        assert len(maps) == int(ctrl[f"store_{key}_n"])
+        for i, m in enumerate(maps):
+            assert np.array_equal(m.numpy(), ctrl[f"store_{key}_{i}"])
+    st.reset()
+    assert st.cur_step == 0 and st.attention_store == {}
+
+
+def test_local_blend_matches_reference(tok, ctrl):
+    a, b = PROMPT_PAIRS[0]
+    lb = ptp_utils.LocalBlend(tok, [a, b], [["house"], ["fall"]], device=CPU)
+    assert np.array_equal(lb.alpha_layers.numpy(), ctrl["localblend_alpha_layers"])
+    store = {"down_cross": [softmax_maps(3000 + i, 4, 256, 77) for i in range(4)],
+             "up_cross": [softmax_maps(3100 + i, 4, 256, 77) for i in range(3)]}
+    x_t = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(7))
+    assert np.allclose(lb(x_t, store).numpy(), ctrl["localblend_out"], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ G6 scheduler
+def test_scheduler_constants_and_reverse(ddim):
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert np.array_equal(s.timesteps.numpy(), ddim["ddim_timesteps"])
+    assert s.timesteps[0] == 981 and s.timesteps[-1] == 1
+    assert np.array_equal(s.alphas_cumprod.numpy(), ddim["alphas_cumprod"])
+    ref = p2p_ref.DDIMRef(50)
+    assert np.array_equal(ref.timesteps.numpy(), ddim["ddim_timesteps"])
+    x, e = torch.from_numpy(ddim["ddim_x"]), torch.from_numpy(ddim["ddim_eps"])
+    for t in s.timesteps.tolist():
+        want = ddim[f"ddim_reverse_t{t}"]
+        assert np.array_equal(ref.reverse(e, t, x).numpy(), want), t        # oracle: operation-for-operation
+        a_c, a_n = s.reverse_coeffs(t)                                       # product: same constants (kernel checked on GPU)
+        x0 = (x - (1 - a_c) ** 0.5 * e) / a_c ** 0.5
+        assert np.allclose((a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * e).numpy(), want, rtol=0, atol=2e-6), t
+
+
+def test_scheduler_step_coeffs_edges():
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    a_t, a_p = s.step_coeffs(1)
+    assert a_p == float(s.final_alpha_cumprod) == float(s.alphas_cumprod[0])   # prev = -19 -> final_alpha_cumprod
+    a_c, a_n = s.reverse_coeffs(1)
+    assert a_c == float(s.final_alpha_cumprod) and a_n == float(s.alphas_cumprod[1])
+    with pytest.raises(ValueError):
+        s.step(torch.zeros(1), 1, torch.zeros(1), eta=0.5)
+
+
+# ------------------------------------------------------------------------------------ G8 NTI loop (oracle)
+def test_oracle_nti_loop_matches_reference(ddim):
+    import types
+    w1, w2 = torch.from_numpy(ddim["nti_w1"]), torch.from_numpy(ddim["nti_w2"])
+
+    def toy(sd, cfg, x, t, ctx, **kw):
+        c = (ctx @ w2).mean(1)
+        return torch.tanh(torch.einsum("bchw,cd->bdhw", x, w1) + c[:, :, None, None] + float(t) * 1e-3)
+
+    sched = p2p_ref.DDIMRef(5)
+    assert np.array_equal(sched.timesteps.numpy(), ddim["nti_timesteps"])
+    lat = [torch.from_numpy(a) for a in ddim["nti_latents"]]
+    ctx = torch.from_numpy(ddim["nti_ctx"])
+    saved = p2p_ref.unet_ref.unet_forward
+    p2p_ref.unet_ref.unet_forward = toy
+    try:
+        out = p2p_ref.null_optimization(None, None, lat, ctx, sched, 10, 1e-5, 7.5)
+    finally:
+        p2p_ref.unet_ref.unet_forward = saved
+    got = np.stack([u.numpy() for u in out])
+    assert got.shape == ddim["nti_uncond"].shape
+    assert np.allclose(got, ddim["nti_uncond"], atol=1e-6)
