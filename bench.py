@@ -1,0 +1,235 @@
+"""Headline benchmark: denoising steps/sec of the SD1.5 512x512 Prompt-to-Prompt edit loop.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: one denoising step of the P2P edit loop =
+UNet forward at batch 4 (2 prompts x classifier-free guidance) with the AttentionRefine controller
+active + CFG combine + DDIM update (`/root/reference/p2p/model/sd_utils.py:67-79`), SD1.5-shaped
+UNet (859.5 M parameters), 64x64 latents (512x512 images), 50-step schedule, synthetic seeded
+weights / latents / embeddings resident in HBM before the timed region.
+
+N > 1: one process per GPU; every rank runs its OWN edit (PIE-Bench images are independent:
+`/root/reference/p2p/test.py:114-181`), so there is no data-path collective; the only collective is
+the one-time RCCL broadcast of the packed weights from rank 0.  value = total steps of all ranks
+divided by the slowest rank's time ("weak" scaling).
+
+The JSON line also carries
+  roofline      dominant kernel (3x3 implicit-GEMM conv, 128x128 tile): algorithmic FLOP per launch
+                / average launch duration measured live with HIP events on the launch stream,
+                against the 2.5 PFLOP/s dense fp16 MFMA peak
+  cpu_baseline  the fp32 CPU oracle (`oracle/`, reference execution semantics: materialised maps +
+                Python controller) timed on this host's cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PROMPTS = ["a photo of a house on a mountain", "a photo of a house on a mountain at fall"]  # edit_syn.py:20-21
+FLOP_PER_STEP = 3.213e12      # 0.803 TFLOP / sample-forward x 4
+PEAK_MFMA_F16 = 2.5e15        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+MAX_STEPS = 50                # controller tables cover one 50-step edit
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=str, default="sd15")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build_pipe(cfg_name, dev, rank, world):
+    """rank 0 draws the synthetic weights; other ranks receive the PACKED device tensors by RCCL broadcast."""
+    import ief_amd  # noqa: F401
+    from ief_amd import config, weights
+    from ief_amd.pipeline import StableDiffusionPipeline, SyntheticTextEncoder, SyntheticVAE
+    from ief_amd.scheduler import DDIMScheduler
+    from ief_amd.tokenizer import WordPieceTokenizer
+    from ief_amd.unet import UNet2DConditionModel
+    cfg = config.CONFIGS[cfg_name]
+    if rank == 0:
+        sd = weights.synthetic_state_dict(cfg, 0)
+    else:
+        sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(cfg).items()}
+    unet = UNet2DConditionModel(cfg, sd, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        for t in unet.packed_tensors():
+            dist.broadcast(t, src=0)
+        torch.cuda.synchronize()
+    pipe = StableDiffusionPipeline(unet, WordPieceTokenizer(cfg.text_max_length),
+                                   SyntheticTextEncoder(cfg.cross_attention_dim).to(dev), SyntheticVAE().to(dev),
+                                   DDIMScheduler(), cfg, sd if rank == 0 else None)
+    return pipe, cfg
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ief_amd import hip
+    from ief_amd.denoise import FusedDenoiser
+    from ief_amd.p2p.model.attention_control import AttentionRefine
+    from ief_amd.p2p.model.register import register_attention_control
+    from ief_amd.p2p.model.sd_utils import _encode_prompts
+    hip.load()
+
+    pipe, cfg = build_pipe(args.config, dev, rank, world)
+    pipe.scheduler.set_timesteps(MAX_STEPS)
+    hw = cfg.sample_size
+    # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19)
+    x_T = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(8888 + rank)).to(dev)
+    with torch.no_grad():
+        u, c = _encode_prompts(pipe, PROMPTS)
+    ctx = torch.cat([u, c])
+    ctrl = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
+    register_attention_control(pipe, ctrl)
+    loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5)
+
+    def run_steps(n):
+        """n steps, restarting the edit (controller + step counters) whenever 50 are used up"""
+        done = 0
+        while done < n:
+            room = MAX_STEPS - ctrl.cur_step
+            if room == 0:
+                ctrl.reset()
+                loop.plan.sync_step()
+                loop.step.zero_()
+                room = MAX_STEPS
+            k = min(room, n - done)
+            for _ in range(k):
+                loop.graph.replay()
+                loop.plan.replay_done()
+            done += k
+
+    loop.run(x_T, num_steps=0)          # allocates, warms up eagerly (untimed) and captures the graph
+    run_steps(args.warmup)
+    ctrl.reset(); loop.plan.sync_step(); loop.step.zero_(); loop.lat.copy_(x_T.expand_as(loop.lat))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = te.item()
+    assert torch.isfinite(loop.lat).all()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    out = {
+        "metric": "denoising steps/sec (SD1.5 512x512 P2P edit step, UNet batch 4)",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{args.config} UNet (859.5M params) P2P AttentionRefine edit step, 2 prompts x CFG = batch 4, "
+                               f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4; "
+                               "one independent edit per GPU",
+                   "images_per_sec_equiv": round(value / 250.0, 4)},
+    }
+    if rank == 0:
+        out["roofline"] = roofline(pipe, loop, ctrl, x_T, value, world)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pipe, cfg, ctx, x_T, ctrl, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
+    """dominant kernel's algorithmic FLOP/s from per-launch HIP-event timings of one eager step"""
+    from ief_amd import hip
+    loop.release()
+    ctrl.reset()
+    loop.use_graph = False
+    loop.lat.copy_(x_T.expand_as(loop.lat)); loop.step.zero_()
+    loop._step_body()                      # eager warm-up of the un-captured path
+    torch.cuda.synchronize()
+    hip.profile_begin()
+    loop._step_body()
+    rec = hip.profile_end()
+    agg = {}
+    for name, flops, ms in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += flops; a[2] += ms
+    total_ms = sum(a[2] for a in agg.values())
+    name, (n, flops, ms) = max(agg.items(), key=lambda kv: kv[1][2])
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "kernel": name, "launches_per_step": n,
+        "avg_launch_ms": round(ms / n, 4), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
+        "achieved": round(achieved, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
+        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
+        "kernel_share_of_step": round(ms / total_ms, 3),
+        "whole_step": {"alg_tflop_per_step": FLOP_PER_STEP / 1e12,
+                       "achieved": round(steps_per_sec / world * FLOP_PER_STEP / 1e12, 2),
+                       "frac": round(steps_per_sec / world * FLOP_PER_STEP / PEAK_MFMA_F16, 4)},
+        "per_kernel_ms": {k: round(v[2], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
+    }
+
+
+def cpu_baseline(pipe, cfg, ctx, x_T, ctrl, budget_s):
+    """the oracle (reference semantics, fp32 eager) on this host: bounded sample of the same workload"""
+    from oracle import p2p_ref, unet_ref
+    sd = pipe._state_dict
+    cores = torch.get_num_threads()
+    ref_ctrl = p2p_ref.P2PControlRef(mode="refine", num_prompts=2, cross_alpha=ctrl.cross_replace_alpha.float().cpu(),
+                                     num_self_replace=ctrl.num_self_replace, mapper=ctrl.mapper.cpu(),
+                                     alphas=ctrl.alphas.float().cpu())
+    ref_ctrl.num_att_layers = unet_ref.count_attention_layers(cfg)
+    sched = p2p_ref.DDIMRef(MAX_STEPS)
+    c = ctx.float().cpu()
+    lat = x_T.cpu().expand(2, -1, -1, -1).clone()
+
+    def step(i, lat):
+        t = sched.timesteps[i]
+        with torch.no_grad():
+            eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), t, c, hook=ref_ctrl)
+        e_u, e_c = eps.chunk(2)
+        return sched.step(e_u + 7.5 * (e_c - e_u), int(t), lat)
+
+    lat = step(0, lat)  # warm-up (untimed)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        lat = step(1 + n, lat)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 8:
+            break
+    return {"value": round(n / dt, 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed B=4 P2P edit steps of the fp32 eager oracle (materialised maps + Python controller) "
+                      f"after 1 warm-up step, {dt:.1f} s, torch threads={cores}"}
+
+
+if __name__ == "__main__":
+    main()

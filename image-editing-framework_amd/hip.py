@@ -121,6 +121,51 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ------------------------------------------------------------------------------- live kernel timing
+# bench.py brackets individual launches with HIP events ON THE STREAM THE KERNEL RUNS ON to get the
+# dominant kernel's average launch duration (roofline.achieved).  Off by default (zero overhead).
+_prof = None
+_TILES = {1: (128, 128), 2: (64, 128), 3: (64, 64), 4: (128, 64)}
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """-> list of (kernel_name, algorithmic_flops, milliseconds)"""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(name, flops, e0.elapsed_time(e1)) for name, flops, e0, e1 in rec]
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if _prof is not None:
+            self.e1.record(torch.cuda.current_stream())
+            _prof.append((self.name, self.flops, self.e0, self.e1))
+
+
+def pick_tile(M: int, N: int, batch: int = 1) -> int:
+    """tile choice (mirrors dispatch_igemm in csrc/gemm_conv.hip): fill the 256 CUs"""
+    nblk = lambda bm, bn: -(-M // bm) * -(-N // bn) * batch
+    if nblk(128, 128) >= 384:
+        return 1
+    if nblk(64, 128) >= 256:
+        return 2
+    return 3
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -191,8 +236,10 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     p.lda, p.ldw, p.ldo = lda, w.stride(0), ldo
     p.rows_per_batch = rows_per_batch
     p.out_scale = out_scale
-    p.tile_hint = tile_hint
-    _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
+    p.tile_hint = tile_hint or pick_tile(M, N)
+    bm, bn = _TILES[p.tile_hint]
+    with _Timed(f"igemm_f16_kernel<{bm}, {bn}, false>", 2.0 * M * N * K):
+        _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     return out
 
 
@@ -247,9 +294,12 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.H, p.Wd, p.C1, p.C2 = H, Wd, C1, C2
     p.stride, p.ups, p.batch_images = stride, 1 if upsample else 0, B
     p.out_scale = 1.0
-    p.tile_hint = tile_hint
+    M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
+    p.tile_hint = tile_hint or pick_tile(M, Cout)
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
-    _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
+    bm, bn = _TILES[p.tile_hint]
+    with _Timed(f"igemm_f16_kernel<{bm}, {bn}, true>", 2.0 * M * Cout * K):
+        _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
     return out
 
 
@@ -313,9 +363,10 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
         out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float16, device=x.device)
     splits = lib.ief_gn_splits(HW)
     partial = torch.empty(B * splits * groups * 2, dtype=torch.float32, device=x.device)
-    _check(lib.ief_groupnorm_silu_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
-                                      _dev32(beta, "beta").data_ptr(), partial.data_ptr(), B, HW, groups, eps,
-                                      1 if silu else 0, _stream()), "ief_groupnorm_silu_f16")
+    with _Timed("groupnorm(stats+apply)", 0.0):
+        _check(lib.ief_groupnorm_silu_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                          _dev32(beta, "beta").data_ptr(), partial.data_ptr(), B, HW, groups, eps,
+                                          1 if silu else 0, _stream()), "ief_groupnorm_silu_f16")
     return out
 
 
@@ -371,7 +422,8 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     _attn_common(p, q, k, v, out, heads)
     p.scale = scale
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
-    _check(lib.ief_attn_flash_f16(byref(p), _stream()), "ief_attn_flash_f16")
+    with _Timed(f"attn_flash_kernel<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
+        _check(lib.ief_attn_flash_f16(byref(p), _stream()), "ief_attn_flash_f16")
     return out
 
 
@@ -390,7 +442,8 @@ def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None
         if tuple(mt.shape[-2:]) != (96, 96) or not mt.is_contiguous() or coef.shape[-1] != 96:
             raise ValueError("attn_cross_p2p: mt must be [slots,96,96] fp16, coef [slots,2,96] fp32")
         p.MT, p.coef = mt.data_ptr(), coef.data_ptr()
-    _check(lib.ief_attn_cross_p2p_f16(byref(p), _stream()), "ief_attn_cross_p2p_f16")
+    with _Timed(f"attn_cross_p2p_kernel<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
+        _check(lib.ief_attn_cross_p2p_f16(byref(p), _stream()), "ief_attn_cross_p2p_f16")
     return out
 
 

@@ -481,6 +481,17 @@ class UNet2DConditionModel(nn.Module):
                 out += [m for m in child.modules() if m.__class__.__name__ == "Attention"]
         return out
 
+    def packed_tensors(self):
+        """every owning device tensor of the packed model (views excluded) — what a weight broadcast sends"""
+        seen, out = set(), []
+        holders = list(self.modules()) + [self]
+        for m in holders:
+            for v in vars(m).values():
+                if isinstance(v, torch.Tensor) and v.is_cuda and v._base is None and v.data_ptr() not in seen:
+                    seen.add(v.data_ptr())
+                    out.append(v)
+        return out
+
     def time_rows(self, timesteps_f32):
         """fp32 [T, sum Cout]: time_emb_proj(silu(time_embedding(time_proj(t)))) for every resnet at once."""
         emb = self.time_embedding(self.time_proj(timesteps_f32))
