@@ -30,6 +30,9 @@ struct AttnCfg {
     static constexpr int DT = (D + 31) / 32;   // 32-row output tiles of O^T
     static constexpr int KS = DP + 8;          // K row stride (halves): odd number of 16-B slots
     static constexpr int CPR = D / 8;          // 16-B chunks per K/V row
+    // D not a multiple of 32 leaves padding rows in the last O^T tile: row D of V^T is set to all ones, so
+    // the PV MFMA itself accumulates the softmax row sum (O^T[D][q] = sum_kv P[q][kv]) at no VALU cost.
+    static constexpr bool ONES_ROW = (D % 32) != 0;
 };
 
 __device__ __forceinline__ half8 pack8(const f32x16& p, int base) {
@@ -87,6 +90,10 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
 
     for (int i = tid; i < 64 * C::KS / 8; i += 256) ((half8*)Ks)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = tid; i < C::DT * 32 * VS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
+    if constexpr (C::ONES_ROW) {
+        __syncthreads();
+        if (tid < 64) Vt[D * VS + tid] = (half_t)1.0f;
+    }
 
     half8 qf[C::D16];
     load_q_frags<D>(qf, p.Q, ((long long)qs * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
@@ -144,35 +151,37 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
         }
+        // online softmax on RAW scores (scale folded into one fma per element: p = 2^(s*sc - m))
         const bool tail = kv0 + 64 > p.L;
-        float mx = -INFINITY;
+        if (tail) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
-            float a = s0[i] * sc, c = s1[i] * sc;
-            if (tail) {
-                if (kv0 + kvl >= p.L) a = -INFINITY;
-                if (kv0 + 32 + kvl >= p.L) c = -INFINITY;
+            for (int i = 0; i < 16; ++i) {
+                const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (kv0 + kvl >= p.L) s0[i] = -INFINITY;
+                if (kv0 + 32 + kvl >= p.L) s1[i] = -INFINITY;
             }
-            s0[i] = a; s1[i] = c;
-            mx = fmaxf(mx, fmaxf(a, c));
         }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx * sc);   // sc > 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float ls = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            s0[i] = exp2f(s0[i] - m_new);
-            s1[i] = exp2f(s1[i] - m_new);
-            ls += s0[i] + s1[i];
+            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], sc, -m_new));
+            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], sc, -m_new));
+            if constexpr (!C::ONES_ROW) ls += s0[i] + s1[i];
         }
-        l_run = l_run * alpha + ls;
+        if constexpr (!C::ONES_ROW) l_run = l_run * alpha + ls;
         m_run = m_new;
+        if (__any(alpha != 1.0f)) {  // rescale only when some row's running max moved (rare after the first tiles)
 #pragma unroll
-        for (int t = 0; t < C::DT; ++t)
+            for (int t = 0; t < C::DT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+                for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+        }
         const half8 pb00 = pack8(s0, 0), pb01 = pack8(s0, 8), pb10 = pack8(s1, 0), pb11 = pack8(s1, 8);
 #pragma unroll
         for (int t = 0; t < C::DT; ++t) {
@@ -188,7 +197,16 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
             __syncthreads();
         }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if constexpr (C::ONES_ROW) {
+        // row D of O^T: tile D/32, row i = D%32 = (reg&3) + 8(reg>>2) + 4h  ->  D%32 is a multiple of 8: reg = (D%32)/2, h = 0
+        constexpr int LT = D / 32, LR = (D % 32) / 2;
+        const float mine = o[LT][LR];
+        const float other = __shfl_xor(mine, 32);
+        l_tot = h ? other : mine;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
     const float inv = 1.0f / l_tot;
     if (q_ok) {
         half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;

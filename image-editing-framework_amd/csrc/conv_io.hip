@@ -10,61 +10,66 @@
 #define CIN_MAX 8
 #define COUT_MAX 8
 
-// block: 256 threads = PIX pixels x (Cout/8) channel chunks; weights staged in LDS as fp32 [9*Cin][Cout]
+// One block = CI_PIX consecutive output pixels x all Cout channels.  Weights ([9*Cin][Cout] fp16 -> fp32) and the im2col'ed input rows ([CI_PIX][9*Cin] fp32) are staged in LDS once; each thread
+// then produces 8 output channels for several pixels: 9*Cin broadcast reads + 8-wide LDS weight reads.
+#define CI_PIX 32
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const half_t* __restrict__ w,
                                                       const float* __restrict__ bias, half_t* __restrict__ out,
                                                       int B, int Cin, int H, int Wd, int Cout) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*Cin][Cout]
+    extern __shared__ __attribute__((aligned(16))) float smem_ci[];
     const int K = 9 * Cin;
-    for (int i = threadIdx.x; i < K * Cout; i += 256) {
-        const int co = i / K, k = i - co * K;          // w is [Cout][3][3][Cin] -> k = (ky*3+kx)*Cin + ci
-        wl[k * Cout + co] = (float)w[i];
+    float* wl = smem_ci;                 // [K][Cout]
+    float* xin = smem_ci + K * Cout;     // [CI_PIX][K]
+    for (int i = threadIdx.x; i < K * Cout; i += 256) wl[i] = (float)w[i];   // w is [3][3][Cin][Cout]: k-major
+    const long long total = (long long)B * H * Wd;
+    const long long pix0 = (long long)blockIdx.x * CI_PIX;
+    for (int i = threadIdx.x; i < CI_PIX * K; i += 256) {
+        const int pl = i / K, k = i - pl * K;
+        const long long pix = pix0 + pl;
+        float v = 0.f;
+        if (pix < total) {
+            const int b = (int)(pix / (H * Wd));
+            const int rem = (int)(pix - (long long)b * H * Wd);
+            const int oy = rem / Wd, ox = rem - oy * Wd;
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd)
+                v = x[(((long long)b * Cin + ci) * H + iy) * Wd + ix];
+        }
+        xin[i] = v;
     }
     __syncthreads();
     const int C8 = Cout >> 3;
-    const int pix_per_block = 256 / C8 > 0 ? 256 / C8 : 1;
-    const int tp = threadIdx.x / C8, c8 = threadIdx.x - tp * C8;
-    if (tp >= pix_per_block) return;
-    const long long pix = (long long)blockIdx.x * pix_per_block + tp;
-    const long long total = (long long)B * H * Wd;
-    if (pix >= total) return;
-    const int b = (int)(pix / (H * Wd));
-    const int rem = (int)(pix - (long long)b * H * Wd);
-    const int oy = rem / Wd, ox = rem - oy * Wd;
-    float acc[8];
+    for (int i = threadIdx.x; i < CI_PIX * C8; i += 256) {
+        const int pl = i / C8, c8 = i - pl * C8;
+        const long long pix = pix0 + pl;
+        if (pix >= total) continue;
+        float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy + ky - 1;
-        if ((unsigned)iy >= (unsigned)H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox + kx - 1;
-            if ((unsigned)ix >= (unsigned)Wd) continue;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float v = x[(((long long)b * Cin + ci) * H + iy) * Wd + ix];
-                const float* wr = wl + ((ky * 3 + kx) * Cin + ci) * Cout + c8 * 8;
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.f;
+        const float* xr = xin + pl * K;
+        for (int k = 0; k < K; ++k) {
+            const float v = xr[k];
+            const f32x4 w0 = *(const f32x4*)(wl + k * Cout + c8 * 8), w1 = *(const f32x4*)(wl + k * Cout + c8 * 8 + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += v * wr[e];
-            }
+            for (int e = 0; e < 4; ++e) { acc[e] += v * w0[e]; acc[4 + e] += v * w1[e]; }
         }
-    }
-    half8 o;
+        half8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
-    *(half8*)(out + pix * Cout + c8 * 8) = o;
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        *(half8*)(out + pix * Cout + c8 * 8) = o;
+    }
 }
 
 extern "C" int ief_conv_in_f32(const float* x, const ief_half* w, const float* bias, ief_half* out,
                                int B, int Cin, int H, int Wd, int Cout, void* stream) {
     if (!x || !w || !out) return IEF_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cin > CIN_MAX || Cout <= 0 || (Cout & 7) || Cout > 2048) return IEF_ESHAPE;
-    const size_t lds = (size_t)9 * Cin * Cout * sizeof(float);
+    const size_t lds = ((size_t)9 * Cin * Cout + (size_t)CI_PIX * 9 * Cin) * sizeof(float);
     if (lds > 64 * 1024) return IEF_ESHAPE;
-    const int C8 = Cout / 8;
-    const int ppb = 256 / C8 > 0 ? 256 / C8 : 1;
     const long long total = (long long)B * H * Wd;
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + ppb - 1) / ppb)), dim3(256), lds, (hipStream_t)stream, x, w,
-                       bias, out, B, Cin, H, Wd, Cout);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + CI_PIX - 1) / CI_PIX)), dim3(256), lds, (hipStream_t)stream,
+                       x, w, bias, out, B, Cin, H, Wd, Cout);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

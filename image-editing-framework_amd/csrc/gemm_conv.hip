@@ -22,7 +22,14 @@
 #include "ief_common.h"
 #include "ief_params.h"
 
-template <int BM, int BN, bool CONV>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+// one wave-instruction: 64 lanes x 16 B from per-lane global addresses -> 1 KiB of LDS at a wave-uniform base
+__device__ __forceinline__ void glds16(const half_t* g, half_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, bool CONV, bool GLDS>
 __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
     constexpr int BK = 64;
     constexpr int NA = BM * 8 / 256, NB = BN * 8 / 256;
@@ -41,8 +48,11 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
     const half_t* __restrict__ A2 = p.A2;
     const half_t* __restrict__ Wt = p.W + z * p.strideW;
 
-    const int kc = tid & 7;       // 16-byte chunk inside the 128-byte K row
-    const int rbase = tid >> 3;   // 0..31
+    const int rbase = tid >> 3;   // 0..31: tile row (+32 i) this thread stages
+    // 16-byte chunk of the 128-byte K row this thread FETCHES.  Register staging: chunk tid&7, written to
+    // the XOR-swizzled LDS slot.  LDS-DMA: the LDS slot is fixed by the lane (tid&7), so the swizzle is
+    // applied to the source chunk instead (same involution; rows rbase+32i share (row>>1)&7).
+    const int kc = GLDS ? ((tid & 7) ^ ((rbase >> 1) & 7)) : (tid & 7);
     long long a_off[NA];
     bool a_ok[NA];
     int a_b[NA], a_y[NA], a_x[NA];
@@ -112,6 +122,45 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = (w_ok[i] && kok) ? *(const half8*)(Wt + w_off[i] + k0) : zero8;
     };
+    // LDS-DMA staging of K tile kt into buffer buf (asynchronous; tracked by vmcnt)
+    auto stage_tile = [&](int buf, int kt) {
+        const int k0 = kt * BK;
+        const half_t* zp = p.zeros;
+        half_t* la = As + buf * BM * BK + (wave * 8) * BK;
+        half_t* lb = Bs + buf * BN * BK + (wave * 8) * BK;
+        if constexpr (CONV) {
+            const int Ctot = p.C1 + p.C2;
+            if (k0 < 9 * Ctot) {
+                const int tap = k0 / Ctot, c0 = k0 - tap * Ctot;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const half_t* src = A;
+                int cs = p.C1, cc = c0;
+                if (c0 >= p.C1) { src = A2; cs = p.C2; cc = c0 - p.C1; }
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                    const int py = iy >> p.ups, px = ix >> p.ups;
+                    const long long off = ((long long)(a_b[i] * Hp + py) * Wp + px) * cs + cc + kc * 8;
+                    glds16(ok ? src + off : zp, la + 32 * i * BK);
+                }
+            } else {
+                const int ke = k0 - 9 * Ctot;
+                const half_t* src = p.E1;
+                int cs = p.CE1, cc = ke;
+                if (ke >= p.CE1) { src = p.E2; cs = p.CE2; cc = ke - p.CE1; }
+#pragma unroll
+                for (int i = 0; i < NA; ++i) glds16(a_ok[i] ? src + a_off[i] * cs + cc + kc * 8 : zp, la + 32 * i * BK);
+            }
+        } else {
+            const bool kok = k0 + kc * 8 < p.K;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16((a_ok[i] && kok) ? A + a_off[i] + k0 : zp, la + 32 * i * BK);
+        }
+        const bool kok = k0 + kc * 8 < p.K;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16((w_ok[i] && kok) ? Wt + w_off[i] + k0 : zp, lb + 32 * i * BK);
+    };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -131,14 +180,30 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    const int nk_all = (p.K + BK - 1) / BK;
+    int kt_lo = 0, nk = nk_all;
+    if (p.splits > 1) {  // this block's K slice
+        const int per = (nk_all + p.splits - 1) / p.splits;
+        kt_lo = blockIdx.y * per;
+        nk = min(nk_all, kt_lo + per);
+    }
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt_lo < nk) {
+        if constexpr (GLDS) {
+            stage_tile(0, kt_lo);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            load_tile(kt_lo);
+            store_tile(0);
+        }
+    }
+    __syncthreads();
+    for (int kt = kt_lo; kt < nk; ++kt) {
+        const int cur = (kt - kt_lo) & 1;
+        if (kt + 1 < nk) {
+            if constexpr (GLDS) stage_tile(cur ^ 1, kt + 1);
+            else load_tile(kt + 1);
+        }
         const half_t* Ac = As + cur * BM * BK;
         const half_t* Bc = Bs + cur * BN * BK;
 #pragma unroll
@@ -161,7 +226,11 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if constexpr (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile has landed in LDS
+        } else {
+            if (kt + 1 < nk) store_tile(cur ^ 1);
+        }
         __syncthreads();
     }
 
@@ -189,6 +258,12 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
             if (m < p.M && n < p.N) {
                 const f32x4 s0 = *(const f32x4*)(stage + row * LDS_N + nc * 8);
                 const f32x4 s1 = *(const f32x4*)(stage + row * LDS_N + nc * 8 + 4);
+                if (p.splits > 1) {  // raw partial sums; the reducer applies the epilogue
+                    float* w = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
+                    *(f32x4*)w = s0;
+                    *(f32x4*)(w + 4) = s1;
+                    continue;
+                }
                 float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
                 if (p.bias) {
                     const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
@@ -216,11 +291,59 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
     }
 }
 
+// sums the split-K slabs and applies the same epilogue as the single-pass kernel
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IefGemmParams p) {
+    const int N8 = p.N >> 3;
+    const long long total = (long long)p.M * N8;
+    const long long slab = (long long)p.M * p.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / N8), n = (int)(i - (long long)m * N8) * 8;
+        const float* w = p.ws + (long long)m * p.N + n;
+        f32x4 a0 = *(const f32x4*)w, a1 = *(const f32x4*)(w + 4);
+        for (int s = 1; s < p.splits; ++s) {
+            a0 += *(const f32x4*)(w + s * slab);
+            a1 += *(const f32x4*)(w + s * slab + 4);
+        }
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (p.bias) {
+            const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        if (p.rowvec) {
+            const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n;
+            const f32x4 b0 = *(const f32x4*)rv, b1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        if (p.residual) {
+            const half8 rs = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
+        *(half8*)(p.Out + (long long)m * p.ldo + n) = o;
+    }
+}
+
 template <int BM, int BN, bool CONV>
 static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, CONV>), dim3(tiles, 1, batch), dim3(256), 0, st, p);
+    const int splits = p.splits > 1 ? p.splits : 1;
+    if (p.flags & 1)
+        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, CONV, true>), dim3(tiles, splits, batch), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, CONV, false>), dim3(tiles, splits, batch), dim3(256), 0, st, p);
     IEF_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long total = (long long)p.M * (p.N / 8);
+        int grid = (int)((total + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, p);
+        IEF_LAUNCH_CHECK();
+    }
     return IEF_OK;
 }
 
@@ -244,6 +367,9 @@ static int check_common(const IefGemmParams& p) {
     if ((p.N & 7) || (p.K & 7) || (p.ldw & 7) || (p.ldo & 7)) return IEF_EALIGN;
     if (p.residual && (p.ldr & 7)) return IEF_EALIGN;
     if (p.rowvec && p.rows_per_batch <= 0) return IEF_ESHAPE;
+    if (p.splits > 1 && !p.ws) return IEF_EINVAL;
+    if ((p.flags & 1) && !p.zeros) return IEF_EINVAL;
+    if (p.splits > 64) return IEF_ESHAPE;
     return IEF_OK;
 }
 
@@ -254,6 +380,7 @@ extern "C" int ief_gemm_f16(const IefGemmParams* pp, int batch, void* stream) {
     if (rc) return rc;
     if (p.lda & 7) return IEF_EALIGN;
     if (batch <= 0) return IEF_ESHAPE;
+    if (p.splits > 1 && batch != 1) return IEF_ESHAPE;
     p.ups = 0; p.H = p.Wd = 1;
     return dispatch_igemm<false>(p, batch, (hipStream_t)stream);
 }

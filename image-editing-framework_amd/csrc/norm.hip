@@ -13,10 +13,11 @@
 
 #define GN_MAX_GROUPS 64
 
+// pixel splits per image for the statistics pass: enough blocks to cover the chip, at least 16 pixels each
 static inline int gn_splits_host(int HW) {
-    int s = HW / 64;
+    int s = HW / 16;
     if (s < 1) s = 1;
-    if (s > 32) s = 32;
+    if (s > 64) s = 64;
     return s;
 }
 extern "C" int ief_gn_splits(int HW) { return gn_splits_host(HW); }
@@ -27,82 +28,96 @@ __device__ __forceinline__ half8 load_cat8(const half_t* x, const half_t* x2, in
     return *(const half8*)(x2 + pix * C2 + (c - C1));
 }
 
-// grid (splits, B); block (C/8 rounded up to 64, PY) with PY pixel lanes
+// Thread layout of both kernels: blockDim.x = C8 * PY (C8 = C/8 chunks, PY pixel lanes), so a thread
+// keeps ONE 8-channel chunk for its whole life: group ids, affine and statistics are resolved once
+// and the inner loop is load - 8 FMAs - store with no integer division.
+// grid (splits, B)
 __global__ void gn_stats_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int C1, int C2,
-                                float* __restrict__ partial, int HW, int groups, int splits) {
+                                float* __restrict__ partial, int HW, int groups, int splits, int PY) {
     const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, sp = blockIdx.x;
-    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    const int cx = threadIdx.x % C8, py = threadIdx.x / C8;
     __shared__ float gsum[GN_MAX_GROUPS], gsq[GN_MAX_GROUPS];
-    const int t = py * blockDim.x + cx;
-    if (t < GN_MAX_GROUPS) { gsum[t] = 0.f; gsq[t] = 0.f; }
+    if (threadIdx.x < GN_MAX_GROUPS) { gsum[threadIdx.x] = 0.f; gsq[threadIdx.x] = 0.f; }
     __syncthreads();
     const int per = (HW + splits - 1) / splits;
     const int p0 = sp * per, p1 = min(HW, p0 + per);
-    if (cx < C8) {
-        float s[8], q[8];
+    float s[8], q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-        for (int p = p0 + py; p < p1; p += PY) {
-            const half8 v = load_cat8(x, x2, C1, C2, (long long)b * HW + p, cx * 8);
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int p = p0 + py; py < PY && p < p1; p += PY) {  // py >= PY: padding threads of a <64-wide layout
+        const half8 v = load_cat8(x, x2, C1, C2, (long long)b * HW + p, cx * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
-        }
-        // fold the 8 channels into (at most 2..8) groups, then LDS atomics (few per thread)
-        int g_prev = (cx * 8) / cpg;
-        float as = 0.f, aq = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (cx * 8 + e) / cpg;
-            if (g != g_prev) { atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq); as = 0.f; aq = 0.f; g_prev = g; }
-            as += s[e]; aq += q[e];
-        }
-        atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq);
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
     }
+    // fold the 8 channels into their (1..8) groups, then a few LDS atomics per thread
+    int g_prev = (cx * 8) / cpg;
+    float as = 0.f, aq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (cx * 8 + e) / cpg;
+        if (g != g_prev) { atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq); as = 0.f; aq = 0.f; g_prev = g; }
+        as += s[e]; aq += q[e];
+    }
+    atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq);
     __syncthreads();
-    if (t < groups) {
-        float* o = partial + (((long long)b * splits + sp) * groups + t) * 2;
-        o[0] = gsum[t]; o[1] = gsq[t];
+    if (threadIdx.x < groups) {
+        float* o = partial + (((long long)b * splits + sp) * groups + threadIdx.x) * 2;
+        o[0] = gsum[threadIdx.x]; o[1] = gsq[threadIdx.x];
     }
 }
 
-// grid (ceil(HW / PIX_PER_BLOCK), B); block 256; each thread walks (pixel, chunk) pairs
-__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2,
-                                                       int C1, int C2, half_t* __restrict__ out,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ partial, int HW, int groups,
-                                                       int splits, float eps, int apply_silu, int pix_per_block) {
-    const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
-    const int b = blockIdx.y;
-    __shared__ float mean_s[GN_MAX_GROUPS], rstd_s[GN_MAX_GROUPS];
-    if (threadIdx.x < groups) {
-        float s = 0.f, q = 0.f;
-        for (int sp = 0; sp < splits; ++sp) {
-            const float* o = partial + (((long long)b * splits + sp) * groups + threadIdx.x) * 2;
-            s += o[0]; q += o[1];
-        }
+// grid (B * groups); block 64: one wave sums the <= 64 split partials of one (batch, group) in parallel
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                         int HW, int groups, int splits, int cpg, float eps) {
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    const int sp = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    if (sp < splits) {
+        const float* o = partial + (((long long)b * splits + sp) * groups + g) * 2;
+        s = o[0]; q = o[1];
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if (sp == 0) {
         const float inv = 1.0f / ((float)cpg * (float)HW);
         const float m = s * inv;
         const float var = fmaxf(q * inv - m * m, 0.f);
-        mean_s[threadIdx.x] = m;
-        rstd_s[threadIdx.x] = rsqrtf(var + eps);
+        stats[((long long)b * groups + g) * 2] = m;
+        stats[((long long)b * groups + g) * 2 + 1] = rsqrtf(var + eps);
     }
-    __syncthreads();
-    const int p0 = blockIdx.x * pix_per_block;
-    const int p1 = min(HW, p0 + pix_per_block);
-    const long long total = (long long)(p1 - p0) * C8;
-    for (long long i = threadIdx.x; i < total; i += 256) {
-        const int p = p0 + (int)(i / C8), c = (int)(i % C8) * 8;
-        const long long pix = (long long)b * HW + p;
-        const half8 v = load_cat8(x, x2, C1, C2, pix, c);
+}
+
+// grid (pixel blocks, B)
+__global__ void gn_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int C1, int C2,
+                                half_t* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ partial, int HW, int groups, int splits, float eps,
+                                int apply_silu, int pix_per_block, int PY) {
+    const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y;
+    const float* st = partial + (long long)gridDim.y * splits * groups * 2 + (long long)b * groups * 2;  // finalized stats
+    const int cx = threadIdx.x % C8, py = threadIdx.x / C8;
+    const int c = cx * 8;
+    float sc[8], sh[8];  // y = x * sc + sh
+    {
         const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
         const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
-        half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int g = (c + e) / cpg;
             const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
-            float y = ((float)v[e] - mean_s[g]) * rstd_s[g] * ga + be;
+            sc[e] = st[2 * g + 1] * ga;
+            sh[e] = be - st[2 * g] * sc[e];
+        }
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    for (int p = p0 + py; py < PY && p < p1; p += PY) {
+        const long long pix = (long long)b * HW + p;
+        const half8 v = load_cat8(x, x2, C1, C2, pix, c);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (float)v[e] * sc[e] + sh[e];
             if (apply_silu) y = silu_f(y);
             o[e] = (half_t)y;
         }
@@ -121,18 +136,29 @@ extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int
     hipStream_t st = (hipStream_t)stream;
     const int splits = gn_splits_host(HW);
     const int C8 = C / 8;
-    int bx = ((C8 + 63) / 64) * 64;
-    int by = 1024 / bx;
-    if (by < 1) by = 1;
-    if (by > 8) by = 8;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, B), dim3(bx, by), 0, st, x, x2, C1, C2, partial, HW, groups, splits);
+    // statistics: up to 1024 threads (C8 * PY), PY bounded by the pixels a block owns
+    int per = (HW + splits - 1) / splits;
+    int PYs = 256 / C8;                    // ~256-thread blocks: few LDS atomics per block, several pixels per thread
+    if (PYs > per) PYs = per;
+    if (PYs < 1) PYs = 1;
+    int ts = C8 * PYs;
+    if (ts < 64) ts = 64;  // the LDS zero-fill / final write use the first 64 threads
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, B), dim3(ts), 0, st, x, x2, C1, C2, partial, HW, groups, splits, PYs);
     IEF_LAUNCH_CHECK();
-    // ~2048 blocks over the chip: pixels per block so that grid.x * B is about that
-    int ppb = (int)(((long long)HW * B + 2047) / 2048);
-    if (ppb < 1) ppb = 1;
+    float* stats = partial + (long long)B * splits * groups * 2;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, partial, stats, HW, groups, splits, C / groups, eps);
+    IEF_LAUNCH_CHECK();
+    // apply: ~256..512-thread blocks, ~4 pixels per thread
+    int PYa = 256 / C8;
+    if (PYa < 1) PYa = 1;
+    if (PYa > HW) PYa = HW;
+    int ppb = PYa * 4;
+    if (ppb > HW) ppb = HW;
+    int ta = C8 * PYa;
+    if (ta < 64) ta = 64;
     const int gx = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, x2, C1, C2, out, gamma, beta, partial, HW,
-                       groups, splits, eps, apply_silu, ppb);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(ta), 0, st, x, x2, C1, C2, out, gamma, beta, partial, HW,
+                       groups, splits, eps, apply_silu, ppb, PYa);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

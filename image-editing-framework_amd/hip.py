@@ -30,6 +30,7 @@ class IefGemmParams(Structure):
         ("stride", c_int), ("ups", c_int), ("batch_images", c_int),
         ("rows_per_batch", c_int), ("out_scale", c_float), ("tile_hint", c_int),
         ("E1", c_void_p), ("E2", c_void_p), ("CE1", c_int), ("CE2", c_int),
+        ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p),
     ]
 
 
@@ -166,6 +167,40 @@ def pick_tile(M: int, N: int, batch: int = 1) -> int:
     return 3
 
 
+GLDS = os.environ.get("IEF_GLDS", "1") != "0"   # direct global->LDS operand staging in the igemm kernels
+_zero_pages = {}
+
+
+def _zeros(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(128, dtype=torch.float16, device=device)
+    return z.data_ptr()
+
+
+SPLITK = os.environ.get("IEF_SPLITK", "1") != "0"
+_SPLIT_TARGET = int(os.environ.get("IEF_SPLIT_TARGET", "256"))   # blocks wanted on the 256 CUs
+_SPLIT_MAX = int(os.environ.get("IEF_SPLIT_MAX", "16"))
+_SPLIT_MIN_KT = int(os.environ.get("IEF_SPLIT_MIN_KT", "6"))     # K tiles (of 64) each slice keeps at least
+
+
+def pick_plan(M: int, N: int, K: int):
+    """(tile_hint, splits).  Layers whose M x N alone gives fewer 128x128 tiles than ~1.5 per CU and whose
+    K loop is long (the 16x16 / 8x8 levels of the UNet: M = 1024 / 256, K up to 23040) are cut along K so
+    that >= ~2 blocks per CU exist; every slice keeps >= 6 K tiles of 64."""
+    nk = -(-K // 64)
+    t128 = -(-M // 128) * -(-N // 128)
+    if not SPLITK or t128 >= 384 or nk < 24:
+        return pick_tile(M, N), 1
+    tile, tiles = 1, t128
+    if M <= 64 or (tiles < 32 and M < 128):
+        tile, tiles = 2, -(-M // 64) * -(-N // 128)
+    splits = min(-(-_SPLIT_TARGET // tiles), nk // _SPLIT_MIN_KT, _SPLIT_MAX)
+    if splits <= 1:
+        return pick_tile(M, N), 1
+    return tile, splits
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -207,7 +242,7 @@ def _rows_ld(t, name):
 
 
 # ------------------------------------------------------------------------------- GEMM / conv
-def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0):
+def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0, splits=1):
     """out[..., n] = (a[..., :] . w[n, :] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale
 
     a: fp16 [..., K] (last dim contiguous, uniform row stride); w: fp16 [N, K]; bias/rowvec fp32.
@@ -236,7 +271,15 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     p.lda, p.ldw, p.ldo = lda, w.stride(0), ldo
     p.rows_per_batch = rows_per_batch
     p.out_scale = out_scale
-    p.tile_hint = tile_hint or pick_tile(M, N)
+    if tile_hint == 0:
+        p.tile_hint, p.splits = pick_plan(M, N, K)
+    else:
+        p.tile_hint, p.splits = tile_hint, max(1, splits)
+    if p.splits > 1:
+        ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)
+        p.ws = ws.data_ptr()
+    if GLDS:
+        p.flags, p.zeros = 1, _zeros(a.device)
     bm, bn = _TILES[p.tile_hint]
     with _Timed(f"igemm_f16_kernel<{bm}, {bn}, false>", 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
@@ -244,7 +287,7 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
 
 
 def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0,
-            extra=None):
+            extra=None, splits=1):
     """3x3 / pad 1 convolution over NHWC fp16.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat),
     w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather.
     extra=(e1, e2|None): fused 1x1 convolution over more NHWC sources sampled at the output pixel; w is
@@ -295,8 +338,16 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.stride, p.ups, p.batch_images = stride, 1 if upsample else 0, B
     p.out_scale = 1.0
     M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
-    p.tile_hint = tile_hint or pick_tile(M, Cout)
+    if tile_hint == 0:
+        p.tile_hint, p.splits = pick_plan(M, Cout, K)
+    else:
+        p.tile_hint, p.splits = tile_hint, max(1, splits)
+    if p.splits > 1:
+        ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)
+        p.ws = ws.data_ptr()
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
+    if GLDS:
+        p.flags, p.zeros = 1, _zeros(x.device)
     bm, bn = _TILES[p.tile_hint]
     with _Timed(f"igemm_f16_kernel<{bm}, {bn}, true>", 2.0 * M * Cout * K):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
@@ -322,12 +373,14 @@ def add(a, b, out=None):
 
 
 def conv_in(x, w, bias, out=None):
-    """latent fp32 NCHW [B,Cin,H,W] -> fp16 NHWC [B,H,W,Cout]; w fp16 [Cout,3,3,Cin]."""
+    """latent fp32 NCHW [B,Cin,H,W] -> fp16 NHWC [B,H,W,Cout]; w fp16 [3,3,Cin,Cout] (k-major)."""
     lib = load()
     _dev32(x, "x")
     _dev16(w, "w")
     B, Cin, H, Wd = x.shape
-    Cout = w.shape[0]
+    if tuple(w.shape[:3]) != (3, 3, Cin) or not w.is_contiguous():
+        raise ValueError("conv_in: weight must be contiguous [3, 3, Cin, Cout]")
+    Cout = w.shape[3]
     if out is None:
         out = torch.empty(B, H, Wd, Cout, dtype=torch.float16, device=x.device)
     _check(lib.ief_conv_in_f32(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), B, Cin, H, Wd, Cout, _stream()),
@@ -362,7 +415,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
     if out is None:
         out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float16, device=x.device)
     splits = lib.ief_gn_splits(HW)
-    partial = torch.empty(B * splits * groups * 2, dtype=torch.float32, device=x.device)
+    partial = torch.empty(B * (splits + 1) * groups * 2, dtype=torch.float32, device=x.device)
     with _Timed("groupnorm(stats+apply)", 0.0):
         _check(lib.ief_groupnorm_silu_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
                                           _dev32(beta, "beta").data_ptr(), partial.data_ptr(), B, HW, groups, eps,

@@ -404,7 +404,7 @@ class UNet2DConditionModel(nn.Module):
         ch = cfg.block_out_channels
         nlev = len(ch)
         G, eps = cfg.norm_num_groups, cfg.norm_eps
-        self.conv_in = Conv2d(_f16(sd["conv_in.weight"].permute(0, 2, 3, 1), dev), _f32(sd["conv_in.bias"], dev), 3)
+        self.conv_in = Conv2d(_f16(sd["conv_in.weight"].permute(2, 3, 1, 0), dev), _f32(sd["conv_in.bias"], dev), 3)  # [3,3,Cin,Cout]
         self.time_proj = Timesteps(ch[0])
         self.time_embedding = TimestepEmbedding(sd, dev)
         self._temb_width = 0

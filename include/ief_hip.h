@@ -61,13 +61,23 @@ typedef struct IefGemmParams {
      * Requires stride 1, no upsample. */
     const ief_half* E1; const ief_half* E2;
     int CE1, CE2;
+    /* split-K: `splits` > 1 cuts the K loop into that many slices (grid.y); each slice writes an fp32
+     * partial slab ws[slice][M][N] and a second launch sums the slabs and applies the epilogue.
+     * ws must hold splits*M*N floats.  Used where M*N alone yields too few tiles for 256 CUs. */
+    int splits;
+    float* ws;
+    /* staging: flags bit 0 = stage operand tiles with direct global->LDS loads (global_load_lds, 16 B per
+     * lane) instead of through registers; `zeros` must then point at >= 16 bytes of device zeros (source of
+     * padded / out-of-range chunks). */
+    int flags;
+    const ief_half* zeros;
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);
 /* fills M, K, ldw, Ho, Wo, rows_per_batch itself from the geometry fields */
 int ief_conv3x3_f16(const IefGemmParams* p, void* stream);
 
-/* conv_in: latent NCHW fp32 [B,Cin,H,W] (Cin<=8) -> NHWC fp16 [B,H,W,Cout]; W [Cout][3][3][Cin] fp16.
+/* conv_in: latent NCHW fp32 [B,Cin,H,W] (Cin<=8) -> NHWC fp16 [B,H,W,Cout]; W [3][3][Cin][Cout] fp16 (k-major).
  * conv_out: NHWC fp16 [B,H,W,C] -> NCHW fp32 [B,Cout,H,W] (Cout<=8); W [Cout][3][3][C] fp16.
  * (UNet2DConditionModel.conv_in / conv_out, called at /root/reference/p2p/model/sd_utils.py:73) */
 int ief_conv_in_f32(const float* x, const ief_half* w, const float* bias, ief_half* out,
@@ -78,7 +88,7 @@ int ief_conv_out_f32(const ief_half* x, const ief_half* w, const float* bias, fl
 /* ------------------------------------------------------------------ normalisation
  * GroupNorm over NHWC (+ optional SiLU): ResnetBlock2D.norm1/norm2 + nonlinearity
  * (/root/reference/pnp/model/register.py:105-110,149-158), Transformer2DModel.norm, conv_norm_out.
- * `partial` is scratch of >= B * splits * groups * 2 floats (splits = ief_gn_splits(HW)).
+ * `partial` is scratch of >= B * (splits + 1) * groups * 2 floats (splits = ief_gn_splits(HW)).
  * Two sources (x, x2) = channel concat [C1 | C2] normalised as one tensor, written to out [.., C1+C2].
  */
 int ief_gn_splits(int HW);

@@ -118,10 +118,10 @@ def test_conv3x3(B, H, W, C1, C2, Cout, stride, ups):
 def test_conv_in_out():
     B, H, W = 2, 24, 16
     x = f32(B, 4, H, W, seed=1)
-    w = h16(320, 3, 3, 4, seed=2, scale=1 / 6)
+    w = h16(3, 3, 4, 320, seed=2, scale=1 / 6)       # [kh, kw, Cin, Cout]
     b = f32(320, seed=3, scale=0.1)
     y = hip.conv_in(dev(x), dev(w), dev(b))
-    ref = F.conv2d(x, w.float().permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    ref = F.conv2d(x, w.float().permute(3, 2, 0, 1), b, padding=1).permute(0, 2, 3, 1)
     close(y, ref, 2e-3, 1e-3)
     xa = h16(B, H, W, 320, seed=4)
     wo = h16(4, 3, 3, 320, seed=5, scale=(9 * 320) ** -0.5)
@@ -339,3 +339,25 @@ def test_bad_arguments_are_rejected():
         hip.gemm(a, w)
     with pytest.raises(TypeError):
         hip.gemm(torch.zeros(8, 8), torch.zeros(8, 8))  # CPU fp32 tensors: no fallback
+
+
+@pytest.mark.parametrize("M,N,K,hint,splits", [(256, 1280, 5120, 1, 8), (200, 136, 1032, 2, 3), (1024, 640, 1280, 1, 20)])
+def test_gemm_splitk(M, N, K, hint, splits):
+    a, w = h16(M, K, seed=1), h16(N, K, seed=2, scale=K ** -0.5)
+    bias, res = f32(N, seed=3, scale=0.1), h16(M, N, seed=4)
+    out = hip.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res), tile_hint=hint, splits=splits)
+    close(out, a.float() @ w.float().t() + bias + res.float(), 2e-3, 1e-3)
+
+
+def test_conv3x3_splitk_auto_and_shortcut():
+    # 8x8 level of the UNet: M = 256, K = 9*2560 + shortcut 2560 -> the auto plan picks split-K
+    B, H, W, C1, C2, Cout = 4, 8, 8, 1280, 1280, 1280
+    assert hip.pick_plan(B * H * W, Cout, 9 * Cout)[1] > 1
+    h = h16(B, H, W, Cout, seed=1)
+    x, skip = h16(B, H, W, C1, seed=2), h16(B, H, W, C2, seed=3)
+    w2 = h16(Cout, 9 * Cout, seed=4, scale=(9 * Cout) ** -0.5)
+    ws = h16(Cout, C1 + C2, seed=5, scale=(C1 + C2) ** -0.5)
+    bias = f32(Cout, seed=6, scale=0.1)
+    out = hip.conv3x3_shortcut(dev(h), dev(torch.cat([w2, ws], 1).contiguous()), dev(bias), dev(x), dev(skip))
+    ref = _conv_ref(h, w2.reshape(Cout, 3, 3, Cout), bias) + torch.cat([x, skip], -1).float() @ ws.float().t()
+    close(out, ref, 2e-3, 1e-3)
