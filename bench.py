@@ -65,9 +65,8 @@ def build_pipe(cfg_name, dev, rank, world):
         sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(cfg).items()}
     unet = UNet2DConditionModel(cfg, sd, device=dev)
     if world > 1:
-        import torch.distributed as dist
-        for t in unet.packed_tensors():
-            dist.broadcast(t, src=0)
+        from ief_amd.dist import broadcast_tensors
+        broadcast_tensors(unet.packed_tensors(), src=0)   # RCCL over xGMI, a few flat buckets
         torch.cuda.synchronize()
     pipe = StableDiffusionPipeline(unet, WordPieceTokenizer(cfg.text_max_length),
                                    SyntheticTextEncoder(cfg.cross_attention_dim).to(dev), SyntheticVAE().to(dev),

@@ -148,4 +148,13 @@ extern "C" int ief_advance_step(int* step, void* stream) {
 }
 
 extern "C" int ief_abi_version(void) { return IEF_ABI_VERSION; }
+// sizeof of the parameter structs as compiled, so a binding can verify its own layout (0: gemm, 1: attn, 2: cross)
+extern "C" int ief_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(IefGemmParams);
+        case 1: return (int)sizeof(IefAttnParams);
+        case 2: return (int)sizeof(IefCrossParams);
+        default: return -1;
+    }
+}
 extern "C" const char* ief_target_arch(void) { return "gfx950"; }

@@ -59,7 +59,7 @@ EXPORTS = [
     "ief_conv_out_f32", "ief_gn_splits", "ief_groupnorm_silu_f16", "ief_layernorm_f16", "ief_geglu_f16",
     "ief_attn_flash_f16", "ief_attn_cross_p2p_f16", "ief_attn_probs_f16", "ief_attn_apply_f16",
     "ief_cfg_ddim_step_f32", "ief_timestep_embedding_f16", "ief_silu_f16", "ief_cast_f32_to_f16",
-    "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step", "ief_add_f16",
+    "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step", "ief_add_f16", "ief_struct_size",
 ]
 
 
@@ -106,6 +106,11 @@ def load():
     lib.ief_add_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     if lib.ief_abi_version() != 1:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
+    lib.ief_struct_size.argtypes = [c_int]
+    for which, st in enumerate((IefGemmParams, IefAttnParams, IefCrossParams)):
+        if lib.ief_struct_size(which) != ctypes.sizeof(st):
+            raise HipExtensionMissing(f"{st.__name__}: ctypes layout ({ctypes.sizeof(st)} B) != library "
+                                      f"({lib.ief_struct_size(which)} B); rebuild libief_hip.so")
     _lib = lib
     return lib
 

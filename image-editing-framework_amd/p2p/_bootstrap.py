@@ -1,0 +1,37 @@
+"""Makes `python edit_syn.py` / `edit_real.py` / `test.py` runnable from inside this folder, the way the
+reference's scripts are run (`/root/reference/README.md:36-58`): puts the repo root on sys.path and loads
+the hyphen-named package as `ief_amd`."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import ief_amd  # noqa: E402,F401
+
+SCHEDULER_CONFIG = dict(ief_amd.SCHEDULER_CONFIG)
+
+
+def seed_everything(seed: int):
+    """stands in for `lightning.pytorch.seed_everything` (`/root/reference/p2p/edit_syn.py:32`)"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32):
+    """the loader switch of `/root/reference/p2p/edit_syn.py:58-86` for the versions this tier supports"""
+    from ief_amd.pipeline import StableDiffusionPipeline
+    from ief_amd.scheduler import DDIMScheduler
+    from ief_amd.p2p.sd_mapping import sd_maps
+    model_key = sd_maps[sd_version]          # KeyError for unknown versions, as in the reference (:26)
+    scheduler = DDIMScheduler.from_config(SCHEDULER_CONFIG)
+    if sd_version in ("1.5", "1.4", "tiny", "small"):
+        return StableDiffusionPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device)
+    if sd_version in ("2.1", "xl-base"):
+        raise ValueError(f"sd_version {sd_version}: SD2.x / SDXL shape families are not built yet (DESIGN.md, next rows)")
+    raise ValueError("please use the right sd_version")

@@ -1,0 +1,64 @@
+"""Edit a synthesized image with Prompt-to-Prompt — CLI of `/root/reference/p2p/edit_syn.py`.
+
+Same flags, defaults, hyper-parameters and outputs (`./exp/source.png`, `./exp/edit.png`);
+`--device` is the HIP device index.  Phase 1 synthesizes the source image with `EmptyControl`;
+phase 2 re-runs with both prompts from the SAME x_T under `AttentionRefine` / `AttentionReplace`.
+"""
+import argparse
+import os
+
+import torch
+
+from _bootstrap import load_pipe, seed_everything
+
+from ief_amd.p2p.model.attention_base import EmptyControl
+from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace
+from ief_amd.p2p.model.sd_utils import P2P
+from ief_amd.p2p.utils.save_image import save_img
+
+parser = argparse.ArgumentParser("General config")
+parser.add_argument("--sd_version", type=str, default="1.5")
+parser.add_argument("--device", type=int, default=0)
+parser.add_argument("--seed", type=int, default=8888)
+parser.add_argument("--source_prompt", type=str, default="a photo of a house on a mountain")
+parser.add_argument("--target_prompt", type=str, default="a photo of a house on a mountain at fall")
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    device = torch.device("cuda:{}".format(args.device))
+    seed_everything(args.seed)
+    source_prompt, target_prompt = [args.source_prompt], [args.target_prompt]
+    num_inference_steps, GUIDANCE_SCALE, LOW_RESOURCE = 50, 7.5, False
+    out_path = "./exp"
+    cross_replace_steps, self_replace_steps = 0.8, 0.4
+    edit_type = "refine"  # ["refine", "replace"]
+
+    pipe = load_pipe(args.sd_version, device)
+    if pipe.__class__.__name__ != "StableDiffusionPipeline":
+        raise ValueError("please use the right sd_version")
+    editor = P2P(model=pipe, num_inference_steps=num_inference_steps)
+
+    os.makedirs(out_path, exist_ok=True)
+    controller = EmptyControl(LOW_RESOURCE=LOW_RESOURCE)
+    image, latent = editor.text2image_ldm_stable(pipe, source_prompt, controller, latent=None,
+                                                 num_inference_steps=num_inference_steps,
+                                                 guidance_scale=GUIDANCE_SCALE, low_resource=LOW_RESOURCE)
+    save_img(image, os.path.join(out_path, "source.png"))
+
+    kw = dict(prompts=source_prompt + target_prompt, tokenizer=pipe.tokenizer, num_steps=num_inference_steps,
+              cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps, device=device)
+    if edit_type == "replace":
+        controller = AttentionReplace(**kw)
+    elif edit_type == "refine":
+        controller = AttentionRefine(**kw)
+    else:
+        raise ValueError("Please choose right eidt type")
+    image, latent = editor.text2image_ldm_stable(pipe, source_prompt + target_prompt, controller, latent=latent,
+                                                 num_inference_steps=num_inference_steps,
+                                                 guidance_scale=GUIDANCE_SCALE, low_resource=LOW_RESOURCE)
+    save_img(image[1], os.path.join(out_path, "edit.png"))
+
+
+if __name__ == "__main__":
+    main()

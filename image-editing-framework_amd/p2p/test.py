@@ -1,0 +1,109 @@
+"""PIE-Bench driver — `/root/reference/p2p/test.py:114-181`, sharded over the GPUs of one node.
+
+Per image: invert (50 DDIM steps, UNet batch 1) -> edit-type rule (equal word counts => "replace", else
+"refine", :120-123) -> edit (50 steps, batch 4) -> `source.png / inversion.png / edit.png` under
+`./test_exp/<relpath>` -> `controller.reset()` + `unregister_attention_control` (:180-181).
+
+Multi-GPU: images are independent, so rank r of W takes items i with i % W == r of the concatenated
+category lists [0,1,2,3,4,6,7,8,9] (category 5 is skipped by the reference, :114) and writes its own
+files; no collective touches the data path.  Launch with
+    python -m torch.distributed.run --nproc-per-node W test.py [...]
+The only collective is the final all_reduce of the image counters / time for the images/sec report.
+
+`--synthetic N` replaces the (unavailable) PIE download by N generated images so the loop can be timed.
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+from PIL import Image
+
+from _bootstrap import load_pipe, seed_everything
+
+from edit_real import edit_one
+from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE
+from ief_amd.p2p.inversion.ddim import ddim_inversion
+from ief_amd.p2p.inversion.nti import NTI
+from ief_amd.p2p.model.sd_utils import P2P, P2P_NTI
+from ief_amd.p2p.utils.save_image import save_img
+
+CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
+
+
+def shard(n_items: int, rank: int, world: int):
+    """indices of the items rank `rank` of `world` processes: i = rank (mod world)"""
+    return list(range(rank, n_items, world))
+
+
+def edit_type_of(source_prompt: str, target_prompt: str) -> str:
+    return "replace" if len(source_prompt.split(" ")) == len(target_prompt.split(" ")) else "refine"
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser("PIE-Bench P2P")
+    ap.add_argument("--sd_version", type=str, default="1.5")
+    ap.add_argument("--dataset_path", type=str, default="./PIE")
+    ap.add_argument("--exp_path", type=str, default="./test_exp")
+    ap.add_argument("--inversion_type", type=str, default="ddim")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
+    ap.add_argument("--no_save", action="store_true")
+    args = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    seed_everything(42)
+    pipe = load_pipe(args.sd_version, device)
+    if args.inversion_type == "ddim":
+        editor, invertor = P2P(model=pipe, num_inference_steps=50), ddim_inversion()
+    elif args.inversion_type == "null-text":
+        editor, invertor = P2P_NTI(model=pipe, num_inference_steps=50), NTI()
+    else:
+        raise ValueError("Please choose right inversion type")
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+
+    if args.synthetic > 0:
+        items = list(SyntheticPIE(os.path.join(args.exp_path, "_synthetic_inputs"), args.synthetic, size=size).items)
+        root = os.path.join(args.exp_path, "_synthetic_inputs")
+    else:
+        items, root = [], os.path.join(args.dataset_path, "annotation_images")
+        for category in CATEGORIES:
+            items += PIE(args.dataset_path, None, category=category).items
+    mine = shard(len(items), rank, world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in mine:
+        image_path, source_prompt, target_prompt = items[i]
+        original = Image.open(image_path).convert("RGB").resize((size, size))
+        images = edit_one(pipe, editor, invertor, original, [source_prompt], [target_prompt], args.inversion_type,
+                          edit_type_of(source_prompt, target_prompt), device)
+        if not args.no_save:
+            out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+            os.makedirs(out_path, exist_ok=True)
+            original.save(os.path.join(out_path, "source.png"))
+            save_img(images[0], os.path.join(out_path, "inversion.png"))
+            save_img(images[1], os.path.join(out_path, "edit.png"))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = torch.tensor([float(len(mine)), dt], device=device)
+    if world > 1:
+        cnt = n[:1].clone()
+        dist.all_reduce(cnt)
+        tmax = n[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        n = torch.cat([cnt, tmax])
+    if rank == 0:
+        print(json.dumps({"images": int(n[0].item()), "seconds": round(n[1].item(), 3),
+                          "images_per_sec": round(n[0].item() / max(n[1].item(), 1e-9), 4), "n_gpus": world}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,27 @@
+"""`save_img` / `save_images` (`/root/reference/p2p/utils/save_image.py:6-31`): PNG writers."""
+import numpy as np
+from PIL import Image
+
+
+def save_img(image, path):
+    """image: uint8 HWC (or 1xHWC) array -> PNG"""
+    arr = np.asarray(image)
+    if arr.ndim == 4:
+        arr = arr[0]
+    Image.fromarray(arr.astype(np.uint8)).save(path)
+
+
+def save_images(images, path, num_rows=1, offset_ratio=0.02):
+    """uint8 images [N,H,W,3] tiled into one PNG grid with white gutters"""
+    images = [np.asarray(im).astype(np.uint8) for im in (images if not isinstance(images, np.ndarray) or images.ndim == 4 else [images])]
+    n = len(images)
+    pad = (-n) % num_rows
+    h, w, c = images[0].shape
+    images += [np.full((h, w, c), 255, np.uint8)] * pad
+    cols = len(images) // num_rows
+    off = int(h * offset_ratio)
+    grid = np.full((h * num_rows + off * (num_rows - 1), w * cols + off * (cols - 1), c), 255, np.uint8)
+    for i, im in enumerate(images):
+        r, q = divmod(i, cols)
+        grid[r * (h + off): r * (h + off) + h, q * (w + off): q * (w + off) + w] = im
+    Image.fromarray(grid).save(path)

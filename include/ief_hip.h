@@ -32,6 +32,8 @@ extern "C" {
 int ief_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char* ief_target_arch(void);
+/* sizeof the parameter structs as compiled (0: IefGemmParams, 1: IefAttnParams, 2: IefCrossParams) */
+int ief_struct_size(int which);
 
 /* ------------------------------------------------------------------ GEMM / conv3x3
  * Out[m][n] = ( sum_k A(m,k) W[n][k] + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n] ) * out_scale

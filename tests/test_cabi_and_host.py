@@ -1,0 +1,179 @@
+"""CPU tests: the C-ABI library builds/loads and exports exactly what `include/ief_hip.h` declares; the
+binding refuses host tensors (no CPU fallback); module tree + hook registration; sharding + weight
+broadcast over a 2-process gloo group."""
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from ief_amd import config, hip, weights  # noqa: E402
+from ief_amd.dist import broadcast_tensors, shard_indices  # noqa: E402
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ief_hip.h")).read()
+    return sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(ief_\w+)\s*\(", src, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ief_hip.h but not exported"
+    assert sorted(hip.EXPORTS) == names, "binding and header disagree on the entry-point list"
+    assert lib.ief_abi_version() == 1 and lib.ief_target_arch() == b"gfx950"
+
+
+def test_binding_rejects_host_tensors_no_cpu_fallback():
+    with pytest.raises(TypeError):
+        hip.gemm(torch.zeros(8, 8, dtype=torch.float16), torch.zeros(8, 8, dtype=torch.float16))
+    with pytest.raises(TypeError):
+        hip.layernorm(torch.zeros(4, 64, dtype=torch.float16), torch.ones(64), torch.zeros(64))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "_LIB_PATH", "/nonexistent/libief_hip.so")
+    with pytest.raises(hip.HipExtensionMissing):
+        hip.load()
+
+
+def test_tile_plans():
+    assert hip.pick_plan(16384, 320, 2880) == (1, 1)          # 64x64 level: plenty of tiles, no split
+    t, s = hip.pick_plan(256, 1280, 11520)                      # 8x8 level: split-K
+    assert s > 1 and 11520 // 64 // s >= 6
+    assert hip.pick_plan(4, 1280, 320)[1] == 1                  # time-embedding GEMM
+
+
+def test_param_inventory_matches_sd15():
+    assert weights.num_params(config.SD15) == 859_520_964      # the published SD1.5 UNet parameter count
+    sd = weights.synthetic_state_dict(config.TINY, 0)
+    sd2 = weights.synthetic_state_dict(config.TINY, 0)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)          # deterministic
+
+
+@pytest.fixture(scope="module")
+def cpu_unet():
+    from ief_amd.unet import UNet2DConditionModel
+    return UNet2DConditionModel(config.TINY, weights.synthetic_state_dict(config.TINY, 0), device="cpu")
+
+
+def test_module_tree_and_registration(cpu_unet):
+    from types import SimpleNamespace
+    from ief_amd.p2p.model.attention_base import AttentionStore, EmptyControl
+    from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control
+    model = SimpleNamespace(unet=cpu_unet)
+    names = [n for n, _ in cpu_unet.named_children()]
+    for want in ("conv_in", "time_proj", "time_embedding", "down_blocks", "up_blocks", "mid_block", "conv_norm_out",
+                 "conv_act", "conv_out"):
+        assert want in names
+    assert cpu_unet.up_blocks[1].attentions[0].transformer_blocks[0].attn1.__class__.__name__ == "Attention"
+    assert cpu_unet.up_blocks[1].resnets[1].__class__.__name__ == "ResnetBlock2D"
+    c = EmptyControl(False)
+    register_attention_control(model, c)
+    assert c.num_att_layers == 32 and cpu_unet._plan is not None and cpu_unet._plan.kind == "empty"
+    assert all(m.is_native() for m in cpu_unet.attention_modules())
+    unregister_attention_control(model, c)
+    assert c.num_att_layers == 0 and cpu_unet._plan is None
+    st = AttentionStore(False)                                   # needs materialised maps -> generic hook
+    register_attention_control(model, st)
+    assert st.num_att_layers == 32 and not any(m.is_native() for m in cpu_unet.attention_modules())
+    unregister_attention_control(model, st)
+    assert all(m.is_native() for m in cpu_unet.attention_modules())
+    with pytest.raises(RuntimeError):                            # forward on host tensors: refused
+        cpu_unet(torch.zeros(1, 4, 16, 16), 1, encoder_hidden_states=torch.zeros(1, 77, 64))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/p2p"), reason="reference checkout not present")
+def test_reference_hook_registration_walks_our_tree(cpu_unet):
+    """the reference's own register.py finds and patches our Attention modules (drop-in hook API)"""
+    import importlib.util
+    from types import SimpleNamespace
+    spec = importlib.util.spec_from_file_location("ref_register", "/root/reference/p2p/model/register.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    class Ctl:
+        num_att_layers = -1
+
+        def __call__(self, attn, is_cross, place):
+            return attn
+    model = SimpleNamespace(unet=cpu_unet)
+    c = Ctl()
+    ref.register_attention_control(model, c)
+    assert c.num_att_layers == 32
+    assert not any(m.is_native() for m in cpu_unet.attention_modules())
+    ref.unregister_attention_control(model, c)
+    assert c.num_att_layers == 0 and all(m.is_native() for m in cpu_unet.attention_modules())
+
+
+def test_lowering_tables_match_python_controller():
+    """the device tables reproduce AttentionControlEdit.forward's cross branch on CPU maps (fp32)"""
+    from ief_amd.tokenizer import WordPieceTokenizer
+    from ief_amd.p2p.model import attention_control as ac, seq_aligner
+    from ief_amd.p2p.model.register import _edit_tables
+    tok = WordPieceTokenizer()
+    a, b = "a photo of a house on a mountain", "a photo of a house on a mountain at fall"
+    eq = seq_aligner.get_equalizer(tok, b, ("fall",), (3.0,))
+    ctrls = [ac.AttentionRefine([a, b], tok, 50, 0.8, 0.4, device="cpu"),
+             ac.AttentionReplace(["a cat sitting on a bench", "a dog sitting on a bench"], tok, 50, 0.8, 0.4, device="cpu"),
+             ac.AttentionReweight([a, b], tok, 50, 0.8, 0.4, eq, device="cpu"),
+             ac.AttentionReweight([a, b], tok, 50, 0.8, 0.4, eq, device="cpu",
+                                  controller=ac.AttentionRefine([a, b], tok, 50, 0.8, 0.4, device="cpu"))]
+    g = torch.Generator().manual_seed(0)
+    for c in ctrls:
+        M, s1, keep = _edit_tables(c)
+        base = torch.softmax(torch.randn(2, 16, 77, generator=g), -1)
+        repl = torch.softmax(torch.randn(1, 2, 16, 77, generator=g), -1)
+        want = c.replace_cross_attention(base, repl).reshape(1, 2, 16, 77)
+        got = torch.einsum("hpw,bwn->bhpn", base, M) * s1[:, None, None, :] + repl * keep[:, None, None, :]
+        assert torch.allclose(got, want, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ 2-process gloo
+def _worker(rank, world, port, n_items, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_items, rank, world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    # weight broadcast: rank 0 holds the packed tensors, rank 1 zeros
+    g = torch.Generator().manual_seed(3)
+    ref = [torch.randn(7, 5, generator=g), torch.randn(1000, generator=g).half(), torch.randn(3, generator=g),
+           torch.randn(64, 64, generator=g).half()]
+    ts = [t.clone() if rank == 0 else torch.zeros_like(t) for t in ref]
+    ncoll = broadcast_tensors(ts, src=0, bucket_bytes=4096)
+    ok = all(torch.equal(a, b) for a, b in zip(ts, ref))
+    cnt = torch.tensor([float(len(mine))])
+    dist.all_reduce(cnt)
+    if rank == 0:
+        out.put((gathered, ok, ncoll, cnt.item()))
+    else:
+        out.put((None, ok, ncoll, cnt.item()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_broadcast_gloo():
+    world, n_items = 2, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gathered = next(r[0] for r in res if r[0] is not None)
+    assert sorted(sum(gathered, [])) == list(range(n_items))      # disjoint and complete
+    assert all(r[1] for r in res), "broadcast did not deliver rank 0's tensors"
+    assert all(r[2] >= 2 for r in res)                              # several buckets were used
+    assert all(r[3] == n_items for r in res)
