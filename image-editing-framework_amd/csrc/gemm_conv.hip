@@ -6,63 +6,84 @@
 // CONV  : A(m,k) is gathered on the fly from an NHWC activation: m = (b, oy, ox),
 //         k = (ky, kx, c); zero padding 1; stride 1 or 2; optional nearest-2x upsample of the
 //         input fused into the gather; optional channel concat of two sources (the UNet's
-//         skip connections) fused as two K ranges.  Nothing is materialised (no im2col).
-//         W is [Cout][3][3][C1+C2] so both operands are K-major, the layout MFMA fragments want.
+//         skip connections) fused as two K ranges; optional extra K range = fused 1x1 convolution
+//         over further sources (ResnetBlock2D.conv_shortcut).  Nothing is materialised (no im2col).
+//         W is [Cout][3][3][C1+C2](+extra) so both operands are K-major, what MFMA fragments want.
 //
-// Tile: BM x BN x 64, 256 threads = 2x2 waves, v_mfma_f32_16x16x32_f16, LDS double buffer
-// with register prefetch of the next K tile (global loads issued before the MFMA block, LDS
-// writes after it, one barrier per K tile).  LDS rows are 128 B with the 16-B chunk index
-// XOR-ed by (row>>1)&7: conflict-free for the ds_read_b128 fragment reads and the staging writes.
-// Epilogue: accumulators -> LDS (fp32) -> rows of 8 outputs per thread: + bias[n]
-// + rowvec[batch(m)][n] (time-embedding) + residual[m][n], * scale, one 16-B fp16 store.
+// One kernel template, a family of tiles <BM, BN, WAVES_M, WAVES_N> x BK = 64:
+//   - operand tiles are staged by LDS-DMA (global_load_lds, 16 B per lane, asynchronous) into a
+//     double buffer; LDS rows are 128 B with the 16-B chunk index XOR-ed by (row>>1)&7 — applied to
+//     the per-lane SOURCE address, the LDS image of a wave-instruction being lane-linear — which
+//     makes the ds_read_b128 fragment reads conflict-free;
+//   - conv addressing is incremental and 32-bit: per-row pixel offsets / padding masks are recomputed
+//     only when the 3x3 tap changes (every Ctot/64 K tiles), a K tile adds one scalar; padded taps,
+//     M / N / K tails read a zero page;
+//   - v_mfma_f32_16x16x32_f16, (BM/WAVES_M/16) x (BN/WAVES_N/16) accumulator tiles per wave;
+//   - epilogue through LDS in 64-row passes: + bias[n] + rowvec[batch(m)][n] (time embedding)
+//     + residual[m][n], * scale, one 16-B fp16 store per 8 outputs;
+//   - split-K (grid.y) with fp32 partial slabs + a reducer kernel for layers whose M x N gives too
+//     few tiles for 256 CUs (the 16x16 / 8x8 UNet levels);
+//   - XCD-aware block remap: consecutive logical tiles (same A panel) share an XCD's L2.
+// BN = 160 tiles exist because SD's channel widths are multiples of 320: N = 320 is 2 x 160 exactly,
+// while 128-wide tiles pad it to 384 and leave 1.5 blocks per CU.
 //
 // Replaces on the reference path (all executed by diffusers/PyTorch eager there):
-//   ResnetBlock2D.conv1/conv2 + temb add + skip add   /root/reference/pnp/model/register.py:139-175
-//   Attention.to_q/to_k/to_v/to_out                   /root/reference/p2p/model/register.py:33-54
+//   ResnetBlock2D.conv1/conv2/conv_shortcut + temb add + skip add   /root/reference/pnp/model/register.py:139-175
+//   Attention.to_q/to_k/to_v/to_out, proj_in/out, FF linears        /root/reference/p2p/model/register.py:33-54
 #include "ief_common.h"
 #include "ief_params.h"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 // one wave-instruction: 64 lanes x 16 B from per-lane global addresses -> 1 KiB of LDS at a wave-uniform base
-__device__ __forceinline__ void glds16(const half_t* g, half_t* lds_wave_base) {
+__device__ __forceinline__ void glds16(const char* g, half_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, bool CONV, bool GLDS>
-__global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const IefGemmParams p) {
     constexpr int BK = 64;
-    constexpr int NA = BM * 8 / 256, NB = BN * 8 / 256;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * (BM + BN) * BK];
+    constexpr int NT = 64 * WAVES_M * WAVES_N;      // threads
+    constexpr int RP = NT / 8;                      // tile rows staged per pass (8 lanes x 16 B = one 128-B row)
+    constexpr int NA = (BM + RP - 1) / RP, NB = (BN + RP - 1) / RP;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int ROWS_A = NA * RP, ROWS_B = NB * RP;   // LDS rows incl. staging overshoot
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && WM <= 64, "wave tile");
+    constexpr int STAGE_HALFS = 2 * (ROWS_A + ROWS_B) * BK;
+    constexpr int EPI_HALFS = 64 * (BN + 4) * 2;     // fp32 [64][BN+4]
+    __shared__ __attribute__((aligned(16))) half_t smem[STAGE_HALFS > EPI_HALFS ? STAGE_HALFS : EPI_HALFS];
     half_t* As = smem;
-    half_t* Bs = smem + 2 * BM * BK;
+    half_t* Bs = smem + 2 * ROWS_A * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
     const long long z = blockIdx.z;
-    const half_t* __restrict__ A = p.A + z * p.strideA;
-    const half_t* __restrict__ A2 = p.A2;
-    const half_t* __restrict__ Wt = p.W + z * p.strideW;
+    const char* __restrict__ A = (const char*)(p.A + z * p.strideA);
+    const char* __restrict__ Wt = (const char*)(p.W + z * p.strideW);
+    const char* __restrict__ zp = (const char*)p.zeros;
 
-    const int rbase = tid >> 3;   // 0..31: tile row (+32 i) this thread stages
-    // 16-byte chunk of the 128-byte K row this thread FETCHES.  Register staging: chunk tid&7, written to
-    // the XOR-swizzled LDS slot.  LDS-DMA: the LDS slot is fixed by the lane (tid&7), so the swizzle is
-    // applied to the source chunk instead (same involution; rows rbase+32i share (row>>1)&7).
-    const int kc = GLDS ? ((tid & 7) ^ ((rbase >> 1) & 7)) : (tid & 7);
-    long long a_off[NA];
+    const int rbase = tid >> 3;   // row (+RP*i) this thread stages
+    // the LDS slot (tid&7) of a lane is fixed by LDS-DMA; the swizzle is applied to the chunk FETCHED
+    const unsigned kcb = (unsigned)(((tid & 7) ^ ((rbase >> 1) & 7)) * 16);   // byte offset of that chunk in the K row
+
+    // ---- per-row state
     bool a_ok[NA];
-    int a_b[NA], a_y[NA], a_x[NA];
-    long long w_off[NB];
+    unsigned a_off[NA];           // dense: byte offset of the row's chunk
+    int a_y[NA], a_x[NA], a_b[NA];
+    unsigned a_m[NA];
+    bool a_live[NA];              // conv: row ok AND current tap in bounds
+    unsigned w_off[NB];
     bool w_ok[NB];
-    const int Hp = p.H >> p.ups, Wp = p.Wd >> p.ups;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + rbase + 32 * i;
-        a_ok[i] = m < p.M;
+        const int r = rbase + RP * i;
+        const int m = m0 + r;
+        a_ok[i] = r < BM && m < p.M;
+        a_m[i] = (unsigned)m;
+        a_live[i] = a_ok[i];
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, rem = m - b * hw;
@@ -70,108 +91,73 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
             a_b[i] = b;
             a_y[i] = oy * p.stride - 1;
             a_x[i] = ox * p.stride - 1;
-            a_off[i] = m;  // output pixel index: the address of the fused-1x1 extra K range
+            a_off[i] = 0;
         } else {
-            a_off[i] = (long long)m * p.lda + kc * 8;
+            a_off[i] = (unsigned)m * (unsigned)p.lda * 2u + kcb;
             a_b[i] = a_y[i] = a_x[i] = 0;
         }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int n = n0 + rbase + 32 * i;
-        w_ok[i] = n < p.N;
-        w_off[i] = (long long)n * p.ldw + kc * 8;
+        const int r = rbase + RP * i;
+        const int n = n0 + r;
+        w_ok[i] = r < BN && n < p.N;
+        w_off[i] = (unsigned)n * (unsigned)p.ldw * 2u + kcb;
     }
 
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    half8 ra[NA], rb[NB];
+    // ---- conv K iterator: (tap, channel offset) advanced by one K tile per stage
+    const int Ctot = p.C1 + p.C2;
+    const int Hp = p.H >> p.ups, Wp = p.Wd >> p.ups;
+    int it_tap = 0, it_c = 0;           // tap 0..8 = 3x3 taps, 9 = fused-1x1 extra range
+    unsigned r1[NA], r2[NA];            // byte offsets of the row's pixel in source 1 / source 2 (+ chunk)
+    auto set_tap = [&](int tap) {
+        if (tap < 9) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                a_live[i] = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                const unsigned pix = (unsigned)((a_b[i] * Hp + (iy >> p.ups)) * Wp + (ix >> p.ups));
+                r1[i] = pix * (unsigned)p.C1 * 2u + kcb;
+                r2[i] = pix * (unsigned)p.C2 * 2u + kcb;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                a_live[i] = a_ok[i];
+                r1[i] = a_m[i] * (unsigned)p.CE1 * 2u + kcb;
+                r2[i] = a_m[i] * (unsigned)p.CE2 * 2u + kcb;
+            }
+        }
+    };
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-        if constexpr (CONV) {
-            const int Ctot = p.C1 + p.C2;
-            if (k0 < 9 * Ctot) {
-                const int tap = k0 / Ctot, c0 = k0 - tap * Ctot;
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const half_t* src = A;
-                int cs = p.C1, cc = c0;
-                if (c0 >= p.C1) { src = A2; cs = p.C2; cc = c0 - p.C1; }
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                    const int py = iy >> p.ups, px = ix >> p.ups;
-                    const long long off = ((long long)(a_b[i] * Hp + py) * Wp + px) * cs + cc + kc * 8;
-                    ra[i] = ok ? *(const half8*)(src + off) : zero8;
-                }
-            } else {  // fused 1x1 over the extra sources, sampled at the output pixel
-                const int ke = k0 - 9 * Ctot;
-                const half_t* src = p.E1;
-                int cs = p.CE1, cc = ke;
-                if (ke >= p.CE1) { src = p.E2; cs = p.CE2; cc = ke - p.CE1; }
-#pragma unroll
-                for (int i = 0; i < NA; ++i)
-                    ra[i] = a_ok[i] ? *(const half8*)(src + a_off[i] * cs + cc + kc * 8) : zero8;
-            }
-        } else {
-            const bool kok = k0 + kc * 8 < p.K;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = (a_ok[i] && kok) ? *(const half8*)(A + a_off[i] + k0) : zero8;
-        }
-        const bool kok = k0 + kc * 8 < p.K;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = (w_ok[i] && kok) ? *(const half8*)(Wt + w_off[i] + k0) : zero8;
-    };
-    // LDS-DMA staging of K tile kt into buffer buf (asynchronous; tracked by vmcnt)
     auto stage_tile = [&](int buf, int kt) {
-        const int k0 = kt * BK;
-        const half_t* zp = p.zeros;
-        half_t* la = As + buf * BM * BK + (wave * 8) * BK;
-        half_t* lb = Bs + buf * BN * BK + (wave * 8) * BK;
+        const unsigned k0b = (unsigned)kt * (BK * 2);
+        half_t* la = As + buf * ROWS_A * BK + (wave * 8) * BK;
+        half_t* lb = Bs + buf * ROWS_B * BK + (wave * 8) * BK;
         if constexpr (CONV) {
-            const int Ctot = p.C1 + p.C2;
-            if (k0 < 9 * Ctot) {
-                const int tap = k0 / Ctot, c0 = k0 - tap * Ctot;
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const half_t* src = A;
-                int cs = p.C1, cc = c0;
-                if (c0 >= p.C1) { src = A2; cs = p.C2; cc = c0 - p.C1; }
+            const char* s1 = it_tap < 9 ? A : (const char*)p.E1;
+            const char* s2 = it_tap < 9 ? (const char*)p.A2 : (const char*)p.E2;
+            const int c1 = it_tap < 9 ? p.C1 : p.CE1;
+            const bool first = it_c < c1;
+            const char* src = first ? s1 : s2;
+            const unsigned cc = (unsigned)(first ? it_c : it_c - c1) * 2u;
 #pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                    const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                    const int py = iy >> p.ups, px = ix >> p.ups;
-                    const long long off = ((long long)(a_b[i] * Hp + py) * Wp + px) * cs + cc + kc * 8;
-                    glds16(ok ? src + off : zp, la + 32 * i * BK);
-                }
-            } else {
-                const int ke = k0 - 9 * Ctot;
-                const half_t* src = p.E1;
-                int cs = p.CE1, cc = ke;
-                if (ke >= p.CE1) { src = p.E2; cs = p.CE2; cc = ke - p.CE1; }
-#pragma unroll
-                for (int i = 0; i < NA; ++i) glds16(a_ok[i] ? src + a_off[i] * cs + cc + kc * 8 : zp, la + 32 * i * BK);
+            for (int i = 0; i < NA; ++i) {
+                const unsigned off = (first ? r1[i] : r2[i]) + cc;
+                glds16(a_live[i] ? src + off : zp, la + RP * i * BK);
             }
+            // advance the iterator by one K tile
+            it_c += BK;
+            if (it_tap < 9 && it_c >= Ctot) { it_c = 0; ++it_tap; set_tap(it_tap); }
         } else {
-            const bool kok = k0 + kc * 8 < p.K;
+            const bool kok = k0b + kcb < (unsigned)p.K * 2u;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) glds16((a_ok[i] && kok) ? A + a_off[i] + k0 : zp, la + 32 * i * BK);
+            for (int i = 0; i < NA; ++i) glds16((a_ok[i] && kok) ? A + (a_off[i] + k0b) : zp, la + RP * i * BK);
         }
-        const bool kok = k0 + kc * 8 < p.K;
+        const bool kok = k0b + kcb < (unsigned)p.K * 2u;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16((w_ok[i] && kok) ? Wt + w_off[i] + k0 : zp, lb + 32 * i * BK);
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = rbase + 32 * i;
-            *(half8*)(As + buf * BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 3)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int row = rbase + 32 * i;
-            *(half8*)(Bs + buf * BN * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 3)) = rb[i];
-        }
+        for (int i = 0; i < NB; ++i) glds16((w_ok[i] && kok) ? Wt + (w_off[i] + k0b) : zp, lb + RP * i * BK);
     };
 
     f32x4 acc[TM][TN];
@@ -187,25 +173,23 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
         kt_lo = blockIdx.y * per;
         nk = min(nk_all, kt_lo + per);
     }
+    if constexpr (CONV) {
+        const int k0 = kt_lo * BK;
+        if (k0 < 9 * Ctot) { it_tap = k0 / Ctot; it_c = k0 - it_tap * Ctot; }
+        else { it_tap = 9; it_c = k0 - 9 * Ctot; }
+        set_tap(it_tap);
+    }
     const int fr = lane & 15, fq = lane >> 4;
     if (kt_lo < nk) {
-        if constexpr (GLDS) {
-            stage_tile(0, kt_lo);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            load_tile(kt_lo);
-            store_tile(0);
-        }
+        stage_tile(0, kt_lo);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     for (int kt = kt_lo; kt < nk; ++kt) {
         const int cur = (kt - kt_lo) & 1;
-        if (kt + 1 < nk) {
-            if constexpr (GLDS) stage_tile(cur ^ 1, kt + 1);
-            else load_tile(kt + 1);
-        }
-        const half_t* Ac = As + cur * BM * BK;
-        const half_t* Bc = Bs + cur * BN * BK;
+        if (kt + 1 < nk) stage_tile(cur ^ 1, kt + 1);
+        const half_t* Ac = As + cur * ROWS_A * BK;
+        const half_t* Bc = Bs + cur * ROWS_B * BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 af[TM], bf[TN];
@@ -226,23 +210,19 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile has landed in LDS
-        } else {
-            if (kt + 1 < nk) store_tile(cur ^ 1);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile has landed in LDS
         __syncthreads();
     }
 
     // ---------------- epilogue through LDS: 64 output rows per pass
     constexpr int LDS_N = BN + 4;
-    constexpr int NPASS = BM / 64;
+    constexpr int NPASS = (BM + 63) / 64;
     constexpr int CH = BN / 8;
     float* stage = (float*)smem;
     half_t* __restrict__ Out = p.Out + z * p.strideO;
     for (int pass = 0; pass < NPASS; ++pass) {
-        if (NPASS == 1 || wr == pass) {
-            const int rb0 = (NPASS == 1) ? wr * WM : 0;
+        if ((wr * WM) / 64 == pass) {
+            const int rb0 = wr * WM - pass * 64;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -252,7 +232,8 @@ __global__ __launch_bounds__(256) void igemm_f16_kernel(const IefGemmParams p) {
                         stage[(rb0 + i * 16 + fq * 4 + r) * LDS_N + wc * WN + j * 16 + fr] = acc[i][j][r];
         }
         __syncthreads();
-        for (int c = tid; c < 64 * CH; c += 256) {
+        constexpr int PROWS = BM < 64 ? BM : 64;
+        for (int c = tid; c < PROWS * CH; c += NT) {
             const int row = c / CH, nc = c - row * CH;
             const int m = m0 + pass * 64 + row, n = n0 + nc * 8;
             if (m < p.M && n < p.N) {
@@ -328,14 +309,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IefGemmParam
     }
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
 static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int splits = p.splits > 1 ? p.splits : 1;
-    if (p.flags & 1)
-        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, CONV, true>), dim3(tiles, splits, batch), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, CONV, false>), dim3(tiles, splits, batch), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, WAVES_M, WAVES_N, CONV>), dim3(tiles, splits, batch),
+                       dim3(64 * WAVES_M * WAVES_N), 0, st, p);
     IEF_LAUNCH_CHECK();
     if (splits > 1) {
         const long long total = (long long)p.M * (p.N / 8);
@@ -347,29 +326,39 @@ static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     return IEF_OK;
 }
 
-// Tile choice: fill 256 CUs.  Big-M layers take 128x128; when that yields fewer than ~1.5
-// waves of blocks fall back to 64-row / 64-col tiles (more, smaller blocks).
+// tile ids (IefGemmParams.tile_hint); the host binding picks one per layer shape
+//   1: 128x128 (2x2 waves)   2: 64x128 (2x2)    3: 64x64 (2x2)     4: 128x64 (2x2)
+//   5: 64x160 (2x2)          6: 128x160 (2x2)   7: 128x160 (4x2)   8: 256x128 (4x2)   9: 128x128 (4x2)
 template <bool CONV>
 static int dispatch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
+    switch (p.tile_hint) {
+        case 1: return launch_igemm<128, 128, 2, 2, CONV>(p, batch, st);
+        case 2: return launch_igemm<64, 128, 2, 2, CONV>(p, batch, st);
+        case 3: return launch_igemm<64, 64, 2, 2, CONV>(p, batch, st);
+        case 4: return launch_igemm<128, 64, 2, 2, CONV>(p, batch, st);
+        case 5: return launch_igemm<64, 160, 2, 2, CONV>(p, batch, st);
+        case 6: return launch_igemm<128, 160, 2, 2, CONV>(p, batch, st);
+        case 7: return launch_igemm<128, 160, 4, 2, CONV>(p, batch, st);
+        case 8: return launch_igemm<256, 128, 4, 2, CONV>(p, batch, st);
+        case 9: return launch_igemm<128, 128, 4, 2, CONV>(p, batch, st);
+        default: break;
+    }
     auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
-    if (p.tile_hint == 1) return launch_igemm<128, 128, CONV>(p, batch, st);
-    if (p.tile_hint == 2) return launch_igemm<64, 128, CONV>(p, batch, st);
-    if (p.tile_hint == 3) return launch_igemm<64, 64, CONV>(p, batch, st);
-    if (p.tile_hint == 4) return launch_igemm<128, 64, CONV>(p, batch, st);
-    if (nblk(128, 128) >= 384) return launch_igemm<128, 128, CONV>(p, batch, st);
-    if (nblk(64, 128) >= 256) return launch_igemm<64, 128, CONV>(p, batch, st);
-    return launch_igemm<64, 64, CONV>(p, batch, st);
+    if (nblk(128, 128) >= 384) return launch_igemm<128, 128, 2, 2, CONV>(p, batch, st);
+    if (nblk(64, 128) >= 256) return launch_igemm<64, 128, 2, 2, CONV>(p, batch, st);
+    return launch_igemm<64, 64, 2, 2, CONV>(p, batch, st);
 }
 
 static int check_common(const IefGemmParams& p) {
-    if (!p.A || !p.W || !p.Out) return IEF_EINVAL;
+    if (!p.A || !p.W || !p.Out || !p.zeros) return IEF_EINVAL;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IEF_ESHAPE;
     if ((p.N & 7) || (p.K & 7) || (p.ldw & 7) || (p.ldo & 7)) return IEF_EALIGN;
     if (p.residual && (p.ldr & 7)) return IEF_EALIGN;
     if (p.rowvec && p.rows_per_batch <= 0) return IEF_ESHAPE;
     if (p.splits > 1 && !p.ws) return IEF_EINVAL;
-    if ((p.flags & 1) && !p.zeros) return IEF_EINVAL;
     if (p.splits > 64) return IEF_ESHAPE;
+    // 32-bit byte offsets inside each operand
+    if ((long long)p.N * p.ldw * 2 >= (1ll << 32)) return IEF_ESHAPE;
     return IEF_OK;
 }
 
@@ -381,6 +370,7 @@ extern "C" int ief_gemm_f16(const IefGemmParams* pp, int batch, void* stream) {
     if (p.lda & 7) return IEF_EALIGN;
     if (batch <= 0) return IEF_ESHAPE;
     if (p.splits > 1 && batch != 1) return IEF_ESHAPE;
+    if ((long long)p.M * p.lda * 2 >= (1ll << 32)) return IEF_ESHAPE;
     p.ups = 0; p.H = p.Wd = 1;
     return dispatch_igemm<false>(p, batch, (hipStream_t)stream);
 }
@@ -406,6 +396,10 @@ extern "C" int ief_conv3x3_f16(const IefGemmParams* pp, void* stream) {
     if (p.rowvec && p.rows_per_batch <= 0) p.rows_per_batch = p.Ho * p.Wo;  // caller may share one row across the batch
     int rc = check_common(p);
     if (rc) return rc;
+    const long long in_pix = (long long)p.batch_images * (p.H >> p.ups) * (p.Wd >> p.ups);
+    const int cmax = p.C1 > p.C2 ? p.C1 : p.C2;
+    const int emax = p.CE1 > p.CE2 ? p.CE1 : p.CE2;
+    if (in_pix * cmax * 2 >= (1ll << 32) || (long long)p.M * emax * 2 >= (1ll << 32)) return IEF_ESHAPE;
     p.strideA = p.strideW = p.strideO = p.strideR = 0;
     return dispatch_igemm<true>(p, 1, (hipStream_t)stream);
 }

@@ -131,7 +131,14 @@ def _stream() -> int:
 # bench.py brackets individual launches with HIP events ON THE STREAM THE KERNEL RUNS ON to get the
 # dominant kernel's average launch duration (roofline.achieved).  Off by default (zero overhead).
 _prof = None
-_TILES = {1: (128, 128), 2: (64, 128), 3: (64, 64), 4: (128, 64)}
+# tile id -> (BM, BN, WAVES_M, WAVES_N), as in csrc/gemm_conv.hip
+_TILES = {1: (128, 128, 2, 2), 2: (64, 128, 2, 2), 3: (64, 64, 2, 2), 4: (128, 64, 2, 2), 5: (64, 160, 2, 2),
+          6: (128, 160, 2, 2), 7: (128, 160, 4, 2), 8: (256, 128, 4, 2), 9: (128, 128, 4, 2)}
+
+
+def _kname(tile, conv):
+    bm, bn, wm, wn = _TILES[tile]
+    return f"igemm_f16_kernel<{bm}, {bn}, {wm}, {wn}, {'true' if conv else 'false'}>"
 
 
 def profile_begin():
@@ -172,8 +179,7 @@ def pick_tile(M: int, N: int, batch: int = 1) -> int:
     return 3
 
 
-GLDS = os.environ.get("IEF_GLDS", "1") != "0"   # direct global->LDS operand staging in the igemm kernels
-_zero_pages = {}
+_zero_pages = {}   # device zero page: source of padded / out-of-range chunks for the LDS-DMA staging
 
 
 def _zeros(device):
@@ -184,16 +190,48 @@ def _zeros(device):
 
 
 SPLITK = os.environ.get("IEF_SPLITK", "1") != "0"
-_SPLIT_TARGET = int(os.environ.get("IEF_SPLIT_TARGET", "256"))   # blocks wanted on the 256 CUs
+_SPLIT_TARGET = int(os.environ.get("IEF_SPLIT_TARGET", "512"))   # blocks wanted on the 256 CUs
 _SPLIT_MAX = int(os.environ.get("IEF_SPLIT_MAX", "16"))
 _SPLIT_MIN_KT = int(os.environ.get("IEF_SPLIT_MIN_KT", "6"))     # K tiles (of 64) each slice keeps at least
 
+# ---- plan selection: tuned table first, heuristic otherwise -----------------------------------------
+# `tuned_plans.json` (next to this file) maps "conv|M|N|K" / "gemm|M|N|K" -> [tile, splits]; it is produced
+# on the GPU by `autotune_plan` (tests/tune_plans.py) and covers the SD1.5 layer shapes at batch 1 / 2 / 4.
+_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans.json")
+_plans = None
+AUTOTUNE = os.environ.get("IEF_AUTOTUNE", "0") == "1"   # tune unseen shapes on first use (outside graph capture)
 
-def pick_plan(M: int, N: int, K: int):
-    """(tile_hint, splits).  Layers whose M x N alone gives fewer 128x128 tiles than ~1.5 per CU and whose
-    K loop is long (the 16x16 / 8x8 levels of the UNet: M = 1024 / 256, K up to 23040) are cut along K so
-    that >= ~2 blocks per CU exist; every slice keeps >= 6 K tiles of 64."""
+
+def _plan_table():
+    global _plans
+    if _plans is None:
+        _plans = {}
+        if os.path.exists(_PLAN_FILE) and os.environ.get("IEF_NO_PLAN_TABLE", "0") != "1":
+            import json
+            with open(_PLAN_FILE) as f:
+                _plans = {k: tuple(v) for k, v in json.load(f).items()}
+    return _plans
+
+
+def save_plans(path=None):
+    import json
+    with open(path or _PLAN_FILE, "w") as f:
+        json.dump({k: list(v) for k, v in sorted(_plan_table().items())}, f, indent=0)
+
+
+def heuristic_plan(M: int, N: int, K: int):
+    """(tile, splits) without measurements.  SD channel widths are multiples of 320 = 2 x 160, so 160-wide
+    tiles waste nothing on N; layers whose M x N alone gives too few tiles (the 32x32 .. 8x8 UNet levels, K up to
+    23040) are cut along K until ~512 blocks exist, each slice keeping >= 6 K tiles of 64."""
     nk = -(-K // 64)
+    if N % 160 == 0 and M >= 128:
+        t6 = -(-M // 128) * (N // 160)
+        if t6 >= 192 and (nk < 24 or t6 >= 384):
+            return 7, 1
+        if nk >= 12 and SPLITK:
+            splits = max(1, min(-(-_SPLIT_TARGET // t6), nk // _SPLIT_MIN_KT, _SPLIT_MAX))
+            if t6 * splits >= 128:
+                return 6, splits
     t128 = -(-M // 128) * -(-N // 128)
     if not SPLITK or t128 >= 384 or nk < 24:
         return pick_tile(M, N), 1
@@ -204,6 +242,65 @@ def pick_plan(M: int, N: int, K: int):
     if splits <= 1:
         return pick_tile(M, N), 1
     return tile, splits
+
+
+def pick_plan(M: int, N: int, K: int, conv: bool = False):
+    hit = _plan_table().get(f"{'conv' if conv else 'gemm'}|{M}|{N}|{K}")
+    return hit if hit is not None else heuristic_plan(M, N, K)
+
+
+def candidate_plans(M: int, N: int, K: int):
+    nk = -(-K // 64)
+    out = []
+    for t, (bm, bn, _, _) in _TILES.items():
+        for s in (1, 2, 4, 8, 16):
+            blocks = -(-M // bm) * -(-N // bn) * s
+            if s > 1 and (nk // s < 4 or blocks > 2048):
+                continue
+            if blocks < 48 and s < 16:
+                continue
+            out.append((t, s))
+    return out
+
+
+def _time_graph(fn, iters=20):
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn()
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def autotune_plan(kind: str, M: int, N: int, K: int, run):
+    """time run(tile, splits) for every candidate plan (hipGraph of 20 launches each); remember the best"""
+    best = None
+    for t, sp in candidate_plans(M, N, K):
+        try:
+            us = _time_graph(lambda: run(t, sp))
+        except RuntimeError:
+            continue
+        if best is None or us < best[0]:
+            best = (us, t, sp)
+    if best is not None:
+        _plan_table()[f"{kind}|{M}|{N}|{K}"] = (best[1], best[2])
+    return best
+
+
+def _capturing() -> bool:
+    return torch.cuda.is_current_stream_capturing()
 
 
 def _ptr(t):
@@ -277,16 +374,18 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     p.rows_per_batch = rows_per_batch
     p.out_scale = out_scale
     if tile_hint == 0:
+        if AUTOTUNE and f"gemm|{M}|{N}|{K}" not in _plan_table() and not _capturing() and _prof is None:
+            autotune_plan("gemm", M, N, K, lambda t, sp: gemm(a, w, bias=bias, residual=residual, rowvec=rowvec,
+                                                               rows_per_batch=rows_per_batch, out=out,
+                                                               out_scale=out_scale, tile_hint=t, splits=sp))
         p.tile_hint, p.splits = pick_plan(M, N, K)
     else:
         p.tile_hint, p.splits = tile_hint, max(1, splits)
     if p.splits > 1:
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)
         p.ws = ws.data_ptr()
-    if GLDS:
-        p.flags, p.zeros = 1, _zeros(a.device)
-    bm, bn = _TILES[p.tile_hint]
-    with _Timed(f"igemm_f16_kernel<{bm}, {bn}, false>", 2.0 * M * N * K):
+    p.flags, p.zeros = 1, _zeros(a.device)
+    with _Timed(_kname(p.tile_hint, False), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     return out
 
@@ -344,17 +443,19 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.out_scale = 1.0
     M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
     if tile_hint == 0:
-        p.tile_hint, p.splits = pick_plan(M, Cout, K)
+        if AUTOTUNE and f"conv|{M}|{Cout}|{K}" not in _plan_table() and not _capturing() and _prof is None:
+            autotune_plan("conv", M, Cout, K, lambda t, sp: conv3x3(x, w, bias, x2=x2, stride=stride, upsample=upsample,
+                                                                     rowvec=rowvec, residual=residual, out=out,
+                                                                     tile_hint=t, splits=sp, extra=extra))
+        p.tile_hint, p.splits = pick_plan(M, Cout, K, conv=True)
     else:
         p.tile_hint, p.splits = tile_hint, max(1, splits)
     if p.splits > 1:
         ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)
         p.ws = ws.data_ptr()
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
-    if GLDS:
-        p.flags, p.zeros = 1, _zeros(x.device)
-    bm, bn = _TILES[p.tile_hint]
-    with _Timed(f"igemm_f16_kernel<{bm}, {bn}, true>", 2.0 * M * Cout * K):
+    p.flags, p.zeros = 1, _zeros(x.device)
+    with _Timed(_kname(p.tile_hint, True), 2.0 * M * Cout * K):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
     return out
 

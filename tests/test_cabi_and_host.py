@@ -45,10 +45,13 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 
 def test_tile_plans():
-    assert hip.pick_plan(16384, 320, 2880) == (1, 1)          # 64x64 level: plenty of tiles, no split
-    t, s = hip.pick_plan(256, 1280, 11520)                      # 8x8 level: split-K
+    t, s = hip.heuristic_plan(16384, 320, 2880)                 # 64x64 level: 256 tiles of 128x160
+    assert s <= 2 and hip._TILES[t][1] == 160                   # N = 320 = 2 x 160: no padded columns
+    t, s = hip.heuristic_plan(256, 1280, 11520)                 # 8x8 level: split-K
     assert s > 1 and 11520 // 64 // s >= 6
-    assert hip.pick_plan(4, 1280, 320)[1] == 1                  # time-embedding GEMM
+    assert hip.heuristic_plan(4, 1280, 320)[1] == 1             # time-embedding GEMM
+    for (t, s) in hip.candidate_plans(1024, 1280, 11520):
+        assert t in hip._TILES and 1 <= s <= 16
 
 
 def test_param_inventory_matches_sd15():

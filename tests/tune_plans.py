@@ -1,0 +1,34 @@
+"""Autotune the (tile, split-K) plan of every GEMM / conv layer shape of the SD1.5 UNet at UNet batch 4 / 2 / 1
+(edit, synthesis, inversion) on the current GPU and write the table the binding loads at import.
+
+    python tests/tune_plans.py [out.json]       (run on the MI355X box; ~1 minute)
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import ief_amd  # noqa: F401
+from ief_amd import hip
+import bench
+
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join("gpurun_out", "tuned_plans.json")
+cfg_name = sys.argv[2] if len(sys.argv) > 2 else "sd15"
+dev = torch.device("cuda:0")
+os.environ["IEF_NO_PLAN_TABLE"] = "1"
+hip._plans = {}
+hip.AUTOTUNE = True
+pipe, cfg = bench.build_pipe(cfg_name, dev, 0, 1)
+hw = cfg.sample_size
+for B in (4, 2, 1):
+    x = torch.randn(B, 4, hw, hw, device=dev)
+    ctx = (torch.randn(B, 77, cfg.cross_attention_dim, device=dev) * 0.1)
+    with torch.no_grad():
+        pipe.unet(x, 501, encoder_hidden_states=ctx)
+    torch.cuda.synchronize()
+    print(f"B={B}: {len(hip._plan_table())} shapes tuned", flush=True)
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+hip.save_plans(out)
+for k, v in sorted(hip._plan_table().items()):
+    print(k, v)
