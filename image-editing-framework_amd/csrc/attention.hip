@@ -35,6 +35,9 @@ struct AttnCfg {
     static constexpr bool ONES_ROW = (D % 32) != 0;
 };
 
+template <bool B>
+struct BoolTag { static constexpr bool value = B; };
+
 __device__ __forceinline__ half8 pack8(const f32x16& p, int base) {
     half8 o;
 #pragma unroll
@@ -71,13 +74,27 @@ __device__ __forceinline__ void load_q_frags(half8 (&qf)[AttnCfg<D>::D16], const
 // ------------------------------------------------------------------------------------------
 // flash attention with source indirection
 // ------------------------------------------------------------------------------------------
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4_t lds_fp16x4_t;
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of halves, delivered column-major
+// (lane i of the group gets column i of the 4 rows).  Every lane passes the address of row (L>>2),
+// columns 4(L&3).. of ITS group's block (L = lane & 15).  EXEC must be all ones.
+__device__ __forceinline__ half4 lds_tr_read(const half_t* p) {
+    const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4_t*)p);
+    return __builtin_bit_cast(half4, v);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) {
     using C = AttnCfg<D>;
-    constexpr int VS = 68;                                   // V^T row stride: 64 keys + 4 pad
+    // V tile kept ROW-major [key][d]; the PV A-operand (V^T fragment) comes from transposing reads.  Row stride
+    // = 64 or 192 (mod 256) bytes so the four rows of a 32-lane half land in distinct 64-B bank slots.
+    constexpr int VRS = D <= 32 ? 32 : (D <= 96 ? 96 : 160);   // halves per V row in LDS
     constexpr int NCH = (64 * C::CPR + 255) / 256;
-    __shared__ __attribute__((aligned(16))) half_t Ks[64 * C::KS];
-    __shared__ __attribute__((aligned(16))) half_t Vt[C::DT * 32 * VS];
+    constexpr int KBUF = 64 * C::KS, VBUF = 64 * VRS;
+    __shared__ __attribute__((aligned(16))) half_t Ks[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) half_t Vs[2 * VBUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -88,11 +105,12 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     const int q0 = blockIdx.x * 128 + wave * 32;
     const bool q_ok = q0 + r < p.N;
 
-    for (int i = tid; i < 64 * C::KS / 8; i += 256) ((half8*)Ks)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < C::DT * 32 * VS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
-    if constexpr (C::ONES_ROW) {
+    // zero both buffers once: K pad columns (d..DP) and V pad columns (d..32*DT) are never rewritten
+    for (int i = tid; i < 2 * KBUF / 8; i += 256) ((half8*)Ks)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < 2 * VBUF / 8; i += 256) ((half8*)Vs)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (C::ONES_ROW) {  // column D of V = 1: the PV MFMA then accumulates the softmax row sum in O^T[D][q]
         __syncthreads();
-        if (tid < 64) Vt[D * VS + tid] = (half_t)1.0f;
+        if (tid < 128) Vs[(tid >> 6) * VBUF + (tid & 63) * VRS + D] = (half_t)1.0f;
     }
 
     half8 qf[C::D16];
@@ -101,26 +119,36 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     const half_t* Kb = p.K + (long long)ks * p.L * p.ldk + head * D;
     const half_t* Vb = p.V + (long long)vs * p.L * p.ldv + head * D;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // staging map of this thread (fixed for the whole kernel)
+    int st_row[NCH], st_k[NCH], st_v[NCH];
+    long long st_gk[NCH], st_gv[NCH];
+    bool st_ok[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / C::CPR, ch = c - row * C::CPR;
+        st_ok[i] = c < 64 * C::CPR;
+        st_row[i] = row;
+        st_k[i] = row * C::KS + ch * 8;
+        st_v[i] = row * VRS + ch * 8;
+        st_gk[i] = (long long)row * p.ldk + ch * 8;
+        st_gv[i] = (long long)row * p.ldv + ch * 8;
+    }
     half8 kreg[NCH], vreg[NCH];
     auto load_tile = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c / C::CPR, ch = c - row * C::CPR;
-            const bool ok = c < 64 * C::CPR && kv0 + row < p.L;
-            kreg[i] = ok ? *(const half8*)(Kb + (long long)(kv0 + row) * p.ldk + ch * 8) : zero8;
-            vreg[i] = ok ? *(const half8*)(Vb + (long long)(kv0 + row) * p.ldv + ch * 8) : zero8;
+            const bool ok = st_ok[i] && kv0 + st_row[i] < p.L;
+            kreg[i] = ok ? *(const half8*)(Kb + (long long)kv0 * p.ldk + st_gk[i]) : zero8;
+            vreg[i] = ok ? *(const half8*)(Vb + (long long)kv0 * p.ldv + st_gv[i]) : zero8;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            if (c < 64 * C::CPR) {
-                const int row = c / C::CPR, ch = c - row * C::CPR;
-                *(half8*)(Ks + row * C::KS + ch * 8) = kreg[i];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * VS + row] = vreg[i][e];
+            if (st_ok[i]) {
+                *(half8*)(Ks + buf * KBUF + st_k[i]) = kreg[i];
+                *(half8*)(Vs + buf * VBUF + st_v[i]) = vreg[i];
             }
         }
     };
@@ -133,27 +161,26 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     float m_run = -INFINITY, l_run = 0.f;
     const float sc = p.scale * LOG2E;
 
-    const int nt = (p.L + 63) / 64;
-    __syncthreads();  // zero fill done
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int j = 0; j < nt; ++j) {
-        const int kv0 = j * 64;
-        if (j + 1 < nt) load_tile(kv0 + 64);
+    // per-lane bases of the fragment reads
+    const int k_lane = r * C::KS + 8 * h;                                   // K rows (A operand of S^T)
+    const int L16 = lane & 15;
+    const int v_lane = (4 * h + (L16 >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (L16 & 3);   // transposing V reads
+
+    // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  `masked` is a compile-time tag so the
+    // full tiles carry no bounds code at all.
+    auto tile_body = [&](int kv0, const half_t* Kc, const half_t* Vc, auto masked) {
         f32x16 s0, s1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
         for (int s = 0; s < C::D16; ++s) {
-            const half8 k0 = *(const half8*)(Ks + r * C::KS + 16 * s + 8 * h);
-            const half8 k1 = *(const half8*)(Ks + (32 + r) * C::KS + 16 * s + 8 * h);
+            const half8 k0 = *(const half8*)(Kc + k_lane + 16 * s);
+            const half8 k1 = *(const half8*)(Kc + k_lane + 32 * C::KS + 16 * s);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
         }
         // online softmax on RAW scores (scale folded into one fma per element: p = 2^(s*sc - m))
-        const bool tail = kv0 + 64 > p.L;
-        if (tail) {
+        if constexpr (decltype(masked)::value) {   // only the last, partial key tile carries the mask code
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -182,20 +209,33 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
         }
-        const half8 pb00 = pack8(s0, 0), pb01 = pack8(s0, 8), pb10 = pack8(s1, 0), pb11 = pack8(s1, 8);
+        const half8 pb[4] = {pack8(s0, 0), pack8(s0, 8), pack8(s1, 0), pack8(s1, 8)};
 #pragma unroll
         for (int t = 0; t < C::DT; ++t) {
-            const half_t* vrow = Vt + (t * 32 + r) * VS;
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 0, h), pb00, o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 16, h), pb01, o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 32, h), pb10, o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(vrow, 48, h), pb11, o[t], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {   // 16 keys per MFMA; fragment = keys {4h..4h+3} and {8+4h..8+4h+3} of the step
+                const half_t* vp = Vc + v_lane + (16 * kk) * VRS + 32 * t;
+                const half4 lo = lds_tr_read(vp), hi = lds_tr_read(vp + 8 * VRS);
+                const half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kk], o[t], 0, 0, 0);
+            }
         }
+    };
+
+    const int nt = (p.L + 63) / 64;
+    __syncthreads();  // zero fill (and ones column) done
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const int kv0 = j * 64, cur = j & 1;
+        if (j + 1 < nt) load_tile(kv0 + 64);            // global loads in flight during the MFMA/softmax work
+        const half_t* Kc = Ks + cur * KBUF;
+        const half_t* Vc = Vs + cur * VBUF;
+        if (kv0 + 64 > p.L) tile_body(kv0, Kc, Vc, BoolTag<true>{});
+        else tile_body(kv0, Kc, Vc, BoolTag<false>{});
+        if (j + 1 < nt) store_tile(cur ^ 1);            // other buffer: last read one barrier ago
         __syncthreads();
-        if (j + 1 < nt) {
-            store_tile();
-            __syncthreads();
-        }
     }
     float l_tot;
     if constexpr (C::ONES_ROW) {

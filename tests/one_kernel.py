@@ -1,0 +1,25 @@
+"""Launch ONE kernel shape a few times (for rocprofv3 --pmc runs).  usage: one_kernel.py attn40|conv64|gemmff"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import ief_amd
+from ief_amd import hip
+DEV = torch.device("cuda:0")
+h = lambda *s, scale=1.0: (torch.randn(*s, device=DEV) * scale).half()
+what = sys.argv[1]
+if what == "attn40":
+    B, heads, N, d = 4, 8, 4096, 40
+    qkv = h(B, N, 3 * heads * d); C = heads * d
+    fn = lambda: hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, d ** -0.5)
+elif what == "conv64":
+    x, w, b = h(4, 64, 64, 320), h(320, 3, 3, 320, scale=0.02), torch.randn(320, device=DEV)
+    fn = lambda: hip.conv3x3(x, w, b)
+elif what == "conv32":
+    x, w, b = h(4, 32, 32, 640), h(640, 3, 3, 640, scale=0.02), torch.randn(640, device=DEV)
+    fn = lambda: hip.conv3x3(x, w, b)
+elif what == "gemmff":
+    a, w = h(4096, 640), h(5120, 640, scale=0.04)
+    fn = lambda: hip.gemm(a, w)
+for _ in range(4):
+    fn()
+torch.cuda.synchronize()
