@@ -113,8 +113,17 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
         if (tid < 128) Vs[(tid >> 6) * VBUF + (tid & 63) * VRS + D] = (half_t)1.0f;
     }
 
+    // Q fragments pre-multiplied by scale*log2(e): scores come out of the MFMA in log2 units, so the softmax
+    // needs no per-element multiply (one extra fp16 rounding of q; error << the fp16 rounding of P)
     half8 qf[C::D16];
     load_q_frags<D>(qf, p.Q, ((long long)qs * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    {
+        const float sc = p.scale * LOG2E;
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)qf[s][e] * sc);
+    }
 
     const half_t* Kb = p.K + (long long)ks * p.L * p.ldk + head * D;
     const half_t* Vb = p.V + (long long)vs * p.L * p.ldv + head * D;
@@ -158,8 +167,17 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     for (int t = 0; t < C::DT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sc = p.scale * LOG2E;
+    // Online softmax with the running row maximum folded INTO the score MFMA: the accumulators start at
+    // -m_run (a per-lane row constant, kept in `minit`), so S' = s - m_run leaves the MFMA chain and the common
+    // case is p = 2^S' with no subtraction at all.  m_run moves only when a tile's maximum exceeds it by more than
+    // RESCALE_THR (then O and the pending S' are corrected exactly once, before S' is exponentiated); P stays
+    // <= 2^RESCALE_THR, far inside fp16 range.
+    constexpr float RESCALE_THR = 5.0f;
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+    f32x16 minit;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) minit[i] = 0.f;
 
     // per-lane bases of the fragment reads
     const int k_lane = r * C::KS + 8 * h;                                   // K rows (A operand of S^T)
@@ -168,10 +186,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
 
     // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  `masked` is a compile-time tag so the
     // full tiles carry no bounds code at all.
-    auto tile_body = [&](int kv0, const half_t* Kc, const half_t* Vc, auto masked) {
-        f32x16 s0, s1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+    auto tile_body = [&](int kv0, const half_t* Kc, const half_t* Vc, auto masked) -> bool {
+        f32x16 s0 = minit, s1 = minit;
 #pragma unroll
         for (int s = 0; s < C::D16; ++s) {
             const half8 k0 = *(const half8*)(Kc + k_lane + 16 * s);
@@ -179,7 +195,6 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
         }
-        // online softmax on RAW scores (scale folded into one fma per element: p = 2^(s*sc - m))
         if constexpr (decltype(masked)::value) {   // only the last, partial key tile carries the mask code
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -191,24 +206,32 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx * sc);   // sc > 0
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float ls = 0.f;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));          // this row's maximum, relative to m_run
+        if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {   // wave-uniform; rare after the first tile
+            // move the reference maximum, rescale what was accumulated under the old one, and REDO this tile's
+            // scores against the new reference (nothing of this tile has been consumed yet).  Keeping the
+            // correction off the fall-through path keeps the accumulators in place in the hot loop.
+            const float delta = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], sc, -m_new));
-            s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], sc, -m_new));
-            if constexpr (!C::ONES_ROW) ls += s0[i] + s1[i];
-        }
-        if constexpr (!C::ONES_ROW) l_run = l_run * alpha + ls;
-        m_run = m_new;
-        if (__any(alpha != 1.0f)) {  // rescale only when some row's running max moved (rare after the first tiles)
+            for (int i = 0; i < 16; ++i) minit[i] = -m_run;
+            if constexpr (!C::ONES_ROW) l_run *= alpha;
 #pragma unroll
             for (int t = 0; t < C::DT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+            first = false;
+            return false;
         }
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i]);
+            s1[i] = __builtin_amdgcn_exp2f(s1[i]);
+            if constexpr (!C::ONES_ROW) ls += s0[i] + s1[i];
+        }
+        if constexpr (!C::ONES_ROW) l_run += ls;
         const half8 pb[4] = {pack8(s0, 0), pack8(s0, 8), pack8(s1, 0), pack8(s1, 8)};
 #pragma unroll
         for (int t = 0; t < C::DT; ++t) {
@@ -220,6 +243,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kk], o[t], 0, 0, 0);
             }
         }
+        return true;
     };
 
     const int nt = (p.L + 63) / 64;
@@ -227,15 +251,17 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     load_tile(0);
     store_tile(0);
     __syncthreads();
-    for (int j = 0; j < nt; ++j) {
+    int pf = 0;   // highest tile whose global loads were issued (a redone tile must not issue them twice)
+    for (int j = 0; j < nt;) {
         const int kv0 = j * 64, cur = j & 1;
-        if (j + 1 < nt) load_tile(kv0 + 64);            // global loads in flight during the MFMA/softmax work
+        if (j + 1 < nt && pf < j + 1) { load_tile(kv0 + 64); pf = j + 1; }   // in flight during the MFMA/softmax work
         const half_t* Kc = Ks + cur * KBUF;
         const half_t* Vc = Vs + cur * VBUF;
-        if (kv0 + 64 > p.L) tile_body(kv0, Kc, Vc, BoolTag<true>{});
-        else tile_body(kv0, Kc, Vc, BoolTag<false>{});
+        const bool done = (kv0 + 64 > p.L) ? tile_body(kv0, Kc, Vc, BoolTag<true>{}) : tile_body(kv0, Kc, Vc, BoolTag<false>{});
+        if (!done) continue;                            // reference maximum moved: same tile again
         if (j + 1 < nt) store_tile(cur ^ 1);            // other buffer: last read one barrier ago
         __syncthreads();
+        ++j;
     }
     float l_tot;
     if constexpr (C::ONES_ROW) {
