@@ -125,6 +125,65 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, const half_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Single-launch GroupNorm: one workgroup per (batch, group).  The group's slab (HW pixels x cpg channels)
+// is read twice by the SAME workgroup (second pass from L2), so statistics need no cross-workgroup
+// reduction, no scratch and no extra launches.  Accesses are 4-byte (2 channels): a group is cpg*2 bytes
+// per pixel (20 .. 160 B), i.e. part of a cache line; groups that share lines are placed on the same XCD
+// (block ids congruent mod 8) so one L2 merges them.  Thread (py, j) keeps channel pair j for all its pixels.
+__global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2,
+                                                       int C1, int C2, half_t* __restrict__ out,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int HW, int groups, float eps, int apply_silu, int PY) {
+    const int C = C1 + C2, cpg = C / groups, cp2 = cpg >> 1;
+    // 4 consecutive groups per XCD: id = xcd + 8k  ->  group = 4*xcd + k%4 (needs groups % 32 == 0, else linear)
+    const int id = blockIdx.x;
+    int b, g;
+    if ((groups & 31) == 0) {
+        const int per_b = groups, local = id % per_b;
+        b = id / per_b;
+        const int chunk = local / 32, l32 = local % 32;
+        g = chunk * 32 + (l32 & 7) * 4 + (l32 >> 3);
+    } else {
+        b = id / groups; g = id % groups;
+    }
+    const int j = threadIdx.x % cp2, py = threadIdx.x / cp2;
+    const bool live = py < PY;
+    const int c = g * cpg + 2 * j;
+    const half_t* src = c < C1 ? x : x2;
+    const int cs = c < C1 ? C1 : C2, cc = c < C1 ? c : c - C1;
+    const half_t* base = src + (long long)b * HW * cs + cc;
+    float s = 0.f, q = 0.f;
+    if (live) {
+        for (int p = py; p < HW; p += PY) {
+            const half2_t v = *(const half2_t*)(base + (long long)p * cs);
+            const float a0 = (float)v[0], a1 = (float)v[1];
+            s += a0 + a1; q += a0 * a0 + a1 * a1;
+        }
+    }
+    __shared__ float red[2][8];
+    s = wave_sum(s); q = wave_sum(q);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    float ts = 0.f, tq = 0.f;
+    for (int w = 0; w < nw; ++w) { ts += red[0][w]; tq += red[1][w]; }
+    const float inv = 1.0f / ((float)cpg * (float)HW);
+    const float mean = ts * inv;
+    const float rstd = rsqrtf(fmaxf(tq * inv - mean * mean, 0.f) + eps);
+    if (!live) return;
+    const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
+    const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+    half_t* ob = out + (long long)b * HW * C + c;
+    for (int p = py; p < HW; p += PY) {
+        const half2_t v = *(const half2_t*)(base + (long long)p * cs);
+        float y0 = (float)v[0] * sc0 + sh0, y1 = (float)v[1] * sc1 + sh1;
+        if (apply_silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
+        half2_t o = {(half_t)y0, (half_t)y1};
+        *(half2_t*)(ob + (long long)p * C) = o;
+    }
+}
+
 extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int C1, int C2, ief_half* out,
                                       const float* gamma, const float* beta, float* partial,
                                       int B, int HW, int groups, float eps, int apply_silu, void* stream) {
@@ -134,6 +193,19 @@ extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int
     if (B <= 0 || HW <= 0 || groups <= 0 || groups > GN_MAX_GROUPS) return IEF_ESHAPE;
     if ((C1 & 7) || (C2 & 7) || (C % groups) || C > 8 * 1024) return IEF_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    const int cpg_ = C / groups;
+    // single launch when one (batch, group) slab is small enough for one workgroup to stream twice quickly
+    if (!(cpg_ & 1) && !(C1 & 1) && (cpg_ >> 1) <= 256 && (long long)HW * cpg_ * 2 <= 48 * 1024) {
+        const int cp2 = cpg_ >> 1;
+        int PY = 512 / cp2;
+        if (PY > HW) PY = HW;
+        int threads = ((cp2 * PY + 63) / 64) * 64;
+        if (threads > 512) { PY -= 1; threads = ((cp2 * PY + 63) / 64) * 64; }
+        hipLaunchKernelGGL(gn_fused_kernel, dim3(B * groups), dim3(threads), 0, st, x, x2, C1, C2, out, gamma, beta, HW,
+                           groups, eps, apply_silu, PY);
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
     const int splits = gn_splits_host(HW);
     const int C8 = C / 8;
     // statistics: up to 1024 threads (C8 * PY), PY bounded by the pixels a block owns
