@@ -11,8 +11,8 @@
 //         W is [Cout][3][3][C1+C2](+extra) so both operands are K-major, what MFMA fragments want.
 //
 // One kernel template, a family of tiles <BM, BN, WAVES_M, WAVES_N> x BK = 64:
-//   - operand tiles are staged by LDS-DMA (global_load_lds, 16 B per lane, asynchronous) into a
-//     double buffer; LDS rows are 128 B with the 16-B chunk index XOR-ed by (row>>1)&7 — applied to
+//   - operand tiles are staged by LDS-DMA (global_load_lds, 16 B per lane, asynchronous) into an
+//     NS-deep ring (2..4 K tiles, counted vmcnt + raw s_barrier so loads stay in flight across barriers); LDS rows are 128 B with the 16-B chunk index XOR-ed by (row>>1)&7 — applied to
 //     the per-lane SOURCE address, the LDS image of a wave-instruction being lane-linear — which
 //     makes the ds_read_b128 fragment reads conflict-free;
 //   - conv addressing is incremental and 32-bit: per-row pixel offsets / padding masks are recomputed
@@ -40,7 +40,7 @@ __device__ __forceinline__ void glds16(const char* g, half_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool CONV>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const IefGemmParams p) {
     constexpr int BK = 64;
     constexpr int NT = 64 * WAVES_M * WAVES_N;      // threads
@@ -49,11 +49,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int ROWS_A = NA * RP, ROWS_B = NB * RP;   // LDS rows incl. staging overshoot
     static_assert(WM % 16 == 0 && WN % 16 == 0 && WM <= 64, "wave tile");
-    constexpr int STAGE_HALFS = 2 * (ROWS_A + ROWS_B) * BK;
+    static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
+    constexpr int STAGE_HALFS = NS * (ROWS_A + ROWS_B) * BK;
+    constexpr int G = NA + NB;                      // LDS-DMA instructions a wave issues per K tile
     constexpr int EPI_HALFS = 64 * (BN + 4) * 2;     // fp32 [64][BN+4]
     __shared__ __attribute__((aligned(16))) half_t smem[STAGE_HALFS > EPI_HALFS ? STAGE_HALFS : EPI_HALFS];
     half_t* As = smem;
-    half_t* Bs = smem + 2 * ROWS_A * BK;
+    half_t* Bs = smem + NS * ROWS_A * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
@@ -180,14 +182,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
         set_tap(it_tap);
     }
     const int fr = lane & 15, fq = lane >> 4;
-    if (kt_lo < nk) {
-        stage_tile(0, kt_lo);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
+    // NS-deep LDS ring: K tiles kt .. kt+NS-2 are in flight while tile kt is multiplied.  Order per iteration:
+    //   counted vmcnt (this wave's share of tile kt has landed)  ->  s_barrier (everybody's has; everybody is done
+    //   reading the buffer tile kt-1 used)  ->  issue tile kt+NS-1 into that buffer  ->  MFMAs on tile kt.
+    // Raw s_barrier + counted waits: __syncthreads() would drain every LDS-DMA in flight.
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (kt_lo + s < nk) stage_tile(s, kt_lo + s);
     for (int kt = kt_lo; kt < nk; ++kt) {
-        const int cur = (kt - kt_lo) & 1;
-        if (kt + 1 < nk) stage_tile(cur ^ 1, kt + 1);
+        const int rel = kt - kt_lo;
+        const int cur = rel % NS;
+        if (nk - 1 - kt >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + NS - 1 < nk) stage_tile((rel + NS - 1) % NS, kt + NS - 1);
         const half_t* Ac = As + cur * ROWS_A * BK;
         const half_t* Bc = Bs + cur * ROWS_B * BK;
 #pragma unroll
@@ -210,9 +218,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile has landed in LDS
-        __syncthreads();
     }
+    __syncthreads();   // all fragment reads done before the staging buffers become the epilogue's scratch
 
     // ---------------- epilogue through LDS: 64 output rows per pass
     constexpr int LDS_N = BN + 4;
@@ -309,12 +316,30 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IefGemmParam
     }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool CONV>
+static int launch_ns(const IefGemmParams& p, int tiles, int splits, int batch, hipStream_t st) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N, RP = NT / 8;
+    constexpr long long lds = 2ll * NS * (((BM + RP - 1) / RP) * RP + ((BN + RP - 1) / RP) * RP) * 64;
+    if constexpr (lds > 160 * 1024) {
+        return IEF_ESHAPE;   // this ring depth does not fit the 160 KiB LDS for this tile
+    } else {
+        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, WAVES_M, WAVES_N, NS, CONV>), dim3(tiles, splits, batch), dim3(NT), 0,
+                           st, p);
+        return IEF_OK;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
 static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int splits = p.splits > 1 ? p.splits : 1;
-    hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, WAVES_M, WAVES_N, CONV>), dim3(tiles, splits, batch),
-                       dim3(64 * WAVES_M * WAVES_N), 0, st, p);
+    int rc;
+    switch (p.stages) {
+        case 3: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 3, CONV>(p, tiles, splits, batch, st); break;
+        case 4: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 4, CONV>(p, tiles, splits, batch, st); break;
+        default: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 2, CONV>(p, tiles, splits, batch, st); break;
+    }
+    if (rc) return rc;
     IEF_LAUNCH_CHECK();
     if (splits > 1) {
         const long long total = (long long)p.M * (p.N / 8);
@@ -357,6 +382,7 @@ static int check_common(const IefGemmParams& p) {
     if (p.rowvec && p.rows_per_batch <= 0) return IEF_ESHAPE;
     if (p.splits > 1 && !p.ws) return IEF_EINVAL;
     if (p.splits > 64) return IEF_ESHAPE;
+    if (p.stages != 0 && (p.stages < 2 || p.stages > 4)) return IEF_ESHAPE;
     // 32-bit byte offsets inside each operand
     if ((long long)p.N * p.ldw * 2 >= (1ll << 32)) return IEF_ESHAPE;
     return IEF_OK;

@@ -30,7 +30,7 @@ class IefGemmParams(Structure):
         ("stride", c_int), ("ups", c_int), ("batch_images", c_int),
         ("rows_per_batch", c_int), ("out_scale", c_float), ("tile_hint", c_int),
         ("E1", c_void_p), ("E2", c_void_p), ("CE1", c_int), ("CE2", c_int),
-        ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p),
+        ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p), ("stages", c_int),
     ]
 
 
@@ -136,9 +136,16 @@ _TILES = {1: (128, 128, 2, 2), 2: (64, 128, 2, 2), 3: (64, 64, 2, 2), 4: (128, 6
           6: (128, 160, 2, 2), 7: (128, 160, 4, 2), 8: (256, 128, 4, 2), 9: (128, 128, 4, 2)}
 
 
-def _kname(tile, conv):
+def _kname(tile, conv, stages=2):
     bm, bn, wm, wn = _TILES[tile]
-    return f"igemm_f16_kernel<{bm}, {bn}, {wm}, {wn}, {'true' if conv else 'false'}>"
+    return f"igemm_f16_kernel<{bm}, {bn}, {wm}, {wn}, {stages or 2}, {'true' if conv else 'false'}>"
+
+
+def _ring_bytes(tile, stages):
+    bm, bn, wm, wn = _TILES[tile]
+    rp = 64 * wm * wn // 8
+    rows = -(-bm // rp) * rp + -(-bn // rp) * rp
+    return 2 * stages * rows * 64
 
 
 def profile_begin():
@@ -245,8 +252,11 @@ def heuristic_plan(M: int, N: int, K: int):
 
 
 def pick_plan(M: int, N: int, K: int, conv: bool = False):
+    """(tile, splits, stages)"""
     hit = _plan_table().get(f"{'conv' if conv else 'gemm'}|{M}|{N}|{K}")
-    return hit if hit is not None else heuristic_plan(M, N, K)
+    if hit is None:
+        hit = heuristic_plan(M, N, K)
+    return (hit[0], hit[1], hit[2] if len(hit) > 2 else 2)
 
 
 def candidate_plans(M: int, N: int, K: int):
@@ -259,21 +269,24 @@ def candidate_plans(M: int, N: int, K: int):
                 continue
             if blocks < 48 and s < 16:
                 continue
-            out.append((t, s))
+            for st in (2, 3, 4):
+                if _ring_bytes(t, st) <= 160 * 1024 and (st == 2 or nk // s >= st):
+                    out.append((t, s, st))
     return out
 
 
 def _time_graph(fn, iters=20):
+    """us per call of fn(i), i = 0..iters-1, replayed from one hipGraph"""
     st = torch.cuda.Stream()
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        fn()
+        fn(0)
     torch.cuda.current_stream().wait_stream(st)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(iters):
-            fn()
+        for i in range(iters):
+            fn(i)
     g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -284,18 +297,26 @@ def _time_graph(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def _cold_copies(w, iters=20, budget=320 << 20):
+    """enough clones of a weight tensor that consecutive launches never find it in the 256 MiB Infinity Cache —
+    inside the UNet every layer's weights stream from HBM once per step, which is what the tuner must see"""
+    k = max(1, min(iters, -(-budget // max(1, w.numel() * w.element_size()))))
+    return [w] + [w.clone() for _ in range(k - 1)]
+
+
 def autotune_plan(kind: str, M: int, N: int, K: int, run):
-    """time run(tile, splits) for every candidate plan (hipGraph of 20 launches each); remember the best"""
+    """time run(tile, splits, stages, i) for every candidate plan (hipGraph of 20 launches each, launch i using
+    the i-th cache-cold weight copy); remember the best"""
     best = None
-    for t, sp in candidate_plans(M, N, K):
+    for t, sp, st in candidate_plans(M, N, K):
         try:
-            us = _time_graph(lambda: run(t, sp))
+            us = _time_graph(lambda i: run(t, sp, st, i))
         except RuntimeError:
             continue
         if best is None or us < best[0]:
-            best = (us, t, sp)
+            best = (us, t, sp, st)
     if best is not None:
-        _plan_table()[f"{kind}|{M}|{N}|{K}"] = (best[1], best[2])
+        _plan_table()[f"{kind}|{M}|{N}|{K}"] = (best[1], best[2], best[3])
     return best
 
 
@@ -344,7 +365,8 @@ def _rows_ld(t, name):
 
 
 # ------------------------------------------------------------------------------- GEMM / conv
-def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0, splits=1):
+def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0, splits=1,
+         stages=2):
     """out[..., n] = (a[..., :] . w[n, :] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale
 
     a: fp16 [..., K] (last dim contiguous, uniform row stride); w: fp16 [N, K]; bias/rowvec fp32.
@@ -375,23 +397,25 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     p.out_scale = out_scale
     if tile_hint == 0:
         if AUTOTUNE and f"gemm|{M}|{N}|{K}" not in _plan_table() and not _capturing() and _prof is None:
-            autotune_plan("gemm", M, N, K, lambda t, sp: gemm(a, w, bias=bias, residual=residual, rowvec=rowvec,
-                                                               rows_per_batch=rows_per_batch, out=out,
-                                                               out_scale=out_scale, tile_hint=t, splits=sp))
-        p.tile_hint, p.splits = pick_plan(M, N, K)
+            wc = _cold_copies(w)
+            autotune_plan("gemm", M, N, K, lambda t, sp, st, i: gemm(a, wc[i % len(wc)], bias=bias, residual=residual,
+                                                                      rowvec=rowvec, rows_per_batch=rows_per_batch, out=out,
+                                                                      out_scale=out_scale, tile_hint=t, splits=sp, stages=st))
+            del wc
+        p.tile_hint, p.splits, p.stages = pick_plan(M, N, K)
     else:
-        p.tile_hint, p.splits = tile_hint, max(1, splits)
+        p.tile_hint, p.splits, p.stages = tile_hint, max(1, splits), stages
     if p.splits > 1:
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)
         p.ws = ws.data_ptr()
     p.flags, p.zeros = 1, _zeros(a.device)
-    with _Timed(_kname(p.tile_hint, False), 2.0 * M * N * K):
+    with _Timed(_kname(p.tile_hint, False, p.stages), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     return out
 
 
 def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0,
-            extra=None, splits=1):
+            extra=None, splits=1, stages=2):
     """3x3 / pad 1 convolution over NHWC fp16.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat),
     w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather.
     extra=(e1, e2|None): fused 1x1 convolution over more NHWC sources sampled at the output pixel; w is
@@ -444,18 +468,21 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
     if tile_hint == 0:
         if AUTOTUNE and f"conv|{M}|{Cout}|{K}" not in _plan_table() and not _capturing() and _prof is None:
-            autotune_plan("conv", M, Cout, K, lambda t, sp: conv3x3(x, w, bias, x2=x2, stride=stride, upsample=upsample,
-                                                                     rowvec=rowvec, residual=residual, out=out,
-                                                                     tile_hint=t, splits=sp, extra=extra))
-        p.tile_hint, p.splits = pick_plan(M, Cout, K, conv=True)
+            wc = _cold_copies(w)
+            autotune_plan("conv", M, Cout, K, lambda t, sp, st, i: conv3x3(x, wc[i % len(wc)], bias, x2=x2, stride=stride,
+                                                                            upsample=upsample, rowvec=rowvec,
+                                                                            residual=residual, out=out, tile_hint=t,
+                                                                            splits=sp, extra=extra, stages=st))
+            del wc
+        p.tile_hint, p.splits, p.stages = pick_plan(M, Cout, K, conv=True)
     else:
-        p.tile_hint, p.splits = tile_hint, max(1, splits)
+        p.tile_hint, p.splits, p.stages = tile_hint, max(1, splits), stages
     if p.splits > 1:
         ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)
         p.ws = ws.data_ptr()
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
-    with _Timed(_kname(p.tile_hint, True), 2.0 * M * Cout * K):
+    with _Timed(_kname(p.tile_hint, True, p.stages), 2.0 * M * Cout * K):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
     return out
 

@@ -73,6 +73,7 @@ typedef struct IefGemmParams {
      * padded / out-of-range chunks). */
     int flags;
     const ief_half* zeros;
+    int stages;               /* depth of the LDS operand ring: 0/2 (double buffer), 3 or 4 K tiles in flight */
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);

@@ -59,22 +59,12 @@ CONVS = [  # (B, H, W, C1, C2, Cout, stride, ups, count)
 ATTN = [(4, 8, 4096, 40, 5), (4, 8, 1024, 80, 5), (4, 8, 256, 160, 5), (4, 8, 64, 160, 1)]
 
 
-SWEEP = [(t, s) for t in (1, 2, 3, 4, 5, 6, 7, 8, 9) for s in (1, 2, 4, 8, 16)]
-
-
 def sweep(fn_of_plan, M, N, K, iters):
-    """best (us, tile, splits) over the tile family x split-K factors that make sense for the shape"""
+    """(us, tile, splits, stages) sorted, over the tile family x split-K x LDS ring depth"""
     res = []
-    nk = -(-K // 64)
-    for t, s in SWEEP:
-        bm, bn = hip._TILES[t][:2]
-        blocks = -(-M // bm) * -(-N // bn) * s
-        if s > 1 and (nk // s < 4 or blocks > 2048):
-            continue
-        if blocks < 64:
-            continue
+    for t, s, st in hip.candidate_plans(M, N, K):
         try:
-            res.append((timeit(lambda: fn_of_plan(t, s), iters), t, s))
+            res.append((timeit(lambda: fn_of_plan(t, s, st), iters), t, s, st))
         except RuntimeError:
             pass
     res.sort()
@@ -91,9 +81,9 @@ def run_gemm(iters, do_sweep=False):
         tot += us * n
         line = f"{us:8.1f} {2.0 * M * N * K / us / 1e6:7.1f} {us * n:8.1f}  ({M},{N},{K}) {hip.pick_plan(M, N, K)}"
         if do_sweep:
-            r = sweep(lambda t, s: hip.gemm(a, w, bias=bias, residual=res, out=out, tile_hint=t, splits=s), M, N, K, iters)
+            r = sweep(lambda t, s, st: hip.gemm(a, w, bias=bias, residual=res, out=out, tile_hint=t, splits=s, stages=st), M, N, K, iters)
             tot_best += r[0][0] * n
-            line += "  best: " + " ".join(f"{u:.1f}us@t{t}s{s}" for u, t, s in r[:4])
+            line += "  best: " + " ".join(f"{u:.1f}us@t{t}s{s}r{st}" for u, t, s, st in r[:4])
         print(line, flush=True)
     print(f"gemm total per step: {tot / 1e3:.3f} ms" + (f"  (best-of-sweep {tot_best / 1e3:.3f} ms)" if do_sweep else ""))
 
@@ -113,9 +103,9 @@ def run_conv(iters, do_sweep=False):
         tot += us * n
         line = f"{us:8.1f} {2.0 * M * Cout * K / us / 1e6:7.1f} {us * n:8.1f}  {(B, H, W, C1, C2, Cout, s, ups)} {hip.pick_plan(M, Cout, K, conv=True)}"
         if do_sweep:
-            r = sweep(lambda t, sp: hip.conv3x3(x, w, bias, x2=x2, stride=s, upsample=ups, tile_hint=t, splits=sp), M, Cout, K, iters)
+            r = sweep(lambda t, sp, st: hip.conv3x3(x, w, bias, x2=x2, stride=s, upsample=ups, tile_hint=t, splits=sp, stages=st), M, Cout, K, iters)
             tot_best += r[0][0] * n
-            line += "  best: " + " ".join(f"{u:.1f}us@t{t}s{sp}" for u, t, sp in r[:4])
+            line += "  best: " + " ".join(f"{u:.1f}us@t{t}s{sp}r{st}" for u, t, sp, st in r[:4])
         print(line, flush=True)
     print(f"conv total per step: {tot / 1e3:.3f} ms" + (f"  (best-of-sweep {tot_best / 1e3:.3f} ms)" if do_sweep else ""))
 

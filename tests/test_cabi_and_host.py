@@ -50,8 +50,8 @@ def test_tile_plans():
     t, s = hip.heuristic_plan(256, 1280, 11520)                 # 8x8 level: split-K
     assert s > 1 and 11520 // 64 // s >= 6
     assert hip.heuristic_plan(4, 1280, 320)[1] == 1             # time-embedding GEMM
-    for (t, s) in hip.candidate_plans(1024, 1280, 11520):
-        assert t in hip._TILES and 1 <= s <= 16
+    for (t, s, st) in hip.candidate_plans(1024, 1280, 11520):
+        assert t in hip._TILES and 1 <= s <= 16 and 2 <= st <= 4 and hip._ring_bytes(t, st) <= 160 * 1024
 
 
 def test_param_inventory_matches_sd15():

@@ -349,6 +349,29 @@ def test_gemm_splitk(M, N, K, hint, splits):
     close(out, a.float() @ w.float().t() + bias + res.float(), 2e-3, 1e-3)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("stages", [2, 3, 4])
+def test_gemm_every_tile_and_ring_depth(tile, stages):
+    """every member of the tile family x LDS ring depth, K tails (72 = 64 + 8) and short K (fewer tiles than stages)"""
+    if hip._ring_bytes(tile, stages) > 160 * 1024:
+        pytest.skip("ring does not fit LDS")
+    for (M, N, K) in [(300, 320, 72), (515, 480, 640)]:
+        a, w = h16(M, K, seed=1), h16(N, K, seed=2, scale=K ** -0.5)
+        bias = f32(N, seed=3, scale=0.1)
+        out = hip.gemm(dev(a), dev(w), bias=dev(bias), tile_hint=tile, splits=1, stages=stages)
+        close(out, a.float() @ w.float().t() + bias, 2e-3, 1e-3)
+
+
+@pytest.mark.parametrize("tile,stages,splits", [(6, 3, 1), (7, 4, 2), (3, 4, 4), (1, 3, 2), (8, 3, 1)])
+def test_conv_ring_depths(tile, stages, splits):
+    B, H, W, C1, C2, Cout = 2, 16, 16, 128, 64, 320
+    x, x2 = h16(B, H, W, C1, seed=1), h16(B, H, W, C2, seed=2)
+    w = h16(Cout, 3, 3, C1 + C2, seed=3, scale=(9 * (C1 + C2)) ** -0.5)
+    bias = f32(Cout, seed=4, scale=0.1)
+    out = hip.conv3x3(dev(x), dev(w), dev(bias), x2=dev(x2), tile_hint=tile, splits=splits, stages=stages)
+    close(out, _conv_ref(x, w, bias, x2=x2), 2e-3, 1e-3)
+
+
 def test_conv3x3_splitk_auto_and_shortcut():
     # 8x8 level of the UNet: M = 256, K = 9*2560 + shortcut 2560 -> the auto plan picks split-K
     B, H, W, C1, C2, Cout = 4, 8, 8, 1280, 1280, 1280
