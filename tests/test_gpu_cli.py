@@ -1,0 +1,65 @@
+"""End-to-end CLI runs on the GPU: the mirrored `edit_syn.py`, `edit_real.py --inversion_type ddim` and the
+sharded `test.py` driver (TINY shape family so they take seconds), plus bench.py under torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P2P = os.path.join(ROOT, "image-editing-framework_amd", "p2p")
+
+
+def run(args, cwd, timeout=600, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable] + args, cwd=cwd, capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_edit_syn_cli(tmp_path):
+    run([os.path.join(P2P, "edit_syn.py"), "--sd_version", "tiny", "--seed", "8888"], cwd=str(tmp_path))
+    src = np.array(Image.open(tmp_path / "exp" / "source.png"))
+    edit = np.array(Image.open(tmp_path / "exp" / "edit.png"))
+    assert src.shape == edit.shape == (128, 128, 3) and src.dtype == np.uint8
+    assert src.std() > 1 and (src.astype(int) - edit.astype(int)).__abs__().max() > 0
+
+
+def test_edit_real_cli_ddim(tmp_path):
+    rng = np.random.RandomState(0)
+    img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "test.jpg")
+    run([os.path.join(P2P, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", "ddim", "--source_image",
+         str(tmp_path / "test.jpg")], cwd=str(tmp_path))
+    for name in ("source.png", "inversion.png", "edit.png"):
+        assert (tmp_path / "exp" / name).exists()
+    # default inversion type is the reference's "null-text": must fail loudly, not silently fall back
+    r = subprocess.run([sys.executable, os.path.join(P2P, "edit_real.py"), "--sd_version", "tiny", "--source_image",
+                        str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "NotImplementedError" in r.stderr
+
+
+def test_pie_driver_synthetic(tmp_path):
+    out = run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--exp_path",
+               str(tmp_path / "test_exp")], cwd=str(tmp_path))
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["images"] == 3 and rec["images_per_sec"] > 0
+    done = [d for d in os.listdir(tmp_path / "test_exp") if d.startswith("syn_")]
+    assert len(done) == 3
+    for d in done:
+        assert sorted(os.listdir(tmp_path / "test_exp" / d)) == ["edit.png", "inversion.png", "source.png"]
+
+
+def test_bench_under_torchrun_one_rank(tmp_path):
+    """the exact launch line the driver uses for N > 1, with N = 1 (one GPU on this box)"""
+    out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+               "--config", "small", "--no-cpu-baseline"], cwd=ROOT, timeout=900)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["value"] > 0 and "roofline" in rec
