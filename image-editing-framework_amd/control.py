@@ -31,6 +31,14 @@ from . import hip
 XL = 96  # padded key count of the cross-attention kernel
 
 
+def _step_hook(c):
+    # P2P controllers call it between_steps (p2p/model/attention_base.py:27), MasaCtrl editors after_step
+    # (masactrl/model/attention_base.py:21)
+    fn = getattr(c, "between_steps", None) or getattr(c, "after_step", None)
+    if fn is not None:
+        fn()
+
+
 def advance_controller(c):
     """`attention_base.py:23-27` for any object following the controller protocol."""
     c.cur_att_layer += 1
@@ -38,7 +46,7 @@ def advance_controller(c):
     if c.cur_att_layer == c.num_att_layers + uncond:
         c.cur_att_layer = 0
         c.cur_step += 1
-        c.between_steps()
+        _step_hook(c)
 
 
 class ControlPlan:
@@ -46,7 +54,7 @@ class ControlPlan:
 
     def __init__(self, controller, kind: str, device, num_prompts: int = 1, num_steps: int = 0,
                  mt: Optional[torch.Tensor] = None, coef_table: Optional[torch.Tensor] = None,
-                 self_window=(0, 0), self_max_tokens: int = 256):
+                 self_window=(0, 0), self_max_tokens: int = 256, masa_steps=(), masa_layers=()):
         self.controller = controller
         self.kind = kind
         self.device = torch.device(device)
@@ -80,12 +88,35 @@ class ControlPlan:
             tab[lo:hi] = repl
             self.self_table = tab.contiguous().to(dev)
             self.self_cur = ident.clone().to(dev)
+        # MasaCtrl mutual self-attention (/root/reference/masactrl/model/attention_control.py:52-66): in the chosen
+        # transformer layers and steps every row of the uncond half attends to K,V of that half's FIRST row (the
+        # source image), likewise for the cond half.  The batch size is not known at registration: tables per B.
+        self.masa_steps = set(int(s) for s in masa_steps)
+        self.masa_layers = set(int(l) for l in masa_layers)
+        self._masa = {}
         self._step_synced = -1
 
+    def prepare(self, B: int):
+        """allocate per-batch device tables OUTSIDE any graph capture"""
+        if self.kind == "masactrl" and B not in self._masa:
+            n = (max(self.masa_steps) + 2) if self.masa_steps else 1
+            self.num_steps = max(self.num_steps, n - 1)
+            ident = torch.arange(B, dtype=torch.int32)
+            src = ident.clone()
+            half = B // 2
+            if half > 0:
+                src[:half] = 0
+                src[half:] = half
+            tab = ident.repeat(n, 1)
+            for st in self.masa_steps:
+                tab[st] = src
+            self._masa[B] = (tab.contiguous().to(self.device), ident.clone().to(self.device))
     # ------------------------------------------------------------------ per-forward protocol
     def applies(self, B: int) -> bool:
         if self.kind == "empty" or self.muted:
             return False
+        if self.kind == "masactrl":
+            return True
         if B != self.batch:
             raise RuntimeError(
                 f"controller was built for {self.num_prompts} prompts (UNet batch {self.batch}) but the UNet was "
@@ -98,15 +129,26 @@ class ControlPlan:
         if not self.captured:
             # keep the device counter equal to the controller's (covers reset() / manual edits)
             cs = int(self.controller.cur_step)
-            if cs > self.num_steps:
+            if cs > self.num_steps and self.kind == "p2p":
                 raise IndexError(f"cur_step {cs} exceeds the controller's {self.num_steps}-step tables")
             self.step.fill_(cs)
         if self.kind == "p2p":
             hip.select_step(self.coef_table, self.coef_cur, self.step)
             hip.select_step(self.self_table, self.self_cur, self.step)
+        elif self.kind == "masactrl":
+            if B not in self._masa:
+                if self.captured:
+                    raise RuntimeError("ControlPlan.prepare(B) must run before graph capture")
+                self.prepare(B)
+            tab, cur = self._masa[B]
+            if not self.captured and int(self.controller.cur_step) >= tab.shape[0]:
+                self.step.fill_(tab.shape[0] - 1)   # past the last controlled step: identity row
+            hip.select_step(tab, cur, self.step)
 
     def end_forward(self, B: int):
-        if self.kind != "empty" and not self.muted and B == self.batch:
+        if self.kind == "masactrl" and not self.muted:
+            hip.advance_step(self.step)
+        elif self.kind != "empty" and not self.muted and B == self.batch:
             hip.advance_step(self.step)
 
     def layer_done(self, attn):
@@ -122,12 +164,15 @@ class ControlPlan:
         c = self.controller
         if c is not None:
             c.cur_step += 1
-            c.between_steps()
+            _step_hook(c)
 
     # ------------------------------------------------------------------ what the kernels read
     def self_sources(self, B: int, N: int, attn):
         if self.kind == "p2p" and self.applies(B) and N <= self.self_max_tokens:
             return self.self_cur, self.self_cur, None
+        if self.kind == "masactrl" and not self.muted and (attn._exec_index // 2) in self.masa_layers:
+            cur = self._masa[B][1]
+            return None, cur, cur
         return None, None, None
 
     def cross_edit(self, B: int, attn):

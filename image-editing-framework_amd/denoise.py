@@ -94,6 +94,7 @@ class FusedDenoiser:
         # allocator pools without moving any counter), on a side stream as capture requires
         saved = self.lat.clone()
         if plan is not None:
+            plan.prepare(self.B)
             plan.muted = True
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())

@@ -1,0 +1,63 @@
+"""`MasaCtrl` sampler (`/root/reference/masactrl/model/sd_utils.py:7-124`): same call signature; the DDIM loop
+(:94-115) runs as a captured hipGraph with the editor lowered to a device plan."""
+import numpy as np
+import torch
+
+from ...denoise import FusedDenoiser
+
+
+class MasaCtrl:
+    def __init__(self, pipeline, num_inference_steps) -> None:
+        self.model = pipeline
+        self.model.scheduler.set_timesteps(num_inference_steps)
+
+    @torch.no_grad()
+    def latent2image(self, latents, return_type="np"):
+        latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
+        image = self.model.vae.decode(latents)["sample"]
+        image = (image / 2 + 0.5).clamp(0, 1)
+        if return_type == "np":
+            image = image.cpu().permute(0, 2, 3, 1).numpy()
+            image = (image * 255).astype(np.uint8)
+        return image
+
+    @torch.no_grad()
+    def __call__(self, prompt, batch_size=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
+                 latents=None, unconditioning=None, neg_prompt=None, ref_intermediate_latents=None,
+                 return_intermediates=False, return_latents=False, **kwds):
+        model = self.model
+        dev = model.unet.device
+        if isinstance(prompt, list):
+            batch_size = len(prompt)
+        elif isinstance(prompt, str):
+            prompt = [prompt] * batch_size
+        if ref_intermediate_latents is not None or kwds.get("dir"):
+            raise NotImplementedError("ref_intermediate_latents / dir are not used by the reference CLIs and not built")
+        tok = model.tokenizer
+        text_input = tok(prompt, padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
+        text_embeddings = model.text_encoder(text_input.input_ids.to(dev))[0]
+        C = model.unet.config.in_channels
+        shape = (batch_size, C, height // 8, width // 8)
+        if latents is None:
+            latents = torch.randn(shape, dtype=torch.float32).to(dev)     # CPU generator, see p2p/model/sd_utils.py
+        else:
+            assert tuple(latents.shape) == shape, \
+                f"The shape of input latent tensor {latents.shape} should equal to predefined one."
+        init_latent = latents.clone()
+        uncond_list = unconditioning if isinstance(unconditioning, list) else None
+        if guidance_scale > 1.0:
+            uc = tok([neg_prompt or ""] * batch_size, padding="max_length", max_length=tok.model_max_length,
+                     return_tensors="pt")
+            context = torch.cat([model.text_encoder(uc.input_ids.to(dev))[0], text_embeddings])
+            g = guidance_scale
+        else:
+            context, g = text_embeddings, None
+        model.scheduler.set_timesteps(num_inference_steps)
+        loop = FusedDenoiser(model, context, batch_size, (height // 8, width // 8), g, uncond_list=uncond_list)
+        try:
+            latents = loop.run(latents)
+        finally:
+            loop.release()
+        if return_latents:
+            return latents, init_latent
+        return self.latent2image(latents, return_type="np"), init_latent

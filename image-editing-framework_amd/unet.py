@@ -466,6 +466,13 @@ class UNet2DConditionModel(nn.Module):
         # all 22 time_emb_proj linears as ONE [sum Cout, temb] GEMM
         self._temb_w = torch.cat([r.time_emb_proj.weight for r in self._resnets], 0).contiguous()
         self._temb_b = torch.cat([r.time_emb_proj.bias for r in self._resnets], 0).contiguous()
+        # execution-order index of every Attention module (down, mid, up; attn1 then attn2 per transformer):
+        # controllers that count calls (`cur_att_layer`) see the layers in THIS order
+        order = [m for blk in self.down_blocks for m in blk.modules() if m.__class__.__name__ == "Attention"]
+        order += [m for m in self.mid_block.modules() if m.__class__.__name__ == "Attention"]
+        order += [m for blk in self.up_blocks for m in blk.modules() if m.__class__.__name__ == "Attention"]
+        for i, m in enumerate(order):
+            m._exec_index = i
         self._temb_table = None   # per-step rows, see precompute_time_table
         self._temb_static = None  # [1, width] fp32 buffer a captured graph reads
         self._plan = None

@@ -199,9 +199,34 @@ def g6_g8():
     print("ddim_nti.npz", len(out), "arrays")
 
 
+
+
+def g7_masactrl():
+    """G7: MasaCtrl `AttentionBase` (importable; `attention_control.py` needs torchvision and is not)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_masa_base", "/root/reference/masactrl/model/attention_base.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    heads, b, n, d = 4, 2, 16, 8
+    q, k, v = (torch.randn(b * heads, n, d, generator=g) for _ in range(3))
+    sim = torch.bmm(q, k.transpose(1, 2)) * d ** -0.5
+    attn = sim.softmax(-1)
+    e = mod.AttentionBase()
+    e.num_att_layers = 3
+    outs = [e(q, k, v, sim, attn, False, "down", heads, scale=d ** -0.5) for _ in range(4)]
+    out["q"], out["k"], out["v"] = q.numpy(), k.numpy(), v.numpy()
+    out["base_out"] = outs[0].numpy()
+    out["counters"] = np.array([e.cur_step, e.cur_att_layer])
+    np.savez_compressed(os.path.join(HERE, "masactrl.npz"), **out)
+    print("masactrl.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     tok = WordPieceTokenizer()
     g1_g2(tok)
     g3_g4_g5(tok)
     g6_g8()
+    g7_masactrl()

@@ -31,6 +31,14 @@ def test_edit_syn_cli(tmp_path):
     assert src.std() > 1 and (src.astype(int) - edit.astype(int)).__abs__().max() > 0
 
 
+def test_masactrl_edit_syn_cli(tmp_path):
+    masa = os.path.join(ROOT, "image-editing-framework_amd", "masactrl")
+    run([os.path.join(masa, "edit_syn.py"), "--sd_version", "tiny"], cwd=str(tmp_path))
+    src = np.array(Image.open(tmp_path / "exp" / "source.png"))
+    edit = np.array(Image.open(tmp_path / "exp" / "edit.png"))
+    assert src.shape == edit.shape == (128, 128, 3) and (src.astype(int) - edit.astype(int)).__abs__().max() > 0
+
+
 def test_edit_real_cli_ddim(tmp_path):
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)

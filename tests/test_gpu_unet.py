@@ -189,3 +189,59 @@ def test_sd15_full_size_forward_matches_oracle():
     e = rel_err(eps, ref)
     print(f"sd15 B=1 512^2: rel err {e:.3e}")
     assert e < 2e-2
+
+
+# ----------------------------------------------------------------------------- MasaCtrl (mutual self-attention)
+def test_masactrl_forward_and_loop_vs_oracle(tiny):
+    from ief_amd.masactrl.model.attention_control import MutualSelfAttentionControl
+    from ief_amd.masactrl.model.register import regiter_attention_editor_diffusers, unregister_attention_control as unreg
+    from ief_amd.masactrl.model.sd_utils import MasaCtrl
+    from oracle.masactrl_ref import MasaCtrlRef
+    pipe = tiny
+    cfg = pipe.cfg
+    nlayers = unet_ref.count_attention_layers(cfg)
+    x1, ctx = _inputs(cfg, 4, seed=9)
+    x = torch.cat([x1[:1], 0.6 * x1[:1] + 0.8 * x1[1:2]] * 2)
+    for step, active in ((2, False), (6, True)):
+        c = MutualSelfAttentionControl(4, 10, total_steps=50)
+        regiter_attention_editor_diffusers(pipe, c)
+        assert c.num_att_layers == nlayers
+        c.cur_step = step
+        got = pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
+        assert c.cur_step == step + 1 and c.cur_att_layer == 0
+        unreg(pipe, c)
+        r = MasaCtrlRef(step_idx=list(range(4, 50)), layer_idx=list(range(10, 16)), num_att_layers=nlayers, cur_step=step)
+        ref = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx, qkv_hook=r)
+        plain = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx)
+        e, effect = rel_err(got, ref), rel_err(plain, ref)
+        print(f"masactrl step {step}: fused-vs-oracle {e:.3e}, size of the control {effect:.3e}")
+        assert e < 2e-2
+        assert (effect > 10 * e) if active else (effect == 0.0)
+    # 6-step sampler (graph loop) from a shared x_T: controlled steps 4, 5
+    editor = MasaCtrl(pipe, 50)
+    c = MutualSelfAttentionControl(4, 10, total_steps=50)
+    regiter_attention_editor_diffusers(pipe, c)
+    g = torch.Generator().manual_seed(8888)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    from ief_amd.denoise import FusedDenoiser
+    pipe.scheduler.set_timesteps(50)
+    context = _context(pipe, PROMPTS)
+    loop = FusedDenoiser(pipe, context, 2, (cfg.sample_size, cfg.sample_size), 7.5)
+    try:
+        lat = loop.run(x_T.to(DEV), num_steps=6).cpu()
+    finally:
+        loop.release()
+    assert c.cur_step == 6
+    unreg(pipe, c)
+    sched = p2p_ref.DDIMRef(50)
+    r = MasaCtrlRef(step_idx=list(range(4, 50)), layer_idx=list(range(10, 16)), num_att_layers=nlayers)
+    lat_ref = x_T.expand(2, -1, -1, -1).clone()
+    cpu_ctx = context.float().cpu()
+    for t in sched.timesteps[:6]:
+        with torch.no_grad():
+            eps = unet_ref.unet_forward(pipe._state_dict, cfg, torch.cat([lat_ref] * 2), t, cpu_ctx, qkv_hook=r)
+        eu, ec = eps.chunk(2)
+        lat_ref = sched.step(eu + 7.5 * (ec - eu), int(t), lat_ref)
+    e = rel_err(lat, lat_ref)
+    print(f"masactrl 6-step sampler: rel err {e:.3e}")
+    assert e < 5e-2
