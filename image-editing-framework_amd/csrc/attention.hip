@@ -127,29 +127,29 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
 
     const half_t* Kb = p.K + (long long)ks * p.L * p.ldk + head * D;
     const half_t* Vb = p.V + (long long)vs * p.L * p.ldv + head * D;
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    // staging map of this thread (fixed for the whole kernel)
-    int st_row[NCH], st_k[NCH], st_v[NCH];
-    long long st_gk[NCH], st_gv[NCH];
+    // staging map of this thread (fixed for the whole kernel).  Loads are unconditional: a row past the last key is
+    // clamped to the last key (its scores are masked to -inf, so neither its K nor its V reaches the output), which
+    // keeps the tile loop free of selects; the row pointers advance by one scalar per tile.
+    int st_k[NCH], st_v[NCH];
+    int st_row[NCH], st_ch[NCH];
     bool st_ok[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + 256 * i;
         const int row = c / C::CPR, ch = c - row * C::CPR;
         st_ok[i] = c < 64 * C::CPR;
-        st_row[i] = row;
+        st_row[i] = st_ok[i] ? row : 0;
+        st_ch[i] = st_ok[i] ? ch * 8 : 0;
         st_k[i] = row * C::KS + ch * 8;
         st_v[i] = row * VRS + ch * 8;
-        st_gk[i] = (long long)row * p.ldk + ch * 8;
-        st_gv[i] = (long long)row * p.ldv + ch * 8;
     }
     half8 kreg[NCH], vreg[NCH];
     auto load_tile = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const bool ok = st_ok[i] && kv0 + st_row[i] < p.L;
-            kreg[i] = ok ? *(const half8*)(Kb + (long long)kv0 * p.ldk + st_gk[i]) : zero8;
-            vreg[i] = ok ? *(const half8*)(Vb + (long long)kv0 * p.ldv + st_gv[i]) : zero8;
+            const int row = min(kv0 + st_row[i], p.L - 1);
+            kreg[i] = *(const half8*)(Kb + (long long)row * p.ldk + st_ch[i]);
+            vreg[i] = *(const half8*)(Vb + (long long)row * p.ldv + st_ch[i]);
         }
     };
     auto store_tile = [&](int buf) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
         }
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+        for (int i = 1; i < 16; ++i) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0[i]), s1[i]);   // one v_max3 per pair
         mx = fmaxf(mx, __shfl_xor(mx, 32));          // this row's maximum, relative to m_run
         if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {   // wave-uniform; rare after the first tile
             // move the reference maximum, rescale what was accumulated under the old one, and REDO this tile's
