@@ -240,6 +240,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
         }
         __syncthreads();
         constexpr int PROWS = BM < 64 ? BM : 64;
+        if (p.flags & 2) {
+            // GEGLU epilogue (FeedForward.net[0]): the weight rows were interleaved in groups of 8 at pack time, so
+            // column chunks alternate [8 hidden | 8 gate]; out[m][j] = hidden_j * gelu(gate_j), Out has N/2 columns.
+            for (int c = tid; c < PROWS * (CH / 2); c += NT) {
+                const int row = c / (CH / 2), pc = c - row * (CH / 2);
+                const int m = m0 + pass * 64 + row, n = n0 + pc * 16;
+                if (m < p.M && n < p.N) {
+                    const float* sp = stage + row * LDS_N + pc * 16;
+                    float hv[8], gv[8];
+#pragma unroll
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const f32x4 a = *(const f32x4*)(sp + 4 * q4), g = *(const f32x4*)(sp + 8 + 4 * q4);
+                        const f32x4 ba = *(const f32x4*)(p.bias + n + 4 * q4), bg = *(const f32x4*)(p.bias + n + 8 + 4 * q4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hv[4 * q4 + e] = a[e] + ba[e]; gv[4 * q4 + e] = g[e] + bg[e]; }
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_f(gv[e]));
+                    *(half8*)(Out + (long long)m * p.ldo + (n >> 1)) = o;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         for (int c = tid; c < PROWS * CH; c += NT) {
             const int row = c / CH, nc = c - row * CH;
             const int m = m0 + pass * 64 + row, n = n0 + nc * 8;
@@ -383,6 +408,9 @@ static int check_common(const IefGemmParams& p) {
     if (p.splits > 1 && !p.ws) return IEF_EINVAL;
     if (p.splits > 64) return IEF_ESHAPE;
     if (p.stages != 0 && (p.stages < 2 || p.stages > 4)) return IEF_ESHAPE;
+    if (p.flags & 2) {  // fused GEGLU epilogue
+        if (!p.bias || p.rowvec || p.residual || p.splits > 1 || (p.N & 15)) return IEF_EINVAL;
+    }
     // 32-bit byte offsets inside each operand
     if ((long long)p.N * p.ldw * 2 >= (1ll << 32)) return IEF_ESHAPE;
     return IEF_OK;

@@ -366,7 +366,7 @@ def _rows_ld(t, name):
 
 # ------------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0, splits=1,
-         stages=2):
+         stages=2, geglu=False):
     """out[..., n] = (a[..., :] . w[n, :] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale
 
     a: fp16 [..., K] (last dim contiguous, uniform row stride); w: fp16 [N, K]; bias/rowvec fp32.
@@ -377,10 +377,11 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"gemm: K mismatch {w.shape[1]} vs {K}")
+    No_expect = N // 2 if geglu else N
     if out is None:
-        out = torch.empty(*a.shape[:-1], N, dtype=torch.float16, device=a.device)
+        out = torch.empty(*a.shape[:-1], No_expect, dtype=torch.float16, device=a.device)
     Mo, No, ldo = _rows_ld(out, "out")
-    if (Mo, No) != (M, N):
+    if (Mo, No) != (M, No_expect):
         raise ValueError("gemm: out shape mismatch")
     p = IefGemmParams()
     p.A, p.W, p.Out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -400,15 +401,18 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
             wc = _cold_copies(w)
             autotune_plan("gemm", M, N, K, lambda t, sp, st, i: gemm(a, wc[i % len(wc)], bias=bias, residual=residual,
                                                                       rowvec=rowvec, rows_per_batch=rows_per_batch, out=out,
-                                                                      out_scale=out_scale, tile_hint=t, splits=sp, stages=st))
+                                                                      out_scale=out_scale, tile_hint=t, splits=sp, stages=st,
+                                                                      geglu=geglu))
             del wc
         p.tile_hint, p.splits, p.stages = pick_plan(M, N, K)
+        if geglu and p.splits > 1:
+            p.tile_hint, p.splits, p.stages = heuristic_plan(M, N, K)[0], 1, 2
     else:
         p.tile_hint, p.splits, p.stages = tile_hint, max(1, splits), stages
     if p.splits > 1:
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)
         p.ws = ws.data_ptr()
-    p.flags, p.zeros = 1, _zeros(a.device)
+    p.flags, p.zeros = (3 if geglu else 1), _zeros(a.device)
     with _Timed(_kname(p.tile_hint, False, p.stages), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     return out

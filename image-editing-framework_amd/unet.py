@@ -221,12 +221,21 @@ class Attention(nn.Module):
 
 
 class GEGLU(nn.Module):
+    """Linear(C -> 8C) + hidden * gelu(gate) in ONE GEMM: the [hidden | gate] halves of the weight are interleaved
+    in groups of 8 rows at pack time so the GEMM epilogue sees a hidden chunk next to its gate chunk and writes
+    the 4C-wide product directly (the 8C-wide intermediate never reaches HBM)."""
+
     def __init__(self, sd, prefix, dev):
         super().__init__()
-        self.proj = Linear(_f16(sd[prefix + ".proj.weight"], dev), _f32(sd[prefix + ".proj.bias"], dev))
+        w, b = sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"]
+        half = w.shape[0] // 2
+        il = lambda t: torch.stack([t[:half].reshape(half // 8, 8, *t.shape[1:]),
+                                    t[half:].reshape(half // 8, 8, *t.shape[1:])], 1).reshape(t.shape)
+        self.proj = Linear(_f16(il(w), dev), _f32(il(b), dev))   # NOTE: rows interleaved [8 hidden | 8 gate] ...
+        self.proj.interleaved = True
 
     def forward(self, x):
-        return hip.geglu(self.proj(x))
+        return hip.gemm(x, self.proj.weight, bias=self.proj.bias, geglu=True)
 
 
 class FeedForward(nn.Module):

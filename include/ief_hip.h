@@ -68,9 +68,9 @@ typedef struct IefGemmParams {
      * ws must hold splits*M*N floats.  Used where M*N alone yields too few tiles for 256 CUs. */
     int splits;
     float* ws;
-    /* staging: flags bit 0 = stage operand tiles with direct global->LDS loads (global_load_lds, 16 B per
-     * lane) instead of through registers; `zeros` must then point at >= 16 bytes of device zeros (source of
-     * padded / out-of-range chunks). */
+    /* flags bit 1 (value 2): fused GEGLU epilogue — W rows interleaved in groups of 8 ([8 hidden | 8 gate] ...),
+     * Out[m][j] = (h_j + bias) * gelu(g_j + bias), Out has N/2 columns (FeedForward.net[0] of diffusers' GEGLU);
+     * `zeros` must point at >= 16 bytes of device zeros (source of padded / out-of-range chunks). */
     int flags;
     const ief_half* zeros;
     int stages;               /* depth of the LDS operand ring: 0/2 (double buffer), 3 or 4 K tiles in flight */

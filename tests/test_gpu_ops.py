@@ -164,6 +164,19 @@ def test_geglu():
     close(out, hdn * F.gelu(gate), 2e-3, 1e-3)
 
 
+@pytest.mark.parametrize("M,C,tile", [(1024, 320, 0), (300, 64, 5), (4096, 640, 7), (256, 1280, 3)])
+def test_gemm_fused_geglu(M, C, tile):
+    x = h16(M, C, seed=1)
+    w = h16(8 * C, C, seed=2, scale=C ** -0.5)          # diffusers layout: rows [hidden (4C) | gate (4C)]
+    b = f32(8 * C, seed=3, scale=0.1)
+    half = 4 * C
+    il = lambda t: torch.stack([t[:half].reshape(half // 8, 8, *t.shape[1:]), t[half:].reshape(half // 8, 8, *t.shape[1:])],
+                               1).reshape(t.shape)
+    out = hip.gemm(dev(x), dev(il(w).contiguous()), bias=dev(il(b).contiguous()), geglu=True, tile_hint=tile)
+    y = x.float() @ w.float().t() + b
+    close(out, y[:, :half] * F.gelu(y[:, half:]), 3e-3, 1e-3)
+
+
 # ----------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, heads, scale, qs=None, ks=None, vs=None, hook=None):
     B, N, C = q.shape
