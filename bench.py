@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=str, default="sd15")
+    ap.add_argument("--latent", type=int, default=0, help="latent side (default: the config's sample_size; 128 = 1024x1024 px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -97,7 +98,7 @@ def main():
 
     pipe, cfg = build_pipe(args.config, dev, rank, world)
     pipe.scheduler.set_timesteps(MAX_STEPS)
-    hw = cfg.sample_size
+    hw = args.latent or cfg.sample_size
     # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19)
     x_T = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(8888 + rank)).to(dev)
     with torch.no_grad():
@@ -182,17 +183,31 @@ def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += ms
     total_ms = sum(a[2] for a in agg.values())
+    alg_flop = sum(a[1] for a in agg.values())   # matmul / conv / attention FLOPs of one step, counted per launch
     name, (n, flops, ms) = max(agg.items(), key=lambda kv: kv[1][2])
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    # this process; see profiles/r01_pmc_traffic.json for the command and the gfx950 FETCH_SIZE correction)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        hit = [v for k, v in pmc.items() if not k.startswith("_") and name.split("<")[0] in k and
+               name.split("<")[1].rstrip(">").replace(" ", "") in k.replace(" ", "")]
+        if hit:
+            traffic = {"hbm_bytes_per_launch": hit[0]["hbm_bytes"], "algorithmic_bytes_per_launch": hit[0]["algorithmic_bytes"],
+                       "source": "profiles/r01_pmc_traffic.json"}
+    except (OSError, ValueError, KeyError):
+        traffic = None
     return {
         "bound": "mfma", "kernel": name, "launches_per_step": n,
         "avg_launch_ms": round(ms / n, 4), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
         "achieved": round(achieved, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
-        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4), "traffic": None,
+        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic,
         "kernel_share_of_step": round(ms / total_ms, 3),
-        "whole_step": {"alg_tflop_per_step": FLOP_PER_STEP / 1e12,
-                       "achieved": round(steps_per_sec / world * FLOP_PER_STEP / 1e12, 2),
-                       "frac": round(steps_per_sec / world * FLOP_PER_STEP / PEAK_MFMA_F16, 4)},
+        "whole_step": {"alg_tflop_per_step": round(alg_flop / 1e12, 3), "survey_tflop_per_step_512px": FLOP_PER_STEP / 1e12,
+                       "achieved": round(steps_per_sec / world * alg_flop / 1e12, 2),
+                       "frac": round(steps_per_sec / world * alg_flop / PEAK_MFMA_F16, 4)},
         "per_kernel_ms": {k: round(v[2], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
     }
 

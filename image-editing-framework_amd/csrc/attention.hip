@@ -98,11 +98,16 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware: the query blocks of one (batch, head) get consecutive LOGICAL ids, which xcd_remap
+    // places on one XCD — its L2 then serves that head's K/V to all of them (measured before: every XCD
+    // fetched every head's K/V, 4x the algorithmic read traffic)
+    const int qblocks = (p.N + 127) / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % qblocks, head = (lid / qblocks) % p.heads, b = lid / (qblocks * p.heads);
     const int qs = p.q_src ? p.q_src[b] : b;
     const int ks = p.k_src ? p.k_src[b] : b;
     const int vs = p.v_src ? p.v_src[b] : b;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     const bool q_ok = q0 + r < p.N;
 
     // zero both buffers once: K pad columns (d..DP) and V pad columns (d..32*DT) are never rewritten
@@ -621,7 +626,7 @@ extern "C" int ief_attn_flash_f16(const IefAttnParams* pp, void* stream) {
     const IefAttnParams p = *pp;
     int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldq, p.ldk, p.ldv, p.ldo, p.Q, p.K, p.V, p.Out);
     if (rc) return rc;
-    dim3 grid((p.N + 127) / 128, p.heads, p.B);
+    dim3 grid(((p.N + 127) / 128) * p.heads * p.B);
     DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
     IEF_LAUNCH_CHECK();
     return IEF_OK;
