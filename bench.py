@@ -55,7 +55,8 @@ def build_pipe(cfg_name, dev, rank, world):
     """rank 0 draws the synthetic weights; other ranks receive the PACKED device tensors by RCCL broadcast."""
     import ief_amd  # noqa: F401
     from ief_amd import config, weights
-    from ief_amd.pipeline import StableDiffusionPipeline, SyntheticTextEncoder, SyntheticVAE
+    from ief_amd.pipeline import StableDiffusionPipeline, SyntheticTextEncoder
+    from ief_amd.vae import AutoencoderKL, SD_VAE, TINY_VAE
     from ief_amd.scheduler import DDIMScheduler
     from ief_amd.tokenizer import WordPieceTokenizer
     from ief_amd.unet import UNet2DConditionModel
@@ -70,7 +71,8 @@ def build_pipe(cfg_name, dev, rank, world):
         broadcast_tensors(unet.packed_tensors(), src=0)   # RCCL over xGMI, a few flat buckets
         torch.cuda.synchronize()
     pipe = StableDiffusionPipeline(unet, WordPieceTokenizer(cfg.text_max_length),
-                                   SyntheticTextEncoder(cfg.cross_attention_dim).to(dev), SyntheticVAE().to(dev),
+                                   SyntheticTextEncoder(cfg.cross_attention_dim).to(dev),
+                                   AutoencoderKL(SD_VAE if cfg_name == "sd15" else TINY_VAE, device=dev),
                                    DDIMScheduler(), cfg, sd if rank == 0 else None)
     return pipe, cfg
 

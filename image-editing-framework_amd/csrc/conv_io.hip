@@ -13,14 +13,22 @@
 // One block = CI_PIX consecutive output pixels x all Cout channels.  Weights ([9*Cin][Cout] fp16 -> fp32) and the im2col'ed input rows ([CI_PIX][9*Cin] fp32) are staged in LDS once; each thread
 // then produces 8 output channels for several pixels: 9*Cin broadcast reads + 8-wide LDS weight reads.
 #define CI_PIX 32
+#define CI_CMAX 256
 __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const half_t* __restrict__ w,
                                                       const float* __restrict__ bias, half_t* __restrict__ out,
                                                       int B, int Cin, int H, int Wd, int Cout) {
     extern __shared__ __attribute__((aligned(16))) float smem_ci[];
     const int K = 9 * Cin;
-    float* wl = smem_ci;                 // [K][Cout]
-    float* xin = smem_ci + K * Cout;     // [CI_PIX][K]
-    for (int i = threadIdx.x; i < K * Cout; i += 256) wl[i] = (float)w[i];   // w is [3][3][Cin][Cout]: k-major
+    // output channels are processed in slices of Cc (grid.y) so the fp32 weight slice fits LDS for any Cout
+    const int Cfull = Cout;
+    const int Cc = Cfull / gridDim.y, co0 = blockIdx.y * Cc;   // host picks gridDim.y | Cout with Cc % 8 == 0, Cc <= CI_CMAX
+    Cout = Cc;
+    float* wl = smem_ci;                 // [K][Cc]
+    float* xin = smem_ci + K * Cc;       // [CI_PIX][K]
+    for (int i = threadIdx.x; i < K * Cout; i += 256) {   // w is [3][3][Cin][Cfull]: k-major
+        const int k = i / Cout, c = i - k * Cout;
+        wl[k * Cc + c] = (float)w[(long long)k * Cfull + co0 + c];
+    }
     const long long total = (long long)B * H * Wd;
     const long long pix0 = (long long)blockIdx.x * CI_PIX;
     for (int i = threadIdx.x; i < CI_PIX * K; i += 256) {
@@ -46,18 +54,18 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
         if (pix >= total) continue;
         float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[co0 + c8 * 8 + e] : 0.f;
         const float* xr = xin + pl * K;
         for (int k = 0; k < K; ++k) {
             const float v = xr[k];
-            const f32x4 w0 = *(const f32x4*)(wl + k * Cout + c8 * 8), w1 = *(const f32x4*)(wl + k * Cout + c8 * 8 + 4);
+            const f32x4 w0 = *(const f32x4*)(wl + k * Cc + c8 * 8), w1 = *(const f32x4*)(wl + k * Cc + c8 * 8 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { acc[e] += v * w0[e]; acc[4 + e] += v * w1[e]; }
         }
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
-        *(half8*)(out + pix * Cout + c8 * 8) = o;
+        *(half8*)(out + pix * Cfull + co0 + c8 * 8) = o;
     }
 }
 
@@ -65,11 +73,15 @@ extern "C" int ief_conv_in_f32(const float* x, const ief_half* w, const float* b
                                int B, int Cin, int H, int Wd, int Cout, void* stream) {
     if (!x || !w || !out) return IEF_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cin > CIN_MAX || Cout <= 0 || (Cout & 7) || Cout > 2048) return IEF_ESHAPE;
-    const size_t lds = ((size_t)9 * Cin * Cout + (size_t)CI_PIX * 9 * Cin) * sizeof(float);
+    int nsl = (Cout + CI_CMAX - 1) / CI_CMAX;   // fewest equal slices of <= CI_CMAX channels, each a multiple of 8
+    while (nsl <= Cout / 8 && (Cout % nsl || ((Cout / nsl) & 7))) ++nsl;
+    if (nsl > Cout / 8) return IEF_ESHAPE;
+    const int Cc = Cout / nsl;
+    const size_t lds = ((size_t)9 * Cin * Cc + (size_t)CI_PIX * 9 * Cin) * sizeof(float);
     if (lds > 64 * 1024) return IEF_ESHAPE;
     const long long total = (long long)B * H * Wd;
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + CI_PIX - 1) / CI_PIX)), dim3(256), lds, (hipStream_t)stream,
-                       x, w, bias, out, B, Cin, H, Wd, Cout);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + CI_PIX - 1) / CI_PIX), Cout / Cc), dim3(256), lds,
+                       (hipStream_t)stream, x, w, bias, out, B, Cin, H, Wd, Cout);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

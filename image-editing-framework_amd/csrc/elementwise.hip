@@ -69,6 +69,105 @@ extern "C" int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void*
     return IEF_OK;
 }
 
+// one block per row; row kept in registers (L <= 256 * 8 * SM_MAXCH)
+#define SM_MAXCH 8
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, int L) {
+    half_t* row = x + (long long)blockIdx.x * L;
+    const int L8 = L >> 3;
+    half8 v[SM_MAXCH];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAXCH; ++i) {
+        const int c8 = threadIdx.x + 256 * i;
+        if (c8 < L8) {
+            v[i] = *(const half8*)(row + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[i][e]);
+        }
+    }
+    __shared__ float red[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    float ev[SM_MAXCH][8];
+#pragma unroll
+    for (int i = 0; i < SM_MAXCH; ++i) {
+        const int c8 = threadIdx.x + 256 * i;
+        if (c8 < L8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ev[i][e] = __expf((float)v[i][e] - mx); s += ev[i][e]; }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < SM_MAXCH; ++i) {
+        const int c8 = threadIdx.x + 256 * i;
+        if (c8 < L8) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(ev[i][e] * inv);
+            *(half8*)(row + c8 * 8) = o;
+        }
+    }
+}
+extern "C" int ief_softmax_rows_f16(ief_half* x, int rows, int L, void* stream) {
+    if (!x) return IEF_EINVAL;
+    if (rows <= 0 || L <= 0 || (L & 7) || L > 256 * 8 * SM_MAXCH) return IEF_ESHAPE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, L);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// 32x32 tiles through LDS (padded): coalesced reads and writes
+__global__ __launch_bounds__(256) void transpose_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int R, int C) {
+    __shared__ half_t tile[32][34];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = in[(long long)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) out[(long long)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+extern "C" int ief_transpose_f16(const ief_half* in, ief_half* out, int R, int C, void* stream) {
+    if (!in || !out) return IEF_EINVAL;
+    if (R <= 0 || C <= 0) return IEF_ESHAPE;
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+__global__ __launch_bounds__(256) void pointwise_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int B, int Cin, int Cout, int HW) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+    float xin[8];
+    for (int c = 0; c < Cin; ++c) xin[c] = x[((long long)b * Cin + c) * HW + p];
+    for (int o = 0; o < Cout; ++o) {
+        float a = bias ? bias[o] : 0.f;
+        for (int c = 0; c < Cin; ++c) a += w[o * Cin + c] * xin[c];
+        out[((long long)b * Cout + o) * HW + p] = a;
+    }
+}
+extern "C" int ief_pointwise_f32(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                                 int HW, void* stream) {
+    if (!x || !w || !out) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || Cout > 8) return IEF_ESHAPE;
+    const long long n = (long long)B * HW;
+    hipLaunchKernelGGL(pointwise_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                       out, B, Cin, Cout, HW);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 __global__ __launch_bounds__(256) void add_f16_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
                                                       half_t* __restrict__ o, long long n8, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_b[i] = b;
-            a_y[i] = oy * p.stride - 1;
-            a_x[i] = ox * p.stride - 1;
+            a_y[i] = oy * p.stride - (p.pad_hi_only ? 0 : 1);
+            a_x[i] = ox * p.stride - (p.pad_hi_only ? 0 : 1);
             a_off[i] = 0;
         } else {
             a_off[i] = (unsigned)m * (unsigned)p.lda * 2u + kcb;
@@ -438,8 +438,9 @@ extern "C" int ief_conv3x3_f16(const IefGemmParams* pp, void* stream) {
     if (p.stride != 1 && p.stride != 2) return IEF_ESHAPE;
     if (p.ups != 0 && p.ups != 1) return IEF_ESHAPE;
     if (p.ups && ((p.H & 1) || (p.Wd & 1))) return IEF_ESHAPE;
-    p.Ho = (p.H + 2 - 3) / p.stride + 1;
-    p.Wo = (p.Wd + 2 - 3) / p.stride + 1;
+    const int pad_total = p.pad_hi_only ? 1 : 2;
+    p.Ho = (p.H + pad_total - 3) / p.stride + 1;
+    p.Wo = (p.Wd + pad_total - 3) / p.stride + 1;
     if (p.CE1 < 0 || p.CE2 < 0 || (p.CE1 % 64) || (p.CE2 % 64)) return IEF_ESHAPE;
     if ((p.CE1 > 0 && !p.E1) || (p.CE2 > 0 && !p.E2) || (p.CE2 > 0 && p.CE1 == 0)) return IEF_EINVAL;
     if ((p.CE1 + p.CE2) > 0 && (p.stride != 1 || p.ups != 0)) return IEF_ESHAPE;

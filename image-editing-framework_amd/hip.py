@@ -31,6 +31,7 @@ class IefGemmParams(Structure):
         ("rows_per_batch", c_int), ("out_scale", c_float), ("tile_hint", c_int),
         ("E1", c_void_p), ("E2", c_void_p), ("CE1", c_int), ("CE2", c_int),
         ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p), ("stages", c_int),
+        ("pad_hi_only", c_int),
     ]
 
 
@@ -60,6 +61,7 @@ EXPORTS = [
     "ief_attn_flash_f16", "ief_attn_cross_p2p_f16", "ief_attn_probs_f16", "ief_attn_apply_f16",
     "ief_cfg_ddim_step_f32", "ief_timestep_embedding_f16", "ief_silu_f16", "ief_cast_f32_to_f16",
     "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step", "ief_add_f16", "ief_struct_size",
+    "ief_softmax_rows_f16", "ief_transpose_f16", "ief_pointwise_f32",
 ]
 
 
@@ -104,6 +106,9 @@ def load():
     lib.ief_select_step.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_advance_step.argtypes = [c_void_p, c_void_p]
     lib.ief_add_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_softmax_rows_f16.argtypes = [c_void_p, c_int, c_int, c_void_p]
+    lib.ief_transpose_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.ief_pointwise_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     if lib.ief_abi_version() != 1:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
@@ -419,7 +424,7 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
 
 
 def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0,
-            extra=None, splits=1, stages=2):
+            extra=None, splits=1, stages=2, pad_hi_only=False):
     """3x3 / pad 1 convolution over NHWC fp16.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat),
     w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather.
     extra=(e1, e2|None): fused 1x1 convolution over more NHWC sources sampled at the output pixel; w is
@@ -448,7 +453,8 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     elif tuple(w.shape[1:]) != (3, 3, C1 + C2):
         raise ValueError(f"conv3x3: weight shape {tuple(w.shape)} does not match C1+C2={C1 + C2}")
     H, Wd = (Hp * 2, Wp * 2) if upsample else (Hp, Wp)
-    Ho, Wo = (H + 2 - 3) // stride + 1, (Wd + 2 - 3) // stride + 1
+    pad_total = 1 if pad_hi_only else 2
+    Ho, Wo = (H + pad_total - 3) // stride + 1, (Wd + pad_total - 3) // stride + 1
     if out is None:
         out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16, device=x.device)
     p = IefGemmParams()
@@ -468,6 +474,7 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.N, p.ldo = Cout, Cout
     p.H, p.Wd, p.C1, p.C2 = H, Wd, C1, C2
     p.stride, p.ups, p.batch_images = stride, 1 if upsample else 0, B
+    p.pad_hi_only = 1 if pad_hi_only else 0
     p.out_scale = 1.0
     M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
     if tile_hint == 0:
@@ -476,7 +483,8 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
             autotune_plan("conv", M, Cout, K, lambda t, sp, st, i: conv3x3(x, wc[i % len(wc)], bias, x2=x2, stride=stride,
                                                                             upsample=upsample, rowvec=rowvec,
                                                                             residual=residual, out=out, tile_hint=t,
-                                                                            splits=sp, extra=extra, stages=st))
+                                                                            splits=sp, extra=extra, stages=st,
+                                                                            pad_hi_only=pad_hi_only))
             del wc
         p.tile_hint, p.splits, p.stages = pick_plan(M, Cout, K, conv=True)
     else:
@@ -495,6 +503,41 @@ def conv3x3_shortcut(h, w_fused, bias_fused, x, skip=None):
     """ResnetBlock2D tail with a channel-changing shortcut in ONE launch:
     conv3x3(h) + conv1x1([x | skip]) + (b2 + bs); w_fused [Cout, 9*Cout + Cin]."""
     return conv3x3(h, w_fused, bias_fused, extra=(x, skip))
+
+
+def softmax_rows_(x):
+    """in-place softmax over the last dim of a contiguous fp16 tensor"""
+    lib = load()
+    _dev16(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("softmax_rows_: x must be contiguous")
+    L = x.shape[-1]
+    _check(lib.ief_softmax_rows_f16(x.data_ptr(), x.numel() // L, L, _stream()), "ief_softmax_rows_f16")
+    return x
+
+
+def transpose(x):
+    """[R, C] fp16 -> [C, R]"""
+    lib = load()
+    _dev16(x, "x")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("transpose: contiguous 2-D tensor expected")
+    out = torch.empty(x.shape[1], x.shape[0], dtype=torch.float16, device=x.device)
+    _check(lib.ief_transpose_f16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()), "ief_transpose_f16")
+    return out
+
+
+def pointwise_f32(x, w, bias=None):
+    """1x1 conv on fp32 NCHW [B,Cin,H,W], w fp32 [Cout,Cin], Cin/Cout <= 8"""
+    lib = load()
+    _dev32(x, "x")
+    _dev32(w, "w")
+    B, Cin = x.shape[0], x.shape[1]
+    Cout = w.shape[0]
+    out = torch.empty(B, Cout, *x.shape[2:], dtype=torch.float32, device=x.device)
+    _check(lib.ief_pointwise_f32(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), B, Cin, Cout,
+                                 x.numel() // (B * Cin), _stream()), "ief_pointwise_f32")
+    return out
 
 
 def add(a, b, out=None):

@@ -11,9 +11,9 @@ The reference dispatches on `pipe.__class__.__name__ == "StableDiffusionPipeline
                              `tokenizer/`, `text_encoder/`) — real weights when a user has them.
 Hub names cannot be fetched here and raise a clear error.
 
-Off the per-step path (once per image) and therefore plain PyTorch-ROCm ops for now: the text
-encoder and the VAE (SURVEY.md §8f rank 3 lists the VAE as a "next" row).  Without a checkpoint
-both are small seeded stand-ins with the right interfaces and shapes.
+The VAE is `vae.AutoencoderKL` (diffusers' architecture and key names on the HIP kernels).  The text
+encoder runs once per image, off the per-step path: a local checkpoint loads transformers'
+`CLIPTextModel` (PyTorch-ROCm); without one a small seeded stand-in with the same interface is used.
 """
 import os
 from types import SimpleNamespace
@@ -25,6 +25,7 @@ from torch import nn
 from .config import CONFIGS, UNetConfig
 from .scheduler import DDIMScheduler
 from .tokenizer import WordPieceTokenizer
+from .vae import AutoencoderKL, SD_VAE, TINY_VAE, VAEConfig
 from . import weights as _weights
 
 
@@ -49,56 +50,6 @@ class SyntheticTextEncoder(nn.Module):
         return (x,)
 
 
-class _LatentDist:
-    def __init__(self, moments):
-        self.mean, self.logvar = moments.chunk(2, dim=1)
-
-    def sample(self, generator=None):
-        return self.mean
-
-    def mode(self):
-        return self.mean
-
-
-class SyntheticVAE(nn.Module):
-    """8x down / 8x up convolutional stand-in for AutoencoderKL (same call surface, seeded weights).
-
-    encode(img [B,3,H,W] in [-1,1]) -> {'latent_dist': dist with .mean [B,4,H/8,W/8]}
-    decode(z   [B,4,h,w])           -> {'sample': [B,3,8h,8w]}
-    (`/root/reference/p2p/inversion/ddim.py:39-40`, `/root/reference/p2p/model/sd_utils.py:83-84`)
-    """
-
-    def __init__(self, seed: int = 2, latent_channels: int = 4):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-
-        def conv(cout, cin, k):
-            w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
-            return nn.Parameter(w, requires_grad=False)
-
-        self.e1, self.e2, self.e3 = conv(32, 3, 3), conv(64, 32, 3), conv(128, 64, 3)
-        self.e4 = conv(2 * latent_channels, 128, 3)
-        self.d1, self.d2, self.d3 = conv(128, latent_channels, 3), conv(64, 128, 3), conv(32, 64, 3)
-        self.d4 = conv(3, 32, 3)
-        self.config = SimpleNamespace(scaling_factor=0.18215, latent_channels=latent_channels)
-        self.dtype = torch.float32
-
-    def encode(self, x):
-        x = x.to(self.e1.dtype)
-        h = F.silu(F.conv2d(x, self.e1, stride=2, padding=1))
-        h = F.silu(F.conv2d(h, self.e2, stride=2, padding=1))
-        h = F.silu(F.conv2d(h, self.e3, stride=2, padding=1))
-        return {"latent_dist": _LatentDist(F.conv2d(h, self.e4, padding=1))}
-
-    def decode(self, z):
-        z = z.to(self.d1.dtype)
-        h = F.silu(F.conv2d(z, self.d1, padding=1))
-        h = F.silu(F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), self.d2, padding=1))
-        h = F.silu(F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), self.d3, padding=1))
-        h = torch.tanh(F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), self.d4, padding=1))
-        return {"sample": h}
-
-
 class StableDiffusionPipeline:
     def __init__(self, unet, tokenizer, text_encoder, vae, scheduler, cfg: UNetConfig, state_dict=None):
         self.unet, self.tokenizer, self.text_encoder, self.vae, self.scheduler = unet, tokenizer, text_encoder, vae, scheduler
@@ -118,11 +69,11 @@ class StableDiffusionPipeline:
             sd = _weights.synthetic_state_dict(cfg, seed)
             tokenizer = WordPieceTokenizer(cfg.text_max_length)
             text_encoder = SyntheticTextEncoder(cfg.cross_attention_dim)
-            vae = SyntheticVAE()
+            vae = AutoencoderKL(SD_VAE if parts[1] == "sd15" else TINY_VAE, device=device)
         elif os.path.isdir(model_key):
             cfg, sd = _load_local_unet(model_key)
             tokenizer, text_encoder = _load_local_text(model_key, cfg)
-            vae = SyntheticVAE()  # TODO(next row): AutoencoderKL weights from `vae/`
+            vae = _load_local_vae(model_key, device)
         else:
             raise FileNotFoundError(
                 f"'{model_key}' is neither 'synthetic:<cfg>' nor a local directory.  Hub names cannot be fetched "
@@ -130,7 +81,6 @@ class StableDiffusionPipeline:
                 "lines 30-32) or use 'synthetic:sd15'.")
         unet = UNet2DConditionModel(cfg, sd, device=device)
         text_encoder = text_encoder.to(device)
-        vae = vae.to(device)
         sched = scheduler if scheduler is not None else DDIMScheduler()
         return cls(unet, tokenizer, text_encoder, vae, sched, cfg, sd if keep_state_dict else None)
 
@@ -169,6 +119,19 @@ def _load_local_unet(path):
     if missing:
         raise KeyError(f"checkpoint lacks {len(missing)} UNet tensors, e.g. {missing[:3]}")
     return cfg, {k: v.float() for k, v in sd.items()}
+
+
+def _load_local_vae(path, device):
+    import json
+    from safetensors.torch import load_file
+    vdir = os.path.join(path, "vae")
+    with open(os.path.join(vdir, "config.json")) as f:
+        c = json.load(f)
+    cfg = VAEConfig(block_out_channels=tuple(c["block_out_channels"]), layers_per_block=c["layers_per_block"],
+                    latent_channels=c["latent_channels"], in_channels=c["in_channels"],
+                    norm_num_groups=c["norm_num_groups"], scaling_factor=c.get("scaling_factor", 0.18215))
+    sd = {k: v.float() for k, v in load_file(os.path.join(vdir, "diffusion_pytorch_model.safetensors")).items()}
+    return AutoencoderKL(cfg, sd, device=device)
 
 
 def _load_local_text(path, cfg):

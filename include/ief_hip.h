@@ -74,6 +74,8 @@ typedef struct IefGemmParams {
     int flags;
     const ief_half* zeros;
     int stages;               /* depth of the LDS operand ring: 0/2 (double buffer), 3 or 4 K tiles in flight */
+    int pad_hi_only;          /* conv: 1 = zero padding only on the bottom/right edge (pad (0,1,0,1)), as the VAE encoder's
+                               * stride-2 Downsample2D uses; 0 = symmetric padding 1 */
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);
@@ -163,6 +165,13 @@ int ief_cfg_ddim_step_f32(const float* eps_u, const float* eps_c, const float* x
 int ief_timestep_embedding_f16(const float* t, ief_half* out, int B, int dim, void* stream);
 /* out = a + b elementwise on fp16 (residual add when a hook owns Attention.forward) */
 int ief_add_f16(const ief_half* a, const ief_half* b, ief_half* out, long long n, void* stream);
+/* in-place row softmax over the last dim of fp16 [rows][L] (materialised attention of the VAE mid block, d = 512) */
+int ief_softmax_rows_f16(ief_half* x, int rows, int L, void* stream);
+/* out[c][r] = in[r][c] for fp16 [R][C] (V^T for the P.V GEMM of the VAE attention) */
+int ief_transpose_f16(const ief_half* in, ief_half* out, int R, int C, void* stream);
+/* 1x1 convolution on a small fp32 NCHW tensor, Cin, Cout <= 8 (AutoencoderKL.quant_conv / post_quant_conv) */
+int ief_pointwise_f32(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int HW,
+                      void* stream);
 /* y = silu(x) elementwise on fp16 (ResnetBlock2D time_emb_proj input) */
 int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void* stream);
 /* fp16 <-> fp32 casts and row gather used to stage per-step tables inside a captured graph:

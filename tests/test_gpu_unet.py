@@ -245,3 +245,32 @@ def test_masactrl_forward_and_loop_vs_oracle(tiny):
     e = rel_err(lat, lat_ref)
     print(f"masactrl 6-step sampler: rel err {e:.3e}")
     assert e < 5e-2
+
+
+def test_full_edit_images_vs_oracle(tiny):
+    """`P2P.text2image_ldm_stable` end to end (text encode -> 10-step controlled edit -> AutoencoderKL decode -> uint8)
+    against the oracle's loop + VAE: the 'edited images' comparison of north_star, on the TINY shape family."""
+    from oracle import vae_ref
+    from ief_amd.vae import synthetic_vae_state_dict
+    pipe = tiny
+    cfg = pipe.cfg
+    n = 10
+    editor = P2P(pipe, n)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(8888))
+    c = AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV)
+    images, lat0 = editor.text2image_ldm_stable(pipe, PROMPTS, c, num_inference_steps=n, guidance_scale=7.5,
+                                                latent=x_T.to(DEV))
+    assert images.shape == (2, 128, 128, 3) and images.dtype.name == "uint8" and c.cur_step == n
+    c2 = AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV)
+    lat, _ = editor.text2image_ldm_stable(pipe, PROMPTS, c2, num_inference_steps=n, guidance_scale=7.5,
+                                          latent=x_T.to(DEV), return_latents=True)
+    unregister_attention_control(pipe, c2)
+    rc = _ref_controller(AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV), 2)
+    ref_lat = p2p_ref.edit_loop(pipe._state_dict, cfg, _context(pipe, PROMPTS).cpu().float(), x_T, rc, p2p_ref.DDIMRef(n), 7.5)
+    vsd = synthetic_vae_state_dict(pipe.vae.cfg, 2)
+    ref_img = p2p_ref.latent_to_uint8(vae_ref.decode(vsd, pipe.vae.cfg, ref_lat / pipe.vae.cfg.scaling_factor))
+    e = rel_err(lat, ref_lat)
+    diff = abs(images.astype(int) - ref_img.astype(int))
+    print(f"10-step edit: latents rel err {e:.3e}; uint8 images max diff {diff.max()}, mean {diff.mean():.3f}, "
+          f"pixels within 2 levels {(diff <= 2).mean():.4f}")
+    assert e < 5e-2 and (diff <= 3).mean() > 0.99
