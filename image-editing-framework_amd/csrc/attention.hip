@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
         l_tot = l_run + __shfl_xor(l_run, 32);
     }
     const float inv = 1.0f / l_tot;
+    // row log-sum-exp in log2 units of the PRE-SCALED scores (q * scale * log2e): what the backward kernels
+    // (attention_bwd.hip) subtract to rebuild P without a second online softmax
+    if (p.lse && q_ok && h == 0) p.lse[((long long)b * p.heads + head) * p.N + q0 + r] = m_run + __log2f(l_tot);
     if (q_ok) {
         half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;
 #pragma unroll

@@ -253,6 +253,7 @@ extern "C" int ief_struct_size(int which) {
         case 0: return (int)sizeof(IefGemmParams);
         case 1: return (int)sizeof(IefAttnParams);
         case 2: return (int)sizeof(IefCrossParams);
+        case 3: return (int)sizeof(IefAttnBwdParams);
         default: return -1;
     }
 }

@@ -41,7 +41,17 @@ class IefAttnParams(Structure):
         ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
         ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int),
         ("scale", c_float),
-        ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p),
+        ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p), ("lse", c_void_p),
+    ]
+
+
+class IefAttnBwdParams(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("dO", c_void_p), ("lse", c_void_p), ("delta", c_void_p),
+        ("dQ", c_void_p), ("dK", c_void_p), ("dV", c_void_p),
+        ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int), ("lddq", c_int), ("lddk", c_int), ("lddv", c_int),
+        ("scale", c_float), ("ds_mul", c_float),
     ]
 
 
@@ -62,6 +72,9 @@ EXPORTS = [
     "ief_cfg_ddim_step_f32", "ief_timestep_embedding_f16", "ief_silu_f16", "ief_cast_f32_to_f16",
     "ief_cast_f16_to_f32", "ief_select_step", "ief_advance_step", "ief_add_f16", "ief_struct_size",
     "ief_softmax_rows_f16", "ief_transpose_f16", "ief_pointwise_f32",
+    "ief_attn_bwd_delta_f32", "ief_attn_bwd_f16", "ief_groupnorm_bwd_f16", "ief_layernorm_bwd_f16", "ief_geglu_il_f16",
+    "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
+    "ief_nti_loss_grad_f32", "ief_nti_adam_f32",
 ]
 
 
@@ -109,10 +122,22 @@ def load():
     lib.ief_softmax_rows_f16.argtypes = [c_void_p, c_int, c_int, c_void_p]
     lib.ief_transpose_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.ief_pointwise_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.ief_attn_bwd_delta_f32.argtypes = [c_void_p] * 3 + [c_int] * 6 + [c_void_p]
+    lib.ief_attn_bwd_f16.argtypes = [POINTER(IefAttnBwdParams), c_int, c_void_p]
+    lib.ief_groupnorm_bwd_f16.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float,
+                                                                                              c_int, c_void_p]
+    lib.ief_layernorm_bwd_f16.argtypes = [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]
+    lib.ief_geglu_il_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.ief_geglu_il_bwd_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.ief_zero_insert2x_f16.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]
+    lib.ief_pool2x2_sum_f16.argtypes = [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]
+    lib.ief_conv_out_bwd_f32.argtypes = [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
+    lib.ief_nti_loss_grad_f32.argtypes = [c_void_p] * 7 + [c_int, c_float, c_void_p]
+    lib.ief_nti_adam_f32.argtypes = [c_void_p] * 8 + [c_int, c_void_p]
     if lib.ief_abi_version() != 1:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
-    for which, st in enumerate((IefGemmParams, IefAttnParams, IefCrossParams)):
+    for which, st in enumerate((IefGemmParams, IefAttnParams, IefCrossParams, IefAttnBwdParams)):
         if lib.ief_struct_size(which) != ctypes.sizeof(st):
             raise HipExtensionMissing(f"{st.__name__}: ctypes layout ({ctypes.sizeof(st)} B) != library "
                                       f"({lib.ief_struct_size(which)} B); rebuild libief_hip.so")
@@ -646,14 +671,19 @@ def _attn_common(p, q, k, v, out, heads):
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
 
 
-def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None):
-    """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok)."""
+def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None):
+    """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok).
+    lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes."""
     lib = load()
     if out is None:
         out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)
     p = IefAttnParams()
     _attn_common(p, q, k, v, out, heads)
     p.scale = scale
+    if lse is not None:
+        if tuple(_dev32(lse, "lse").shape) != (q.shape[0], heads, q.shape[1]):
+            raise ValueError("attn_flash: lse must be fp32 [B, heads, N]")
+        p.lse = lse.data_ptr()
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
     with _Timed(f"attn_flash_kernel<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
         _check(lib.ief_attn_flash_f16(byref(p), _stream()), "ief_attn_flash_f16")
@@ -784,3 +814,171 @@ def select_step(table, out, step):
 def advance_step(step):
     lib = load()
     _check(lib.ief_advance_step(_devi32(step, "step").data_ptr(), _stream()), "ief_advance_step")
+
+
+# ------------------------------------------------------------------------------- activation gradients (null-text inversion)
+def attn_bwd(q, k, v, o, do, lse, heads, scale, dq=None, dk=None, dv=None, ds_mul=None, want_dq=True, want_dkv=True):
+    """Gradients of out = softmax(q k^T scale) v w.r.t. q, k, v given dO (`do`), the forward output `o` and its `lse`.
+    q/do/o [B,N,h*d], k/v [B,L,h*d] (strided views ok); dq/dk/dv may be column slices of larger buffers."""
+    lib = load()
+    B, N, _ = q.shape
+    L = k.shape[1]
+    d = o.shape[-1] // heads
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (do, "do")):
+        _dev16(t, nm)
+        if t.dim() != 3 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
+            raise ValueError(f"{nm}: expected [B, rows, heads*d] with batch stride rows * ld")
+    _dev32(lse, "lse")
+    delta = torch.empty(B, heads, N, dtype=torch.float32, device=q.device)
+    _check(lib.ief_attn_bwd_delta_f32(o.data_ptr(), do.data_ptr(), delta.data_ptr(), B, heads, N, d, o.stride(1),
+                                      do.stride(1), _stream()), "ief_attn_bwd_delta_f32")
+    p = IefAttnBwdParams()
+    p.Q, p.K, p.V, p.dO, p.lse, p.delta = q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    p.B, p.heads, p.N, p.L, p.d = B, heads, N, L, d
+    p.ldq, p.ldk, p.ldv, p.ldo = q.stride(1), k.stride(1), v.stride(1), do.stride(1)
+    p.scale = scale
+    p.ds_mul = float(ds_mul) if ds_mul is not None else float(min(L, 1024))
+    what = 0
+    if want_dq:
+        if dq is None:
+            dq = torch.empty(B, N, heads * d, dtype=torch.float16, device=q.device)
+        _dev16(dq, "dq")
+        p.dQ, p.lddq = dq.data_ptr(), dq.stride(1)
+        what |= 1
+    if want_dkv:
+        if dk is None:
+            dk = torch.empty(B, L, heads * d, dtype=torch.float16, device=q.device)
+        if dv is None:
+            dv = torch.empty(B, L, heads * d, dtype=torch.float16, device=q.device)
+        _dev16(dk, "dk"), _dev16(dv, "dv")
+        p.dK, p.dV, p.lddk, p.lddv = dk.data_ptr(), dv.data_ptr(), dk.stride(1), dv.stride(1)
+        what |= 2
+    fl = (6.0 if want_dq else 0.0) + (8.0 if want_dkv else 0.0)
+    with _Timed(f"attn_bwd_kernel<{d}>", fl * B * heads * N * L * d):
+        _check(lib.ief_attn_bwd_f16(byref(p), what, _stream()), "ief_attn_bwd_f16")
+    return dq, dk, dv
+
+
+def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None):
+    """dx (and dx2 for a channel-concat input) of groupnorm(x | x2) [+ SiLU]; `add` is summed into the result."""
+    lib = load()
+    _dev16(x, "x"), _dev16(dy, "dy")
+    B, C1 = x.shape[0], x.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    HW = x.numel() // (B * C1)
+    if not x.is_contiguous() or not dy.is_contiguous() or dy.numel() != B * HW * (C1 + C2):
+        raise ValueError("groupnorm_bwd: x / dy must be contiguous, dy [B, HW, C1+C2]")
+    if x2 is not None and (not _dev16(x2, "x2").is_contiguous() or x2.numel() != B * HW * C2):
+        raise ValueError("groupnorm_bwd: x2 shape")
+    if add is not None and (not _dev16(add, "add").is_contiguous() or add.numel() != dy.numel()):
+        raise ValueError("groupnorm_bwd: add must match dy")
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    with _Timed("groupnorm_bwd", 0.0):
+        _check(lib.ief_groupnorm_bwd_f16(x.data_ptr(), _ptr(x2), C1, C2, dy.data_ptr(), _ptr(add), dx.data_ptr(), _ptr(dx2),
+                                         _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups, eps,
+                                         1 if silu else 0, _stream()), "ief_groupnorm_bwd_f16")
+    return (dx, dx2) if x2 is not None else dx
+
+
+def layernorm_bwd(x, dy, gamma, eps=1e-5, add=None):
+    lib = load()
+    _dev16(x, "x"), _dev16(dy, "dy")
+    if not x.is_contiguous() or not dy.is_contiguous() or dy.shape != x.shape:
+        raise ValueError("layernorm_bwd: x / dy must be contiguous and of equal shape")
+    if add is not None and (not _dev16(add, "add").is_contiguous() or add.shape != x.shape):
+        raise ValueError("layernorm_bwd: add must match x")
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _check(lib.ief_layernorm_bwd_f16(x.data_ptr(), dy.data_ptr(), _ptr(add), dx.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                     x.numel() // C, C, eps, _stream()), "ief_layernorm_bwd_f16")
+    return dx
+
+
+def geglu_il(pre):
+    """pre [..., 2*Ch] in the interleaved FF1 layout -> hidden * gelu(gate) [..., Ch]"""
+    lib = load()
+    _dev16(pre, "pre")
+    if not pre.is_contiguous():
+        raise ValueError("geglu_il: pre must be contiguous")
+    Ch = pre.shape[-1] // 2
+    out = torch.empty(*pre.shape[:-1], Ch, dtype=torch.float16, device=pre.device)
+    _check(lib.ief_geglu_il_f16(pre.data_ptr(), out.data_ptr(), pre.numel() // (2 * Ch), Ch, _stream()), "ief_geglu_il_f16")
+    return out
+
+
+def geglu_il_bwd(pre, dy):
+    lib = load()
+    _dev16(pre, "pre"), _dev16(dy, "dy")
+    Ch = pre.shape[-1] // 2
+    if not pre.is_contiguous() or not dy.is_contiguous() or dy.shape[-1] != Ch or dy.numel() * 2 != pre.numel():
+        raise ValueError("geglu_il_bwd: pre [..., 2*Ch], dy [..., Ch], both contiguous")
+    dpre = torch.empty_like(pre)
+    _check(lib.ief_geglu_il_bwd_f16(pre.data_ptr(), dy.data_ptr(), dpre.data_ptr(), pre.numel() // (2 * Ch), Ch, _stream()),
+           "ief_geglu_il_bwd_f16")
+    return dpre
+
+
+def zero_insert2x(x):
+    """[B,H,W,C] -> [B,2H,2W,C] with x at the even positions, zeros elsewhere (stride-2 conv data gradient)"""
+    lib = load()
+    _dev16(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("zero_insert2x: contiguous NHWC expected")
+    B, H, W, C = x.shape
+    out = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float16, device=x.device)
+    _check(lib.ief_zero_insert2x_f16(x.data_ptr(), out.data_ptr(), B, H, W, C, _stream()), "ief_zero_insert2x_f16")
+    return out
+
+
+def pool2x2_sum(x):
+    """[B,2H,2W,C] -> [B,H,W,C] summing each 2x2 block (nearest-2x upsample backward)"""
+    lib = load()
+    _dev16(x, "x")
+    if x.dim() != 4 or not x.is_contiguous() or (x.shape[1] & 1) or (x.shape[2] & 1):
+        raise ValueError("pool2x2_sum: contiguous NHWC with even H, W expected")
+    B, H2, W2, C = x.shape
+    out = torch.empty(B, H2 // 2, W2 // 2, C, dtype=torch.float16, device=x.device)
+    _check(lib.ief_pool2x2_sum_f16(x.data_ptr(), out.data_ptr(), B, H2 // 2, W2 // 2, C, _stream()), "ief_pool2x2_sum_f16")
+    return out
+
+
+def conv_out_bwd(d_eps, w):
+    """d_eps fp32 NCHW [B,Cout,H,W], w fp16 [Cout,3,3,C] (conv_out's own weight) -> fp16 NHWC [B,H,W,C]"""
+    lib = load()
+    _dev32(d_eps, "d_eps"), _dev16(w, "w")
+    B, Cout, H, W = d_eps.shape
+    C = w.shape[-1]
+    if tuple(w.shape) != (Cout, 3, 3, C) or not w.is_contiguous():
+        raise ValueError("conv_out_bwd: weight must be contiguous [Cout, 3, 3, C]")
+    out = torch.empty(B, H, W, C, dtype=torch.float16, device=w.device)
+    _check(lib.ief_conv_out_bwd_f32(d_eps.data_ptr(), w.data_ptr(), out.data_ptr(), B, C, H, W, Cout, _stream()),
+           "ief_conv_out_bwd_f32")
+    return out
+
+
+def nti_loss_grad(eps_u, eps_c, x, target, coef, d_eps, stats, grad_scale=1.0):
+    """NTI objective + normalised gradient w.r.t. eps_u (see include/ief_hip.h); stats fp32 [2] <- (loss, factor)."""
+    lib = load()
+    for t, nm in ((eps_u, "eps_u"), (eps_c, "eps_c"), (x, "x"), (target, "target"), (coef, "coef"), (d_eps, "d_eps"),
+                  (stats, "stats")):
+        _dev32(t, nm)
+    n = eps_u.numel()
+    if any(t.numel() != n for t in (eps_c, x, target, d_eps)) or coef.numel() < 3 or stats.numel() < 2:
+        raise ValueError("nti_loss_grad: shape mismatch")
+    _check(lib.ief_nti_loss_grad_f32(eps_u.data_ptr(), eps_c.data_ptr(), x.data_ptr(), target.data_ptr(), coef.data_ptr(),
+                                     d_eps.data_ptr(), stats.data_ptr(), n, grad_scale, _stream()), "ief_nti_loss_grad_f32")
+
+
+def nti_adam(param, m, v, grad16, stats, hyper, step, param16):
+    """One torch.optim.Adam step on fp32 `param` with g = grad16 * stats[1]; hyper fp32 {lr, beta1, beta2, eps}."""
+    lib = load()
+    for t, nm in ((param, "param"), (m, "m"), (v, "v"), (stats, "stats"), (hyper, "hyper")):
+        _dev32(t, nm)
+    _dev16(grad16, "grad16"), _dev16(param16, "param16")
+    _devi32(step, "step")
+    n = param.numel()
+    if any(t.numel() != n for t in (m, v, grad16, param16)) or not grad16.is_contiguous() or not param16.is_contiguous():
+        raise ValueError("nti_adam: shape mismatch")
+    _check(lib.ief_nti_adam_f32(param.data_ptr(), m.data_ptr(), v.data_ptr(), grad16.data_ptr(), stats.data_ptr(),
+                                hyper.data_ptr(), step.data_ptr(), param16.data_ptr(), n, _stream()), "ief_nti_adam_f32")

@@ -1,0 +1,140 @@
+"""Null-text optimisation engine: the loop of `/root/reference/p2p/inversion/nti.py:9-45` on the HIP kernels.
+
+Per DDIM timestep i the reference
+  1. computes eps_cond once (no grad),
+  2. runs <= num_inner_steps of {UNet(uncond) -> CFG -> scheduler.step -> mse against the inversion latent ->
+     backward -> Adam}, stopping early when the loss (of the PRE-update embedding) falls under eps + 2e-5 i,
+  3. advances latent_cur with the optimised embedding.
+Here each of the three is ONE captured hipGraph over static buffers (a fresh Adam per timestep = zeroed
+moments and step counter, lr in a device scalar), so an inner iteration costs one graph replay plus the
+host read of the loss that the early-stop rule needs — exactly the reference's `loss.item()`.
+
+The gradient is not torch autograd: `grad.UNetAdjoint` chains activation-gradient kernels (weights are
+frozen on this path).  Everything that varies with the timestep is a row of a device table.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import hip
+from .grad import UNetAdjoint
+
+
+class NullTextOptimizer:
+    def __init__(self, model, cond: torch.Tensor, guidance_scale: float, latent_hw, grad_scale: float = 1.0,
+                 use_graph: bool = True):
+        self.model, self.unet, self.sched = model, model.unet, model.scheduler
+        dev = self.unet.device
+        self.dev = dev
+        self.adj = UNetAdjoint(self.unet, grad_scale)
+        self.adj.prepack()
+        h, w = latent_hw
+        C = self.unet.config.in_channels
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.lat = torch.zeros(1, C, h, w, **f32)
+        self.target = torch.zeros(1, C, h, w, **f32)
+        self.eps_c = torch.zeros(1, C, h, w, **f32)
+        self.d_eps = torch.zeros(1, C, h, w, **f32)
+        self.stats = torch.zeros(2, **f32)
+        self.hyper = torch.tensor([1e-2, 0.9, 0.999, 1e-8], **f32)     # torch.optim.Adam defaults (nti.py:17)
+        self.adam_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        ts = self.sched.timesteps.tolist()
+        self.num_steps = len(ts)
+        g = float(guidance_scale)
+        self.coef_table = torch.tensor([[*self.sched.step_coeffs(t), g, 0.0] for t in ts], **f32)
+        self.coef = torch.zeros(4, **f32)
+        self.temb_table = self.unet.time_rows(torch.tensor(ts, **f32)).contiguous()
+        self.temb = torch.zeros(1, self.temb_table.shape[1], **f32)
+        self.cond16 = hip.to_f16(cond.to(dev).float().contiguous())
+        L, Cc = self.cond16.shape[1:]
+        self.param = torch.zeros(1, L, Cc, **f32)
+        self.m = torch.zeros_like(self.param)
+        self.v = torch.zeros_like(self.param)
+        self.p16 = torch.zeros(1, L, Cc, dtype=torch.float16, device=dev)
+        self.use_graph = use_graph
+        self._graphs = None
+        self.inner_steps_run: List[int] = []     # per timestep, how many Adam steps the early-stop rule allowed
+        self.last_losses: List[float] = []
+
+    # ------------------------------------------------------------------ the three stream-ordered bodies
+    def _body_cond(self):
+        eps = self.unet(self.lat, encoder_hidden_states=self.cond16, temb_row=self.temb)["sample"]
+        self.eps_c.copy_(eps)
+
+    def _body_inner(self):
+        eps_u = self.adj.forward(self.lat, self.temb, self.p16)
+        hip.nti_loss_grad(eps_u, self.eps_c, self.lat, self.target, self.coef, self.d_eps, self.stats, self.adj.grad_scale)
+        g16 = self.adj.backward(self.d_eps)
+        hip.nti_adam(self.param, self.m, self.v, g16, self.stats, self.hyper, self.adam_step, self.p16)
+
+    def _body_tail(self):
+        eps_u = self.unet(self.lat, encoder_hidden_states=self.p16, temb_row=self.temb)["sample"]
+        hip.cfg_ddim_step(eps_u, self.eps_c, self.lat, self.coef, out=self.lat)
+
+    def _capture(self):
+        for m in self.unet.attention_modules():
+            m.cache_kv = False          # the uncond context changes under the same buffer: never cache its K/V
+        saved = [t.clone() for t in (self.lat, self.param, self.m, self.v, self.p16, self.adam_step, self.eps_c)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):          # warm-up: allocator pools, packed adjoint weights
+            self._body_cond(), self._body_inner(), self._body_tail()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graphs = []
+        for body in (self._body_cond, self._body_inner, self._body_tail):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            graphs.append(g)
+        for t, sv in zip((self.lat, self.param, self.m, self.v, self.p16, self.adam_step, self.eps_c), saved):
+            t.copy_(sv)
+        self._graphs = graphs
+
+    def _run(self, which: int):
+        if self._graphs is not None:
+            self._graphs[which].replay()
+        else:
+            (self._body_cond, self._body_inner, self._body_tail)[which]()
+
+    # ------------------------------------------------------------------ public
+    def run(self, latents: List[torch.Tensor], uncond: torch.Tensor, num_inner_steps: int, epsilon: float,
+            num_outer: Optional[int] = None) -> List[torch.Tensor]:
+        """latents: the 51 inversion latents (x_0 .. x_T); uncond [1,77,C].  Returns one [1,77,C] fp32 per timestep."""
+        dev = self.dev
+        self.lat.copy_(latents[-1].to(dev).float())
+        self.param.copy_(uncond.to(dev).float()[:1])
+        hip.to_f16(self.param, out=self.p16)
+        if self.use_graph and self._graphs is None:
+            self._capture()
+        elif not self.use_graph:
+            for m in self.unet.attention_modules():
+                m.cache_kv = False
+        out = []
+        self.inner_steps_run, self.last_losses = [], []
+        n = self.num_steps if num_outer is None else num_outer
+        for i in range(n):
+            self.temb.copy_(self.temb_table[i:i + 1])
+            self.coef.copy_(self.coef_table[i])
+            self.target.copy_(latents[len(latents) - i - 2].to(dev).float())
+            self.m.zero_(), self.v.zero_(), self.adam_step.zero_()          # `Adam([uncond], lr=...)` anew (nti.py:17)
+            self.hyper[0:1].fill_(1e-2 * (1.0 - i / 100.0))
+            self._run(0)
+            done, loss = 0, float("nan")
+            for j in range(num_inner_steps):
+                self._run(1)
+                done += 1
+                loss = float(self.stats[0].item())
+                if loss < epsilon + i * 2e-5:
+                    break
+            self.inner_steps_run.append(done)
+            self.last_losses.append(loss)
+            out.append(self.param.clone())
+            self._run(2)
+        return out
+
+    def release(self):
+        self._graphs = None
+        for m in self.unet.attention_modules():
+            m.cache_kv = True
+            m._kv_key, m._kv = None, None

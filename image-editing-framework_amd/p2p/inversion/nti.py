@@ -1,20 +1,25 @@
-"""Null-text inversion (`/root/reference/p2p/inversion/nti.py:9-45`).
+"""Null-text inversion (`/root/reference/p2p/inversion/nti.py:9-45`), same class name and signature.
 
-Per timestep the reference Adam-optimises the unconditional embedding through the UNet, which
-needs the UNet's BACKWARD with respect to `encoder_hidden_states` (cross-attention K/V
-projections -> attention -> everything downstream).  The activation-gradient kernels are the
-first "next" row of the scope table and are not built yet; this class keeps
-the reference's name and signature and fails loudly instead of silently running a slow or wrong
-substitute.  The numerics of the loop itself are pinned in the oracle against the reference
-(`oracle/p2p_ref.py:null_optimization`, fixture G8).  `P2P_NTI.text2image_ldm_stable` already accepts
-a precomputed `uncond_embeddings_list` (e.g. loaded by `dataset.pie.PIE_NTI_Inversion`).
+Per timestep the reference Adam-optimises the unconditional embedding through the UNet with torch
+autograd.  Here the loop runs on the HIP kernels: `ief_amd.nti.NullTextOptimizer` replays one captured
+hipGraph per inner iteration (UNet forward keeping the adjoint's inputs -> objective -> hand-written
+activation-gradient pass -> Adam) and reads the loss back for the reference's early-stop rule.
+The numerics of the loop are pinned in the oracle against the reference (`oracle/p2p_ref.py:
+null_optimization`, fixture G8); `tests/test_gpu_grad.py` holds this class to that oracle.
 """
+from ...nti import NullTextOptimizer
 from .ddim import ddim_inversion
 
 
 class NTI(ddim_inversion):
     def null_optimization(self, model, latents, context, num_inner_steps, epsilon, guidance_scale):
-        raise NotImplementedError(
-            "null-text optimisation needs the UNet backward w.r.t. encoder_hidden_states, which is not built yet "
-            "(DESIGN.md, 'What comes next' #1).  Use --inversion_type ddim, or pass precomputed "
-            "uncond_embeddings_list to P2P_NTI.text2image_ldm_stable.")
+        """latents: the 51 latents of `ddim_inversion_loop`; context [2,77,C] = (uncond, cond).
+        Returns a list of `num_inference_steps` tensors [1,77,C] (detached), as the reference does (:36,45)."""
+        uncond_embeddings, cond_embeddings = context.chunk(2)
+        opt = NullTextOptimizer(model, cond_embeddings, guidance_scale, tuple(latents[-1].shape[-2:]))
+        try:
+            out = opt.run(latents, uncond_embeddings, num_inner_steps, epsilon)
+        finally:
+            opt.release()
+        self.inner_steps_run = opt.inner_steps_run      # diagnostics: Adam steps taken per timestep
+        return out

@@ -32,7 +32,7 @@ extern "C" {
 int ief_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char* ief_target_arch(void);
-/* sizeof the parameter structs as compiled (0: IefGemmParams, 1: IefAttnParams, 2: IefCrossParams) */
+/* sizeof the parameter structs as compiled (0: IefGemmParams, 1: IefAttnParams, 2: IefCrossParams, 3: IefAttnBwdParams) */
 int ief_struct_size(int which);
 
 /* ------------------------------------------------------------------ GEMM / conv3x3
@@ -121,6 +121,7 @@ typedef struct IefAttnParams {
     int ldq, ldk, ldv, ldo;
     float scale;
     const int* q_src; const int* k_src; const int* v_src;
+    float* lse;   /* ief_attn_flash_f16 only, may be NULL: fp32 [B][heads][N] row log-sum-exp (log2 units) for ief_attn_bwd_f16 */
 } IefAttnParams;
 int ief_attn_flash_f16(const IefAttnParams* p, void* stream);
 
@@ -180,6 +181,58 @@ int ief_cast_f32_to_f16(const float* x, ief_half* out, long long n, void* stream
 int ief_cast_f16_to_f32(const ief_half* x, float* out, long long n, void* stream);
 int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, void* stream);
 int ief_advance_step(int* step, void* stream);
+
+/* ------------------------------------------------------------------ null-text inversion: activation gradients
+ * The reference optimises the unconditional embedding with torch autograd through the whole UNet
+ * (/root/reference/p2p/inversion/nti.py:15-33: `uncond_embeddings.requires_grad`, `loss.backward()`,
+ * `optimizer.step()`), weights frozen.  Only gradients w.r.t. ACTIVATIONS are therefore needed:
+ *   - linear / conv3x3 data gradients are ief_gemm_f16 / ief_conv3x3_f16 on transposed (and tap-flipped) weights;
+ *   - the entry points below are the backward of everything else on the path.
+ * Gradients are fp16 and carry a global scale chosen by ief_nti_loss_grad_f32 (undone in ief_nti_adam_f32).
+ */
+typedef struct IefAttnBwdParams {
+    const ief_half* Q; const ief_half* K; const ief_half* V; const ief_half* dO;
+    const float* lse;     /* [B][heads][N] from ief_attn_flash_f16 */
+    const float* delta;   /* [B][heads][N] from ief_attn_bwd_delta_f32 */
+    ief_half* dQ; ief_half* dK; ief_half* dV;
+    int B, heads, N, L, d;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float scale;
+    float ds_mul;         /* dS is multiplied by this before its fp16 rounding (undone in fp32); > 0 */
+} IefAttnBwdParams;
+/* delta[b][h][n] = sum_d dO * O  (the softmax-backward row term) */
+int ief_attn_bwd_delta_f32(const ief_half* O, const ief_half* dO, float* delta, int B, int heads, int N, int d,
+                           int ldo, int lddo, void* stream);
+/* what: 1 = dQ, 2 = dK and dV, 3 = all.  d in {32,40,64,80,160}; any N, L >= 1. */
+int ief_attn_bwd_f16(const IefAttnBwdParams* p, int what, void* stream);
+/* GroupNorm(+SiLU) backward w.r.t. the input: x (+x2 channel concat) is the forward INPUT, dy [B][HW][C1+C2] the gradient
+ * of the output, `add` (optional, same shape as dy) is added to the result; dx [B][HW][C1], dx2 [B][HW][C2]. */
+int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int C1, int C2, const ief_half* dy, const ief_half* add,
+                          ief_half* dx, ief_half* dx2, const float* gamma, const float* beta, int B, int HW, int groups,
+                          float eps, int apply_silu, void* stream);
+/* LayerNorm backward w.r.t. the input (+ optional `add`) */
+int ief_layernorm_bwd_f16(const ief_half* x, const ief_half* dy, const ief_half* add, ief_half* dx, const float* gamma,
+                          int rows, int C, float eps, void* stream);
+/* GEGLU on the interleaved projection layout of the fused FF1 GEMM ([8 hidden | 8 gate] column groups):
+ * forward out[r][8g+e] = pre[r][16g+e] * gelu(pre[r][16g+8+e]) and its backward w.r.t. pre */
+int ief_geglu_il_f16(const ief_half* pre, ief_half* out, int rows, int Ch, void* stream);
+int ief_geglu_il_bwd_f16(const ief_half* pre, const ief_half* dy, ief_half* dpre, int rows, int Ch, void* stream);
+/* stride-2 conv data gradient = stride-1 conv of the zero-inserted gradient: out[b][2i][2j] = in[b][i][j], else 0 */
+int ief_zero_insert2x_f16(const ief_half* in, ief_half* out, int B, int H, int W, int C, void* stream);
+/* nearest-2x upsample backward: out[b][i][j] = sum of the 2x2 block of in [B][2H][2W][C] */
+int ief_pool2x2_sum_f16(const ief_half* in, ief_half* out, int B, int H, int W, int C, void* stream);
+/* conv_out data gradient: d_eps fp32 NCHW [B][Cout][H][W], w fp16 [Cout][3][3][C] -> dh fp16 NHWC [B][H][W][C] */
+int ief_conv_out_bwd_f32(const float* d_eps, const ief_half* w, ief_half* dh, int B, int C, int H, int W, int Cout,
+                         void* stream);
+/* NTI objective (nti.py:24-27): rec = DDIM step of x with eps = eps_u + g (eps_c - eps_u); loss = mean((rec - target)^2).
+ * coef: DEVICE fp32 {a_from, a_to, g} as for ief_cfg_ddim_step_f32.  Writes stats[0] = loss, stats[1] = factor, and the NORMALISED gradient
+ * d_eps = (rec - target) / max|rec - target| * grad_scale, with d loss / d eps_u = d_eps * factor.  n <= 2^20. */
+int ief_nti_loss_grad_f32(const float* eps_u, const float* eps_c, const float* x, const float* target, const float* coef,
+                          float* d_eps, float* stats, int n, float grad_scale, void* stream);
+/* torch.optim.Adam step (nti.py:17,29-30) on fp32 param [n]: g = grad16 * stats[1]; state m, v, DEVICE int step count
+ * (incremented here), hyper: DEVICE fp32 {lr, beta1, beta2, eps}; also writes the fp16 copy the next forward reads. */
+int ief_nti_adam_f32(float* param, float* m, float* v, const ief_half* grad16, const float* stats, const float* hyper,
+                     int* step, ief_half* param16, int n, void* stream);
 
 #ifdef __cplusplus
 }
