@@ -70,14 +70,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const IefAttnBwdParams p)
     constexpr int NCH = (64 * CPR + 255) / 256;
     __shared__ __attribute__((aligned(16))) half_t Y1s[64 * RS];
     __shared__ __attribute__((aligned(16))) half_t Y2s[64 * RS];
-    __shared__ float ylse[64], ydel[64];
+    __shared__ __attribute__((aligned(16))) float ylse[64], ydel[64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nx = DKV ? p.L : p.N, ny = DKV ? p.N : p.L;
     const int xblocks = (nx + 127) / 128;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int xblk = lid % xblocks, head = (lid / xblocks) % p.heads, b = lid / (xblocks * p.heads);
+    const int ysplits = DKV ? max(p.kv_splits, 1) : 1;
+    const int split = lid % ysplits, lid2 = lid / ysplits;
+    const int xblk = lid2 % xblocks, head = (lid2 / xblocks) % p.heads, b = lid2 / (xblocks * p.heads);
     const int col = xblk * 128 + wave * 32 + r;
     const bool col_ok = col < nx;
 
@@ -165,12 +167,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const IefAttnBwdParams p)
     const int tr_lane = (4 * h + (L16 >> 2)) * RS + 16 * ((lane >> 4) & 1) + 4 * (L16 & 3);  // transposing reads
     const float mul = p.ds_mul;
 
-    const int nt = (ny + 63) / 64;
+    const int nt_all = (ny + 63) / 64;
+    const int tps = (nt_all + ysplits - 1) / ysplits;          // tiles per split (a trailing split may be empty: writes zeros)
+    const int jb = split * tps, nt = min(nt_all, jb + tps);
     __syncthreads();
-    load_tile(0);
+    load_tile(jb * 64);
     store_tile();
     __syncthreads();
-    for (int j = 0; j < nt; ++j) {
+    for (int j = jb; j < nt; ++j) {
         const int y0 = j * 64;
         if (j + 1 < nt) load_tile(y0 + 64);
         f32x16 t1[2], t2[2];
@@ -192,13 +196,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const IefAttnBwdParams p)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rl = 32 * u + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const bool ok = y0 + rl < ny;
-                const float l = DKV ? ylse[rl] : lse_c, dl = DKV ? ydel[rl] : del_c;
-                const float pr = ok ? __builtin_amdgcn_exp2f(t1[u][i] - l) : 0.f;
-                t1[u][i] = pr;
-                t2[u][i] = pr * (t2[u][i] - dl) * mul;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int rb = 32 * u + 8 * g4 + 4 * h;
+                f32x4 l4 = {lse_c, lse_c, lse_c, lse_c}, d4 = {del_c, del_c, del_c, del_c};
+                if constexpr (DKV) { l4 = *(const f32x4*)(ylse + rb); d4 = *(const f32x4*)(ydel + rb); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g4 + e;
+                    const bool ok = y0 + rb + e < ny;
+                    const float pr = ok ? __builtin_amdgcn_exp2f(t1[u][i] - l4[e]) : 0.f;
+                    t1[u][i] = pr;
+                    t2[u][i] = pr * (t2[u][i] - d4[e]) * mul;
+                }
             }
         const half8 db[4] = {pack8s(t2[0], 0), pack8s(t2[0], 8), pack8s(t2[1], 0), pack8s(t2[1], 8)};
         half8 pb[4];
@@ -224,6 +233,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const IefAttnBwdParams p)
         __syncthreads();
     }
 
+    if (DKV && ysplits > 1) {
+        // raw fp32 partials: ws[which][split][b][col][heads*D]; attn_bwd_reduce_kernel sums the splits
+        if (col_ok) {
+            const long long per = (long long)p.B * nx * p.heads * D;
+            float* w1 = p.ws + (long long)split * per + ((long long)b * nx + col) * p.heads * D + head * D;
+            float* w2 = w1 + (long long)ysplits * per;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dbase = t * 32 + 8 * g + 4 * h;
+                    if (dbase < D) {
+                        *(f32x4*)(w1 + dbase) = (f32x4){acc1[t][4 * g], acc1[t][4 * g + 1], acc1[t][4 * g + 2], acc1[t][4 * g + 3]};
+                        if constexpr (DKV)
+                            *(f32x4*)(w2 + dbase) = (f32x4){acc2[t][4 * g], acc2[t][4 * g + 1], acc2[t][4 * g + 2], acc2[t][4 * g + 3]};
+                    }
+                }
+        }
+        return;
+    }
     if (col_ok) {
         const float f1 = p.scale / mul;
         half_t* o1 = (DKV ? p.dK : p.dQ) + ((long long)b * nx + col) * (DKV ? p.lddk : p.lddq) + head * D;
@@ -247,13 +276,36 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const IefAttnBwdParams p)
     }
 }
 
+// sums the query-split partials of dK / dV (fixed order: deterministic) and applies the fp32 factors
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const IefAttnBwdParams p) {
+    const int C = p.heads * p.d, C4 = C >> 2;
+    const long long rows = (long long)p.B * p.L, total = rows * C4;
+    const long long per = rows * C;
+    const float f1 = p.scale / p.ds_mul;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / C4;
+        const int c = (int)(i % C4) * 4;
+        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        for (int s = 0; s < p.kv_splits; ++s) {
+            const f32x4 x = *(const f32x4*)(p.ws + (long long)s * per + row * C + c);
+            const f32x4 y = *(const f32x4*)(p.ws + ((long long)p.kv_splits + s) * per + row * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += x[e]; b[e] += y[e]; }
+        }
+        half4 ka = {sat_half(a[0] * f1), sat_half(a[1] * f1), sat_half(a[2] * f1), sat_half(a[3] * f1)};
+        half4 va = {sat_half(b[0]), sat_half(b[1]), sat_half(b[2]), sat_half(b[3])};
+        *(half4*)(p.dK + row * p.lddk + c) = ka;
+        *(half4*)(p.dV + row * p.lddv + c) = va;
+    }
+}
+
 #define BWD_DISPATCH(DD, KV)                                                                                        \
     hipLaunchKernelGGL((attn_bwd_kernel<DD, KV>), dim3(grid), dim3(256), 0, st, p)
 
 template <bool KV>
 static int launch_bwd(const IefAttnBwdParams& p, hipStream_t st) {
     const int nx = KV ? p.L : p.N;
-    const int grid = ((nx + 127) / 128) * p.heads * p.B;
+    const int grid = ((nx + 127) / 128) * p.heads * p.B * (KV && p.kv_splits > 1 ? p.kv_splits : 1);
     switch (p.d) {
         case 32: BWD_DISPATCH(32, KV); break;
         case 40: BWD_DISPATCH(40, KV); break;
@@ -263,6 +315,13 @@ static int launch_bwd(const IefAttnBwdParams& p, hipStream_t st) {
         default: return IEF_ESHAPE;
     }
     IEF_LAUNCH_CHECK();
+    if (KV && p.kv_splits > 1) {
+        const long long total = (long long)p.B * p.L * (p.heads * p.d / 4);
+        int rg = (int)((total + 255) / 256);
+        if (rg > 2048) rg = 2048;
+        hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
+        IEF_LAUNCH_CHECK();
+    }
     return IEF_OK;
 }
 
@@ -292,6 +351,7 @@ extern "C" int ief_attn_bwd_f16(const IefAttnBwdParams* pp, int what, void* stre
     if ((what & 1) && (p.lddq & 3)) return IEF_EALIGN;
     if ((what & 2) && ((p.lddk & 3) || (p.lddv & 3))) return IEF_EALIGN;
     if (!(p.ds_mul > 0.f)) return IEF_ESHAPE;
+    if (p.kv_splits < 0 || p.kv_splits > 256 || (p.kv_splits > 1 && !p.ws)) return IEF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     int rc = IEF_OK;
     if (what & 1) rc = launch_bwd<false>(p, st);

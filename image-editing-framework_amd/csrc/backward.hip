@@ -89,14 +89,157 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel(const half_t* __restrict__ 
     }
 }
 
+// Large slabs: two launches over (pixel split, batch) with 16-byte accesses, like gn_stats / gn_apply in norm.hip.
+// A thread owns ONE 8-channel chunk for all its pixels; (mean, rstd) come from the forward.
+#define GNB_MAX_GROUPS 64
+__device__ __forceinline__ half8 load_cat8b(const half_t* x, const half_t* x2, int C1, int C2, long long pix, int c) {
+    if (c < C1) return *(const half8*)(x + pix * C1 + c);
+    return *(const half8*)(x2 + pix * C2 + (c - C1));
+}
+
+// grid (splits, B): per-(batch, split, group) partial sums of g and g * xhat
+__global__ void gn_bwd_partial_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int C1, int C2,
+                                      const half_t* __restrict__ dy, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ stats,
+                                      float* __restrict__ partial, int HW, int groups, int splits, int apply_silu, int PY) {
+    const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int cx = threadIdx.x % C8, py = threadIdx.x / C8;
+    const int c = cx * 8;
+    __shared__ float g1[GNB_MAX_GROUPS], g2[GNB_MAX_GROUPS];
+    if (threadIdx.x < GNB_MAX_GROUPS) { g1[threadIdx.x] = 0.f; g2[threadIdx.x] = 0.f; }
+    __syncthreads();
+    float mean[8], rstd[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cpg;
+        mean[e] = stats[((long long)b * groups + g) * 2];
+        rstd[e] = stats[((long long)b * groups + g) * 2 + 1];
+        ga[e] = gamma[c + e]; be[e] = beta[c + e];
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = sp * per, p1 = min(HW, p0 + per);
+    for (int p = p0 + py; py < PY && p < p1; p += PY) {
+        const long long pix = (long long)b * HW + p;
+        const half8 v = load_cat8b(x, x2, C1, C2, pix, c);
+        const half8 d = *(const half8*)(dy + pix * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float h = ((float)v[e] - mean[e]) * rstd[e];
+            float g = (float)d[e];
+            if (apply_silu) g *= dsilu_f(h * ga[e] + be[e]);
+            g *= ga[e];
+            s1[e] += g; s2[e] += g * h;
+        }
+    }
+    int g_prev = c / cpg;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cpg;
+        if (g != g_prev) { atomicAdd(&g1[g_prev], a1); atomicAdd(&g2[g_prev], a2); a1 = 0.f; a2 = 0.f; g_prev = g; }
+        a1 += s1[e]; a2 += s2[e];
+    }
+    atomicAdd(&g1[g_prev], a1); atomicAdd(&g2[g_prev], a2);
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        float* o = partial + (((long long)b * splits + sp) * groups + threadIdx.x) * 2;
+        o[0] = g1[threadIdx.x]; o[1] = g2[threadIdx.x];
+    }
+}
+
+// grid (pixel blocks, B): sums the split partials (one wave per group, in LDS), then writes dx
+__global__ void gn_bwd_apply_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int C1, int C2,
+                                    const half_t* __restrict__ dy, const half_t* __restrict__ add, half_t* __restrict__ dx,
+                                    half_t* __restrict__ dx2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, const float* __restrict__ partial, int HW, int groups,
+                                    int splits, int apply_silu, int pix_per_block, int PY) {
+    const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y;
+    __shared__ float m1s[GNB_MAX_GROUPS], m2s[GNB_MAX_GROUPS];
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+        const float inv = 1.0f / ((float)cpg * (float)HW);
+        for (int g = wave; g < groups; g += nw) {
+            float a = 0.f, q = 0.f;
+            if (lane < splits) {
+                const float* o = partial + (((long long)b * splits + lane) * groups + g) * 2;
+                a = o[0]; q = o[1];
+            }
+            a = wave_sum(a); q = wave_sum(q);
+            if (lane == 0) { m1s[g] = a * inv; m2s[g] = q * inv; }
+        }
+    }
+    __syncthreads();
+    const int cx = threadIdx.x % C8, py = threadIdx.x / C8;
+    const int c = cx * 8;
+    float mean[8], rstd[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cpg;
+        mean[e] = stats[((long long)b * groups + g) * 2];
+        rstd[e] = stats[((long long)b * groups + g) * 2 + 1];
+        ga[e] = gamma[c + e]; be[e] = beta[c + e];
+        m1[e] = m1s[g]; m2[e] = m2s[g];
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    for (int p = p0 + py; py < PY && p < p1; p += PY) {
+        const long long pix = (long long)b * HW + p;
+        const half8 v = load_cat8b(x, x2, C1, C2, pix, c);
+        const half8 d = *(const half8*)(dy + pix * C + c);
+        half8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (add) a = *(const half8*)(add + pix * C + c);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float h = ((float)v[e] - mean[e]) * rstd[e];
+            float g = (float)d[e];
+            if (apply_silu) g *= dsilu_f(h * ga[e] + be[e]);
+            g *= ga[e];
+            o[e] = sat16(rstd[e] * (g - m1[e] - h * m2[e]) + (float)a[e]);
+        }
+        if (c < C1) *(half8*)(dx + pix * C1 + c) = o;
+        else *(half8*)(dx2 + pix * C2 + (c - C1)) = o;
+    }
+}
+
 extern "C" int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int C1, int C2, const ief_half* dy,
                                      const ief_half* add, ief_half* dx, ief_half* dx2, const float* gamma, const float* beta,
-                                     int B, int HW, int groups, float eps, int apply_silu, void* stream) {
+                                     const float* stats, float* partial, int B, int HW, int groups, float eps,
+                                     int apply_silu, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta) return IEF_EINVAL;
     if (C2 > 0 && (!x2 || !dx2)) return IEF_EINVAL;
     const int C = C1 + C2;
-    if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C % groups)) return IEF_ESHAPE;
+    if (B <= 0 || HW <= 0 || groups <= 0 || groups > GNB_MAX_GROUPS || C1 <= 0 || C2 < 0 || (C % groups)) return IEF_ESHAPE;
     const int cpg = C / groups;
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = (long long)HW * cpg * 2 > 48 * 1024;
+    if (big && stats && partial && !(C1 & 7) && !(C2 & 7) && C <= 8 * 1024) {
+        const int splits = ief_gn_splits(HW);
+        const int C8 = C / 8;
+        const int per = (HW + splits - 1) / splits;
+        int PYs = 256 / C8;
+        if (PYs > per) PYs = per;
+        if (PYs < 1) PYs = 1;
+        int ts = C8 * PYs;
+        if (ts < 64) ts = 64;
+        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(splits, B), dim3(ts), 0, st, x, x2, C1, C2, dy, gamma, beta, stats,
+                           partial, HW, groups, splits, apply_silu, PYs);
+        IEF_LAUNCH_CHECK();
+        int PYa = 256 / C8;
+        if (PYa < 1) PYa = 1;
+        if (PYa > HW) PYa = HW;
+        int ppb = PYa * 4;
+        if (ppb > HW) ppb = HW;
+        int ta = C8 * PYa;
+        if (ta < 64) ta = 64;
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(ta), 0, st, x, x2, C1, C2, dy, add, dx, dx2,
+                           gamma, beta, stats, partial, HW, groups, splits, apply_silu, ppb, PYa);
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
     if ((cpg & 1) || (C1 & 1) || (cpg >> 1) > 512) return IEF_ESHAPE;
     const int cp2 = cpg >> 1;
     int PY = 512 / cp2;
@@ -104,8 +247,8 @@ extern "C" int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int 
     int threads = ((cp2 * PY + 63) / 64) * 64;
     if (threads > 512) { PY -= 1; threads = ((cp2 * PY + 63) / 64) * 64; }
     if (PY < 1) return IEF_ESHAPE;
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * groups), dim3(threads), 0, (hipStream_t)stream, x, x2, C1, C2, dy, add, dx,
-                       dx2, gamma, beta, HW, groups, eps, apply_silu, PY);
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * groups), dim3(threads), 0, st, x, x2, C1, C2, dy, add, dx, dx2, gamma, beta,
+                       HW, groups, eps, apply_silu, PY);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

@@ -134,6 +134,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ x, const half_t* __re
 __global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2,
                                                        int C1, int C2, half_t* __restrict__ out,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ stats_out,
                                                        int HW, int groups, float eps, int apply_silu, int PY) {
     const int C = C1 + C2, cpg = C / groups, cp2 = cpg >> 1;
     // 4 consecutive groups per XCD: id = xcd + 8k  ->  group = 4*xcd + k%4 (needs groups % 32 == 0, else linear)
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict_
     const float inv = 1.0f / ((float)cpg * (float)HW);
     const float mean = ts * inv;
     const float rstd = rsqrtf(fmaxf(tq * inv - mean * mean, 0.f) + eps);
+    if (threadIdx.x == 0) { stats_out[((long long)b * groups + g) * 2] = mean; stats_out[((long long)b * groups + g) * 2 + 1] = rstd; }
     if (!live) return;
     const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
     const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
@@ -201,8 +203,9 @@ extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int
         if (PY > HW) PY = HW;
         int threads = ((cp2 * PY + 63) / 64) * 64;
         if (threads > 512) { PY -= 1; threads = ((cp2 * PY + 63) / 64) * 64; }
-        hipLaunchKernelGGL(gn_fused_kernel, dim3(B * groups), dim3(threads), 0, st, x, x2, C1, C2, out, gamma, beta, HW,
-                           groups, eps, apply_silu, PY);
+        // (mean, rstd) land where the three-launch path leaves them: after the split partials
+        hipLaunchKernelGGL(gn_fused_kernel, dim3(B * groups), dim3(threads), 0, st, x, x2, C1, C2, out, gamma, beta,
+                           partial + (long long)B * gn_splits_host(HW) * groups * 2, HW, groups, eps, apply_silu, PY);
         IEF_LAUNCH_CHECK();
         return IEF_OK;
     }

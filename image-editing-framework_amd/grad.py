@@ -91,14 +91,14 @@ class UNetAdjoint:
 
     # ------------------------------------------------------------------ forward, keeping what the backward reads
     def _res_fwd(self, r, x, trow, skip=None):
-        g1 = r.norm1(x, silu=True, x2=skip)
+        g1, st1 = r.norm1(x, silu=True, x2=skip, return_stats=True)
         h1 = hip.conv3x3(g1, r.conv1.weight, r.conv1.bias, rowvec=trow)
-        g2 = r.norm2(h1, silu=True)
+        g2, st2 = r.norm2(h1, silu=True, return_stats=True)
         if r.conv_shortcut is None:
             out = hip.conv3x3(g2, r.conv2.weight, r.conv2.bias, residual=x)
         else:
             out = hip.conv3x3_shortcut(g2, r.w2_fused, r.b2_fused, x, skip)
-        self.rec[id(r)] = (x, skip, h1)
+        self.rec[id(r)] = (x, skip, h1, st1, st2)
         return out
 
     def _tr_fwd(self, t, x, kv_all):
@@ -106,7 +106,8 @@ class UNetAdjoint:
         N = H * W
         blk = t.transformer_blocks[0]
         a1, a2, ff = blk.attn1, blk.attn2, blk.ff
-        h0 = t.proj_in(t.norm(x)).reshape(B, N, C)
+        hn, st0 = t.norm(x, return_stats=True)
+        h0 = t.proj_in(hn).reshape(B, N, C)
         qkv = hip.gemm(blk.norm1(h0), a1.w_qkv)
         lse1 = torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device)
         o1 = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], a1.heads, a1.scale, lse=lse1)
@@ -119,7 +120,7 @@ class UNetAdjoint:
         pre = hip.gemm(blk.norm3(h2), ff.net[0].proj.weight, bias=ff.net[0].proj.bias)
         h3 = ff.net[2](hip.geglu_il(pre), residual=h2)
         out = t.proj_out(h3.reshape(B, H, W, C), residual=x)
-        self.rec[id(t)] = (x, h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre)
+        self.rec[id(t)] = (x, h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre, st0)
         return out
 
     def forward(self, sample, temb_row, ctx16):
@@ -153,22 +154,23 @@ class UNetAdjoint:
                     h = self._tr_fwd(blk.attentions[j], h, self.kv_all)
             if blk.upsamplers is not None:
                 h = blk.upsamplers[0](h)
-        self.rec["final"] = (h,)
-        return hip.conv_out(u.conv_norm_out(h, silu=True), u.conv_out.weight, u.conv_out.bias)
+        hn, stf = u.conv_norm_out(h, silu=True, return_stats=True)
+        self.rec["final"] = (h, stf)
+        return hip.conv_out(hn, u.conv_out.weight, u.conv_out.bias)
 
     # ------------------------------------------------------------------ backward
     def _res_bwd(self, r, d_out):
-        x, skip, h1 = self.rec[id(r)]
+        x, skip, h1, st1, st2 = self.rec[id(r)]
         n1, n2 = r.norm1, r.norm2
         d_g2 = hip.conv3x3(d_out, self.wt_conv(r.conv2.weight))
-        d_h1 = hip.groupnorm_bwd(h1, d_g2, n2.weight, n2.bias, n2.num_groups, n2.eps, silu=True)
+        d_h1 = hip.groupnorm_bwd(h1, d_g2, n2.weight, n2.bias, n2.num_groups, n2.eps, silu=True, stats=st2)
         d_g1 = hip.conv3x3(d_h1, self.wt_conv(r.conv1.weight))
         add = d_out if r.conv_shortcut is None else hip.gemm(d_out, self.wt_lin(r.conv_shortcut.weight))
-        res = hip.groupnorm_bwd(x, d_g1, n1.weight, n1.bias, n1.num_groups, n1.eps, silu=True, x2=skip, add=add)
+        res = hip.groupnorm_bwd(x, d_g1, n1.weight, n1.bias, n1.num_groups, n1.eps, silu=True, x2=skip, add=add, stats=st1)
         return res if skip is not None else (res, None)
 
     def _tr_bwd(self, t, d_out, stop=False):
-        x, h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre = self.rec[id(t)]
+        x, h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre, st0 = self.rec[id(t)]
         B, H, W, C = x.shape
         N = H * W
         blk = t.transformer_blocks[0]
@@ -192,18 +194,18 @@ class UNetAdjoint:
         d_h0 = hip.layernorm_bwd(h0, hip.gemm(dqkv, self.wt_lin(a1.w_qkv)), blk.norm1.weight, blk.norm1.eps, add=d_h1)
         d_hn = hip.gemm(d_h0, self.wt_lin(t.proj_in.weight)).reshape(B, H, W, C)
         n = t.norm
-        return hip.groupnorm_bwd(x, d_hn, n.weight, n.bias, n.num_groups, n.eps, silu=False, add=d_out)
+        return hip.groupnorm_bwd(x, d_hn, n.weight, n.bias, n.num_groups, n.eps, silu=False, add=d_out, stats=st0)
 
     def backward(self, d_eps):
         """d_eps fp32 NCHW (gradient of the objective w.r.t. the UNet output, already scaled) -> fp16 [B,77,Cc]:
         the gradient w.r.t. the fp16 context the last `forward` ran on, in the same scale."""
         u = self.unet
-        (hf,) = self.rec["final"]
+        hf, stf = self.rec["final"]
         B = hf.shape[0]
         self.dkv_all = torch.empty(B, self.kv_all.shape[1], self.kv_width, dtype=torch.float16, device=hf.device)
         n = u.conv_norm_out
         d = hip.conv_out_bwd(d_eps, u.conv_out.weight)
-        d = hip.groupnorm_bwd(hf, d, n.weight, n.bias, n.num_groups, n.eps, silu=True)
+        d = hip.groupnorm_bwd(hf, d, n.weight, n.bias, n.num_groups, n.eps, silu=True, stats=stf)
         self._tap("conv_norm_out", d)
         dskips = []
         for bi in reversed(range(len(u.up_blocks))):

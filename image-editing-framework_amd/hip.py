@@ -51,7 +51,7 @@ class IefAttnBwdParams(Structure):
         ("dQ", c_void_p), ("dK", c_void_p), ("dV", c_void_p),
         ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
         ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int), ("lddq", c_int), ("lddk", c_int), ("lddv", c_int),
-        ("scale", c_float), ("ds_mul", c_float),
+        ("scale", c_float), ("ds_mul", c_float), ("kv_splits", c_int), ("ws", c_void_p),
     ]
 
 
@@ -124,7 +124,7 @@ def load():
     lib.ief_pointwise_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.ief_attn_bwd_delta_f32.argtypes = [c_void_p] * 3 + [c_int] * 6 + [c_void_p]
     lib.ief_attn_bwd_f16.argtypes = [POINTER(IefAttnBwdParams), c_int, c_void_p]
-    lib.ief_groupnorm_bwd_f16.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float,
+    lib.ief_groupnorm_bwd_f16.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_float,
                                                                                               c_int, c_void_p]
     lib.ief_layernorm_bwd_f16.argtypes = [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]
     lib.ief_geglu_il_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -608,8 +608,9 @@ def conv_out(x, w, bias, out=None):
 
 
 # ------------------------------------------------------------------------------- norms
-def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
-    """GroupNorm over NHWC / tokens-major fp16 [B, ..., C] (+ optional channel-concat x2), optional SiLU."""
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return_stats=False):
+    """GroupNorm over NHWC / tokens-major fp16 [B, ..., C] (+ optional channel-concat x2), optional SiLU.
+    return_stats: also return the fp32 (mean, rstd) [B, groups, 2] the backward reuses."""
     lib = load()
     _dev16(x, "x")
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
@@ -625,6 +626,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None):
         _check(lib.ief_groupnorm_silu_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
                                           _dev32(beta, "beta").data_ptr(), partial.data_ptr(), B, HW, groups, eps,
                                           1 if silu else 0, _stream()), "ief_groupnorm_silu_f16")
+    if return_stats:
+        return out, partial[B * splits * groups * 2:].view(B, groups, 2)
     return out
 
 
@@ -853,14 +856,22 @@ def attn_bwd(q, k, v, o, do, lse, heads, scale, dq=None, dk=None, dv=None, ds_mu
         _dev16(dk, "dk"), _dev16(dv, "dv")
         p.dK, p.dV, p.lddk, p.lddv = dk.data_ptr(), dv.data_ptr(), dk.stride(1), dv.stride(1)
         what |= 2
+        # few keys (cross-attention) => few workgroups: cut the query range so ~256 of them run
+        blocks, tiles = ((L + 127) // 128) * heads * B, (N + 63) // 64
+        if blocks < 128 and tiles >= 4:
+            p.kv_splits = max(1, min(tiles // 2, 256 // blocks))
+            if p.kv_splits > 1:
+                ws = torch.empty(2 * p.kv_splits * B * L * heads * d, dtype=torch.float32, device=q.device)
+                p.ws = ws.data_ptr()
     fl = (6.0 if want_dq else 0.0) + (8.0 if want_dkv else 0.0)
     with _Timed(f"attn_bwd_kernel<{d}>", fl * B * heads * N * L * d):
         _check(lib.ief_attn_bwd_f16(byref(p), what, _stream()), "ief_attn_bwd_f16")
     return dq, dk, dv
 
 
-def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None):
-    """dx (and dx2 for a channel-concat input) of groupnorm(x | x2) [+ SiLU]; `add` is summed into the result."""
+def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None, stats=None):
+    """dx (and dx2 for a channel-concat input) of groupnorm(x | x2) [+ SiLU]; `add` is summed into the result.
+    stats: (mean, rstd) [B, groups, 2] from `groupnorm(..., return_stats=True)` — enables the split two-launch path."""
     lib = load()
     _dev16(x, "x"), _dev16(dy, "dy")
     B, C1 = x.shape[0], x.shape[-1]
@@ -874,10 +885,16 @@ def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None
         raise ValueError("groupnorm_bwd: add must match dy")
     dx = torch.empty_like(x)
     dx2 = torch.empty_like(x2) if x2 is not None else None
+    partial = None
+    if stats is not None:
+        if tuple(_dev32(stats, "stats").shape) != (B, groups, 2):
+            raise ValueError("groupnorm_bwd: stats must be fp32 [B, groups, 2]")
+        partial = torch.empty(B * lib.ief_gn_splits(HW) * groups * 2, dtype=torch.float32, device=x.device)
     with _Timed("groupnorm_bwd", 0.0):
         _check(lib.ief_groupnorm_bwd_f16(x.data_ptr(), _ptr(x2), C1, C2, dy.data_ptr(), _ptr(add), dx.data_ptr(), _ptr(dx2),
-                                         _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups, eps,
-                                         1 if silu else 0, _stream()), "ief_groupnorm_bwd_f16")
+                                         _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), _ptr(stats),
+                                         _ptr(partial), B, HW, groups, eps, 1 if silu else 0, _stream()),
+               "ief_groupnorm_bwd_f16")
     return (dx, dx2) if x2 is not None else dx
 
 

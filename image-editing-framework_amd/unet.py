@@ -85,8 +85,8 @@ class GroupNorm(nn.Module):
         super().__init__()
         self.weight, self.bias, self.num_groups, self.eps = weight, bias, num_groups, eps
 
-    def forward(self, x, silu=False, x2=None):
-        return hip.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2)
+    def forward(self, x, silu=False, x2=None, return_stats=False):
+        return hip.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2, return_stats=return_stats)
 
 
 class LayerNorm(nn.Module):

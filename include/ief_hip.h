@@ -93,7 +93,8 @@ int ief_conv_out_f32(const ief_half* x, const ief_half* w, const float* bias, fl
 /* ------------------------------------------------------------------ normalisation
  * GroupNorm over NHWC (+ optional SiLU): ResnetBlock2D.norm1/norm2 + nonlinearity
  * (/root/reference/pnp/model/register.py:105-110,149-158), Transformer2DModel.norm, conv_norm_out.
- * `partial` is scratch of >= B * (splits + 1) * groups * 2 floats (splits = ief_gn_splits(HW)).
+ * `partial` is scratch of >= B * (splits + 1) * groups * 2 floats (splits = ief_gn_splits(HW)); on completion its
+ * LAST B * groups * 2 floats hold (mean, rstd) per (batch, group) — what ief_groupnorm_bwd_f16 takes as `stats`.
  * Two sources (x, x2) = channel concat [C1 | C2] normalised as one tensor, written to out [.., C1+C2].
  */
 int ief_gn_splits(int HW);
@@ -199,6 +200,10 @@ typedef struct IefAttnBwdParams {
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float scale;
     float ds_mul;         /* dS is multiplied by this before its fp16 rounding (undone in fp32); > 0 */
+    /* dK/dV with few keys (cross-attention: 77) own too few workgroups: kv_splits > 1 cuts the query range into that many
+     * slices, each writing fp32 partials to ws (>= 2 * kv_splits * B * L * heads * d floats), summed in a fixed order. */
+    int kv_splits;
+    float* ws;
 } IefAttnBwdParams;
 /* delta[b][h][n] = sum_d dO * O  (the softmax-backward row term) */
 int ief_attn_bwd_delta_f32(const ief_half* O, const ief_half* dO, float* delta, int B, int heads, int N, int d,
@@ -206,10 +211,12 @@ int ief_attn_bwd_delta_f32(const ief_half* O, const ief_half* dO, float* delta, 
 /* what: 1 = dQ, 2 = dK and dV, 3 = all.  d in {32,40,64,80,160}; any N, L >= 1. */
 int ief_attn_bwd_f16(const IefAttnBwdParams* p, int what, void* stream);
 /* GroupNorm(+SiLU) backward w.r.t. the input: x (+x2 channel concat) is the forward INPUT, dy [B][HW][C1+C2] the gradient
- * of the output, `add` (optional, same shape as dy) is added to the result; dx [B][HW][C1], dx2 [B][HW][C2]. */
+ * of the output, `add` (optional, same shape as dy) is added to the result; dx [B][HW][C1], dx2 [B][HW][C2].
+ * stats: (mean, rstd) [B][groups][2] saved by the forward, or NULL (recomputed); partial: scratch of
+ * >= B * ief_gn_splits(HW) * groups * 2 floats, or NULL (forces the one-workgroup-per-group kernel). */
 int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int C1, int C2, const ief_half* dy, const ief_half* add,
-                          ief_half* dx, ief_half* dx2, const float* gamma, const float* beta, int B, int HW, int groups,
-                          float eps, int apply_silu, void* stream);
+                          ief_half* dx, ief_half* dx2, const float* gamma, const float* beta, const float* stats,
+                          float* partial, int B, int HW, int groups, float eps, int apply_silu, void* stream);
 /* LayerNorm backward w.r.t. the input (+ optional `add`) */
 int ief_layernorm_bwd_f16(const ief_half* x, const ief_half* dy, const ief_half* add, ief_half* dx, const float* gamma,
                           int rows, int C, float eps, void* stream);

@@ -81,7 +81,8 @@ def test_attn_bwd_strided_outputs():
 
 # ------------------------------------------------------------------------------------------------ norms, GEGLU
 @pytest.mark.parametrize("C1,C2,HW,silu", [(320, 0, 1024, True), (640, 320, 256, True), (1280, 640, 64, True),
-                                           (64, 0, 256, False), (128, 64, 16, True), (320, 0, 4096, False)])
+                                           (64, 0, 256, False), (128, 64, 16, True), (320, 0, 4096, False),
+                                           (640, 320, 4096, True), (640, 640, 1024, True)])
 def test_groupnorm_bwd_vs_autograd(C1, C2, HW, silu):
     B, G, C = 2, 32, C1 + C2
     x, x2 = h16(B, HW, C1, seed=1), (h16(B, HW, C2, seed=2) if C2 else None)
@@ -89,17 +90,23 @@ def test_groupnorm_bwd_vs_autograd(C1, C2, HW, silu):
     g = torch.Generator().manual_seed(5)
     gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
     beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
-    got = hip.groupnorm_bwd(x, dy, gamma, beta, G, 1e-5, silu=silu, x2=x2, add=add)
     xin = (torch.cat([x, x2], -1) if C2 else x).float().requires_grad_(True)
     y = F.group_norm(xin.transpose(1, 2), G, gamma, beta, 1e-5).transpose(1, 2)
     (F.silu(y) if silu else y).backward(dy.float())
     ref = xin.grad + add.float()
-    if C2:
-        e = max(rel_err(got[0], ref[..., :C1]), rel_err(got[1], ref[..., C1:]))
-    else:
-        e = rel_err(got, ref)
-    print(f"groupnorm_bwd C={C1}+{C2} HW={HW} silu={silu}: {e:.2e}")
-    assert e < 1e-2
+    # the forward's saved statistics: what the split two-launch path (large slabs) consumes
+    _, st = hip.groupnorm(x, gamma, beta, G, 1e-5, silu=silu, x2=x2, return_stats=True)
+    xg = xin.detach().reshape(B, HW, G, C // G).permute(0, 2, 1, 3).reshape(B, G, -1)
+    assert rel_err(st[..., 0], xg.mean(-1)) < 1e-3 or xg.mean(-1).abs().max() < 1e-2
+    assert rel_err(st[..., 1], (xg.var(-1, unbiased=False) + 1e-5).rsqrt()) < 1e-3
+    for stats in (None, st):
+        got = hip.groupnorm_bwd(x, dy, gamma, beta, G, 1e-5, silu=silu, x2=x2, add=add, stats=stats)
+        if C2:
+            e = max(rel_err(got[0], ref[..., :C1]), rel_err(got[1], ref[..., C1:]))
+        else:
+            e = rel_err(got, ref)
+        print(f"groupnorm_bwd C={C1}+{C2} HW={HW} silu={silu} stats={'saved' if stats is not None else 'recomputed'}: {e:.2e}")
+        assert e < 1e-2
 
 
 @pytest.mark.parametrize("C", [64, 320, 1280])
