@@ -16,8 +16,9 @@ import bench
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join("gpurun_out", "tuned_plans.json")
 cfg_name = sys.argv[2] if len(sys.argv) > 2 else "sd15"
 dev = torch.device("cuda:0")
-os.environ["IEF_NO_PLAN_TABLE"] = "1"
-hip._plans = {}
+if os.environ.get("IEF_TUNE_KEEP", "0") != "1":      # IEF_TUNE_KEEP=1: keep the committed table, tune only missing shapes
+    os.environ["IEF_NO_PLAN_TABLE"] = "1"
+    hip._plans = {}
 hip.AUTOTUNE = True
 pipe, cfg = bench.build_pipe(cfg_name, dev, 0, 1)
 hw = cfg.sample_size
@@ -28,6 +29,16 @@ for B in (4, 2, 1):
         pipe.unet(x, 501, encoder_hidden_states=ctx)
     torch.cuda.synchronize()
     print(f"B={B}: {len(hip._plan_table())} shapes tuned", flush=True)
+# null-text optimisation: the data-gradient GEMMs / convs of the reverse pass at batch 1 (grad.UNetAdjoint)
+from ief_amd.grad import UNetAdjoint
+adj = UNetAdjoint(pipe.unet)
+x = torch.randn(1, 4, hw, hw, device=dev)
+ctx16 = (torch.randn(1, 77, cfg.cross_attention_dim, device=dev) * 0.1).half()
+temb = pipe.unet.time_rows(torch.tensor([501.0], device=dev))
+eps = adj.forward(x, temb, ctx16)
+adj.backward(torch.randn_like(eps).contiguous())
+torch.cuda.synchronize()
+print(f"NTI reverse pass: {len(hip._plan_table())} shapes tuned", flush=True)
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 hip.save_plans(out)
 for k, v in sorted(hip._plan_table().items()):
