@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     half_t* As = smem;
     half_t* Bs = smem + NS * ROWS_A * BK;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases (m0) stay on the scalar unit
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -71,21 +72,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     // the LDS slot (tid&7) of a lane is fixed by LDS-DMA; the swizzle is applied to the chunk FETCHED
     const unsigned kcb = (unsigned)(((tid & 7) ^ ((rbase >> 1) & 7)) * 16);   // byte offset of that chunk in the K row
 
-    // ---- per-row state
+    const int nk_all = (p.K + BK - 1) / BK;
+    int kt_lo = 0, nk = nk_all;
+    if (p.splits > 1) {  // this block's K slice
+        const int per = (nk_all + p.splits - 1) / p.splits;
+        kt_lo = blockIdx.y * per;
+        nk = min(nk_all, kt_lo + per);
+    }
+    // K % 64 != 0 (never on the UNet's shapes): chunks of the LAST K tile that lie past K read the zero page
+    const bool ktail = (p.K & (BK - 1)) != 0;
+    const bool tail_zero = (unsigned)(nk_all - 1) * (BK * 2) + kcb >= (unsigned)p.K * 2u;
+
+    // ---- staging state: one 64-bit source pointer per LDS-DMA piece, advanced by one K tile (128 B) per stage.
+    // Rows that are out of range (M / N tails, conv padding) point at the zero page and do not advance, so the
+    // per-tile address work is one 64-bit add per piece; the pointers are rebuilt only when the conv tap or the
+    // concat source changes.
+    const char* pa[NA];
+    unsigned sa[NA];
+    const char* pw[NB];
+    unsigned sw[NB];
     bool a_ok[NA];
-    unsigned a_off[NA];           // dense: byte offset of the row's chunk
     int a_y[NA], a_x[NA], a_b[NA];
     unsigned a_m[NA];
-    bool a_live[NA];              // conv: row ok AND current tap in bounds
-    unsigned w_off[NB];
-    bool w_ok[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = rbase + RP * i;
         const int m = m0 + r;
         a_ok[i] = r < BM && m < p.M;
         a_m[i] = (unsigned)m;
-        a_live[i] = a_ok[i];
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, rem = m - b * hw;
@@ -93,24 +107,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
             a_b[i] = b;
             a_y[i] = oy * p.stride - (p.pad_hi_only ? 0 : 1);
             a_x[i] = ox * p.stride - (p.pad_hi_only ? 0 : 1);
-            a_off[i] = 0;
+            pa[i] = zp; sa[i] = 0;
         } else {
-            a_off[i] = (unsigned)m * (unsigned)p.lda * 2u + kcb;
             a_b[i] = a_y[i] = a_x[i] = 0;
+            pa[i] = a_ok[i] ? A + ((unsigned long long)(unsigned)m * (unsigned)p.lda * 2ull + kcb + (unsigned long long)kt_lo * (BK * 2)) : zp;
+            sa[i] = a_ok[i] ? BK * 2 : 0;
         }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int r = rbase + RP * i;
         const int n = n0 + r;
-        w_ok[i] = r < BN && n < p.N;
-        w_off[i] = (unsigned)n * (unsigned)p.ldw * 2u + kcb;
+        const bool ok = r < BN && n < p.N;
+        pw[i] = ok ? Wt + ((unsigned long long)(unsigned)n * (unsigned)p.ldw * 2ull + kcb + (unsigned long long)kt_lo * (BK * 2)) : zp;
+        sw[i] = ok ? BK * 2 : 0;
     }
 
     // ---- conv K iterator: (tap, channel offset) advanced by one K tile per stage
     const int Ctot = p.C1 + p.C2;
     const int Hp = p.H >> p.ups, Wp = p.Wd >> p.ups;
     int it_tap = 0, it_c = 0;           // tap 0..8 = 3x3 taps, 9 = fused-1x1 extra range
+    bool a_live[NA];
     unsigned r1[NA], r2[NA];            // byte offsets of the row's pixel in source 1 / source 2 (+ chunk)
     auto set_tap = [&](int tap) {
         if (tap < 9) {
@@ -132,34 +149,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
             }
         }
     };
+    // pointers of the current (tap, channel offset): source 1 below c1 channels, source 2 above
+    auto set_src = [&]() {
+        const char* s1 = it_tap < 9 ? A : (const char*)p.E1;
+        const char* s2 = it_tap < 9 ? (const char*)p.A2 : (const char*)p.E2;
+        const int c1 = it_tap < 9 ? p.C1 : p.CE1;
+        const bool first = it_c < c1;
+        const char* src = first ? s1 : s2;
+        const unsigned cc = (unsigned)(first ? it_c : it_c - c1) * 2u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            pa[i] = a_live[i] ? src + ((first ? r1[i] : r2[i]) + cc) : zp;
+            sa[i] = a_live[i] ? BK * 2 : 0;
+        }
+    };
 
     auto stage_tile = [&](int buf, int kt) {
-        const unsigned k0b = (unsigned)kt * (BK * 2);
         half_t* la = As + buf * ROWS_A * BK + (wave * 8) * BK;
         half_t* lb = Bs + buf * ROWS_B * BK + (wave * 8) * BK;
-        if constexpr (CONV) {
-            const char* s1 = it_tap < 9 ? A : (const char*)p.E1;
-            const char* s2 = it_tap < 9 ? (const char*)p.A2 : (const char*)p.E2;
-            const int c1 = it_tap < 9 ? p.C1 : p.CE1;
-            const bool first = it_c < c1;
-            const char* src = first ? s1 : s2;
-            const unsigned cc = (unsigned)(first ? it_c : it_c - c1) * 2u;
+        const bool tz = ktail && kt == nk_all - 1 && tail_zero;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const unsigned off = (first ? r1[i] : r2[i]) + cc;
-                glds16(a_live[i] ? src + off : zp, la + RP * i * BK);
-            }
-            // advance the iterator by one K tile
-            it_c += BK;
-            if (it_tap < 9 && it_c >= Ctot) { it_c = 0; ++it_tap; set_tap(it_tap); }
-        } else {
-            const bool kok = k0b + kcb < (unsigned)p.K * 2u;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) glds16((a_ok[i] && kok) ? A + (a_off[i] + k0b) : zp, la + RP * i * BK);
+        for (int i = 0; i < NA; ++i) {
+            glds16(tz ? zp : pa[i], la + RP * i * BK);
+            pa[i] += sa[i];
         }
-        const bool kok = k0b + kcb < (unsigned)p.K * 2u;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16((w_ok[i] && kok) ? Wt + (w_off[i] + k0b) : zp, lb + RP * i * BK);
+        for (int i = 0; i < NB; ++i) {
+            glds16(tz ? zp : pw[i], lb + RP * i * BK);
+            pw[i] += sw[i];
+        }
+        if constexpr (CONV) {   // advance the iterator by one K tile; rebuild the pointers at tap / source boundaries
+            it_c += BK;
+            if (it_tap < 9) {
+                if (it_c >= Ctot) { it_c = 0; ++it_tap; set_tap(it_tap); set_src(); }
+                else if (it_c == p.C1) set_src();
+            } else if (it_c == p.CE1 && p.CE2 > 0) {
+                set_src();
+            }
+        }
     };
 
     f32x4 acc[TM][TN];
@@ -168,56 +195,97 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk_all = (p.K + BK - 1) / BK;
-    int kt_lo = 0, nk = nk_all;
-    if (p.splits > 1) {  // this block's K slice
-        const int per = (nk_all + p.splits - 1) / p.splits;
-        kt_lo = blockIdx.y * per;
-        nk = min(nk_all, kt_lo + per);
-    }
     if constexpr (CONV) {
         const int k0 = kt_lo * BK;
         if (k0 < 9 * Ctot) { it_tap = k0 / Ctot; it_c = k0 - it_tap * Ctot; }
         else { it_tap = 9; it_c = k0 - 9 * Ctot; }
         set_tap(it_tap);
+        set_src();
     }
     const int fr = lane & 15, fq = lane >> 4;
-    // NS-deep LDS ring: K tiles kt .. kt+NS-2 are in flight while tile kt is multiplied.  Order per iteration:
+    // fragment offsets (halves) inside one ring slot: row * 64 + swizzled chunk; k-step 1 flips chunk bit 2
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wr * WM + i * 16 + fr;
+        aoff[i] = row * BK + ((fq ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wc * WN + j * 16 + fr;
+        boff[j] = row * BK + ((fq ^ ((row >> 1) & 7)) << 3);
+    }
+    // One K tile: both k-steps' fragments are requested up front, so the second set's LDS latency hides behind the
+    // first set's MFMAs (the compiler turns the two uses into counted lgkmcnt waits).
+    half8 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    auto read_frags = [&](const half_t* Ac, const half_t* Bc) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af0[i] = *(const half8*)(Ac + aoff[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf0[j] = *(const half8*)(Bc + boff[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af1[i] = *(const half8*)(Ac + (aoff[i] ^ 32));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf1[j] = *(const half8*)(Bc + (boff[j] ^ 32));
+    };
+    auto mfma_frags = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0[i], bf0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[i], bf1[j], acc[i][j], 0, 0, 0);
+    };
+    // NS-deep LDS ring: K tiles kt .. kt+NS-2 are in flight while tile kt is multiplied.  Order per tile (interval
+    // between two barriers):
     //   counted vmcnt (this wave's share of tile kt has landed)  ->  s_barrier (everybody's has; everybody is done
-    //   reading the buffer tile kt-1 used)  ->  issue tile kt+NS-1 into that buffer  ->  MFMAs on tile kt.
-    // Raw s_barrier + counted waits: __syncthreads() would drain every LDS-DMA in flight.
+    //   reading the slot tile kt-1 used)  ->  issue tile kt+NS-1 into that slot  ->  fragments + MFMAs of tile kt.
+    // Raw s_barrier + counted waits: __syncthreads() would drain every LDS-DMA in flight.  The loop is unrolled NS
+    // times so every slot index is a compile-time constant.
+    // 8-wave tiles, NS >= 3: the two waves of a SIMD would run that sequence in lockstep (both issuing LDS-DMA, then
+    // both multiplying).  Waves 4..7 therefore run HALF A TILE LATE: in interval kt they first multiply tile kt-1 from
+    // fragments they read (and waited for) before the barrier, then stage and read tile kt — so each SIMD always has one
+    // wave on the matrix pipe while its partner issues DMA / LDS reads.  Same barriers, same slots, same sums.
+    constexpr bool PINGPONG = (WAVES_M * WAVES_N == 8) && NS >= 3;
+    const bool late = PINGPONG && wave >= 4;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (kt_lo + s < nk) stage_tile(s, kt_lo + s);
-    for (int kt = kt_lo; kt < nk; ++kt) {
-        const int rel = kt - kt_lo;
-        const int cur = rel % NS;
-        if (nk - 1 - kt >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        if (kt + NS - 1 < nk) stage_tile((rel + NS - 1) % NS, kt + NS - 1);
-        const half_t* Ac = As + cur * ROWS_A * BK;
-        const half_t* Bc = Bs + cur * ROWS_B * BK;
+    if (!late) {
+        for (int kt = kt_lo; kt < nk; kt += NS) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 af[TM], bf[TN];
-            const int chunk = ks * 4 + fq;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wr * WM + i * 16 + fr;
-                af[i] = *(const half8*)(Ac + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            for (int s = 0; s < NS; ++s) {
+                const int k = kt + s;
+                if (k < nk) {
+                    if (nk - 1 - k >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS, k + NS - 1);
+                    read_frags(As + s * ROWS_A * BK, Bs + s * ROWS_B * BK);
+                    mfma_frags();
+                }
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wc * WN + j * 16 + fr;
-                bf[j] = *(const half8*)(Bc + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+    } else {
+        for (int kt = kt_lo; kt < nk; kt += NS) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k = kt + s;
+                if (k < nk) {
+                    if (nk - 1 - k >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 2)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    if (k > kt_lo) mfma_frags();                                   // tile k-1, fragments already in registers
+                    if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS, k + NS - 1);
+                    read_frags(As + s * ROWS_A * BK, Bs + s * ROWS_B * BK);         // tile k: landed (barrier above)
+                }
+            }
+        }
+        if (nk > kt_lo) mfma_frags();
     }
     __syncthreads();   // all fragment reads done before the staging buffers become the epilogue's scratch
 
