@@ -33,6 +33,11 @@ struct AttnCfg {
     // D not a multiple of 32 leaves padding rows in the last O^T tile: row D of V^T is set to all ones, so
     // the PV MFMA itself accumulates the softmax row sum (O^T[D][q] = sum_kv P[q][kv]) at no VALU cost.
     static constexpr bool ONES_ROW = (D % 32) != 0;
+    // D not a multiple of 16 leaves padding columns in the K tile / Q fragments (k = D .. DP-1 of the score MFMA):
+    // K[key][D] is set to 1 and Q^T[D][q] to -m_run[q], so the MFMA itself subtracts the running row maximum and the
+    // accumulators can start from the constant 0 (no per-lane 16-register init vector, no per-element subtraction).
+    static constexpr bool FOLD_MAX = (D % 16) != 0;
+    static constexpr int PAD_S = D / 16, PAD_H = (D % 16) / 8, PAD_E = (D % 16) % 8;   // k-step / lane half / element of column D
 };
 
 template <bool B>
@@ -116,6 +121,11 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     if constexpr (C::ONES_ROW) {  // column D of V = 1: the PV MFMA then accumulates the softmax row sum in O^T[D][q]
         __syncthreads();
         if (tid < 128) Vs[(tid >> 6) * VBUF + (tid & 63) * VRS + D] = (half_t)1.0f;
+        if constexpr (C::FOLD_MAX)
+            if (tid < 128) Ks[(tid >> 6) * KBUF + (tid & 63) * C::KS + D] = (half_t)1.0f;
+    } else if constexpr (C::FOLD_MAX) {
+        __syncthreads();
+        if (tid < 128) Ks[(tid >> 6) * KBUF + (tid & 63) * C::KS + D] = (half_t)1.0f;
     }
 
     // Q fragments pre-multiplied by scale*log2(e): scores come out of the MFMA in log2 units, so the softmax
@@ -192,7 +202,13 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
     // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  `masked` is a compile-time tag so the
     // full tiles carry no bounds code at all.
     auto tile_body = [&](int kv0, const half_t* Kc, const half_t* Vc, auto masked) -> bool {
-        f32x16 s0 = minit, s1 = minit;
+        f32x16 s0, s1;
+        if constexpr (C::FOLD_MAX) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        } else {
+            s0 = minit; s1 = minit;
+        }
 #pragma unroll
         for (int s = 0; s < C::D16; ++s) {
             const half8 k0 = *(const half8*)(Kc + k_lane + 16 * s);
@@ -208,19 +224,33 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
                 if (kv0 + 32 + kvl >= p.L) s1[i] = -INFINITY;
             }
         }
-        float mx = fmaxf(s0[0], s1[0]);
+        // this lane's 32 scores (two independent max3 chains); the other half of the row lives in lane^32, but the
+        // common case only needs to know that NOBODY exceeds the threshold, which __any answers without a shuffle
+        float mxa = fmaxf(s0[0], s1[0]), mxb = fmaxf(s0[8], s1[8]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0[i]), s1[i]);   // one v_max3 per pair
-        mx = fmaxf(mx, __shfl_xor(mx, 32));          // this row's maximum, relative to m_run
+        for (int i = 1; i < 8; ++i) {
+            mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, s0[i]), s1[i]);
+            mxb = __builtin_fmaxf(__builtin_fmaxf(mxb, s0[8 + i]), s1[8 + i]);
+        }
+        float mx = fmaxf(mxa, mxb);
         if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {   // wave-uniform; rare after the first tile
             // move the reference maximum, rescale what was accumulated under the old one, and REDO this tile's
             // scores against the new reference (nothing of this tile has been consumed yet).  Keeping the
             // correction off the fall-through path keeps the accumulators in place in the hot loop.
-            const float delta = first ? mx : fmaxf(mx, 0.f);
-            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
-            m_run += delta;
+            mx = fmaxf(mx, __shfl_xor(mx, 32));          // this row's maximum, relative to m_run
+            float delta = first ? mx : fmaxf(mx, 0.f);
+            if constexpr (C::FOLD_MAX) {
+                // the reference lives in an fp16 operand: move it by an amount that keeps it exactly representable
+                const float m_new = (float)(half_t)(m_run + delta);
+                delta = m_new - m_run;
+                m_run = m_new;
+                if (h == C::PAD_H) qf[C::PAD_S][C::PAD_E] = (half_t)(-m_new);
+            } else {
+                m_run += delta;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) minit[i] = -m_run;
+                for (int i = 0; i < 16; ++i) minit[i] = -m_run;
+            }
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
             if constexpr (!C::ONES_ROW) l_run *= alpha;
 #pragma unroll
             for (int t = 0; t < C::DT; ++t)
@@ -633,6 +663,28 @@ extern "C" int ief_attn_flash_f16(const IefAttnParams* pp, void* stream) {
     DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
     IEF_LAUNCH_CHECK();
     return IEF_OK;
+}
+
+// diagnostics: resident workgroups per CU the runtime grants attn_flash_kernel<d> (occupancy of the hot attention kernel)
+extern "C" int ief_attn_flash_occupancy(int d) {
+    int n = -1;
+    hipError_t e = hipErrorInvalidValue;
+    if (d == 40) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_flash_kernel<40>, 256, 0);
+    else if (d == 80) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_flash_kernel<80>, 256, 0);
+    else if (d == 160) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_flash_kernel<160>, 256, 0);
+    return e == hipSuccess ? n : -(int)e;
+}
+extern "C" int ief_attn_flash_attrs(int* out) {   // {numRegs, sharedSizeBytes, maxThreadsPerBlock, localSizeBytes, device LDS per CU}
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, (const void*)attn_flash_kernel<40>) != hipSuccess) return -1;
+    out[0] = a.numRegs; out[1] = (int)a.sharedSizeBytes; out[2] = a.maxThreadsPerBlock; out[3] = (int)a.localSizeBytes;
+    int v = 0; hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, 0); out[4] = v;
+    for (int dyn = 0; dyn < 6; ++dyn) {
+        int n = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_flash_kernel<40>, 256, dyn * 8192);
+        out[5 + dyn] = n;
+    }
+    return 0;
 }
 
 extern "C" int ief_attn_cross_p2p_f16(const IefCrossParams* pp, void* stream) {

@@ -11,7 +11,8 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_longlo
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libief_hip.so")
+# IEF_HIP_LIB / IEF_PLAN_FILE: A/B two builds of the library (and their tuned tables) on one GPU box
+_LIB_PATH = os.environ.get("IEF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libief_hip.so")
 _lib = None
 
 
@@ -234,7 +235,7 @@ _SPLIT_MIN_KT = int(os.environ.get("IEF_SPLIT_MIN_KT", "6"))     # K tiles (of 6
 # ---- plan selection: tuned table first, heuristic otherwise -----------------------------------------
 # `tuned_plans.json` (next to this file) maps "conv|M|N|K" / "gemm|M|N|K" -> [tile, splits]; it is produced
 # on the GPU by `autotune_plan` (tests/tune_plans.py) and covers the SD1.5 layer shapes at batch 1 / 2 / 4.
-_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans.json")
+_PLAN_FILE = os.environ.get("IEF_PLAN_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans.json")
 _plans = None
 AUTOTUNE = os.environ.get("IEF_AUTOTUNE", "0") == "1"   # tune unseen shapes on first use (outside graph capture)
 
