@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     constexpr int STAGE_HALFS = NS * (ROWS_A + ROWS_B) * BK;
     constexpr int G = NA + NB;                      // LDS-DMA instructions a wave issues per K tile
-    constexpr int EPI_HALFS = 64 * (BN + 4) * 2;     // fp32 [64][BN+4]
+    constexpr int EPI_HALFS = (64 * (BN + 4) + 64 * (BN / 8) * 2 + 128) * 2;   // fp32 [64][BN+4] + row-moment partials [64][BN/8][2] + row mean / rstd [2][64]
     __shared__ __attribute__((aligned(16))) half_t smem[STAGE_HALFS > EPI_HALFS ? STAGE_HALFS : EPI_HALFS];
     half_t* As = smem;
     half_t* Bs = smem + NS * ROWS_A * BK;
@@ -294,8 +294,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     constexpr int NPASS = (BM + 63) / 64;
     constexpr int CH = BN / 8;
     float* stage = (float*)smem;
+    float* rpart = stage + 64 * LDS_N;               // [64][CH][2] partial (sum, sumsq) per output chunk
+    float* row_mu = rpart + 64 * CH * 2;             // folded LayerNorm: mean and rstd of the 64 rows of a pass
+    float* row_rs = row_mu + 64;
     half_t* __restrict__ Out = p.Out + z * p.strideO;
     for (int pass = 0; pass < NPASS; ++pass) {
+        if (p.rstat_in && tid < 64) {
+            const int m = m0 + pass * 64 + tid;
+            float s1 = 0.f, s2 = 0.f;
+            if (m < p.M) {
+                const float* rs = p.rstat_in + (long long)m * p.rstat_slots * 2;
+                for (int t = 0; t < p.rstat_slots; ++t) { s1 += rs[2 * t]; s2 += rs[2 * t + 1]; }
+            }
+            const float mu = s1 / (float)p.K;
+            row_mu[tid] = mu;
+            row_rs[tid] = rsqrtf(fmaxf(s2 / (float)p.K - mu * mu, 0.f) + p.ln_eps);
+        }
         if ((wr * WM) / 64 == pass) {
             const int rb0 = wr * WM - pass * 64;
 #pragma unroll
@@ -317,10 +331,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                 if (m < p.M && n < p.N) {
                     const float* sp = stage + row * LDS_N + pc * 16;
                     float hv[8], gv[8];
+                    const float rs_ = p.rstat_in ? row_rs[row] : 1.f, mu_ = p.rstat_in ? row_mu[row] : 0.f;
 #pragma unroll
                     for (int q4 = 0; q4 < 2; ++q4) {
-                        const f32x4 a = *(const f32x4*)(sp + 4 * q4), g = *(const f32x4*)(sp + 8 + 4 * q4);
+                        f32x4 a = *(const f32x4*)(sp + 4 * q4), g = *(const f32x4*)(sp + 8 + 4 * q4);
                         const f32x4 ba = *(const f32x4*)(p.bias + n + 4 * q4), bg = *(const f32x4*)(p.bias + n + 8 + 4 * q4);
+                        if (p.rstat_in) {
+                            const f32x4 ca = *(const f32x4*)(p.colsum + n + 4 * q4), cg = *(const f32x4*)(p.colsum + n + 8 + 4 * q4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { a[e] = rs_ * (a[e] - mu_ * ca[e]); g[e] = rs_ * (g[e] - mu_ * cg[e]); }
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { hv[4 * q4 + e] = a[e] + ba[e]; gv[4 * q4 + e] = g[e] + bg[e]; }
                     }
@@ -346,6 +366,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                     continue;
                 }
                 float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                if (p.rstat_in) {
+                    const float rs_ = row_rs[row], mu_ = row_mu[row];
+                    const f32x4 c0 = *(const f32x4*)(p.colsum + n), c1 = *(const f32x4*)(p.colsum + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = rs_ * (v[e] - mu_ * c0[e]); v[4 + e] = rs_ * (v[4 + e] - mu_ * c1[e]); }
+                }
                 if (p.bias) {
                     const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
 #pragma unroll
@@ -366,9 +392,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
                 *(half8*)(Out + (long long)m * p.ldo + n) = o;
+                if (p.rstat_out) {   // moments of what the consumer will read (the fp16-rounded values)
+                    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)o[e]; a1 += f; a2 += f * f; }
+                    rpart[(row * CH + nc) * 2] = a1;
+                    rpart[(row * CH + nc) * 2 + 1] = a2;
+                }
+            } else if (p.rstat_out) {
+                rpart[(row * CH + nc) * 2] = 0.f;
+                rpart[(row * CH + nc) * 2 + 1] = 0.f;
             }
         }
         __syncthreads();
+        if (p.rstat_out && tid < PROWS) {   // fixed summation order: deterministic
+            const int m = m0 + pass * 64 + tid;
+            if (m < p.M) {
+                float a1 = 0.f, a2 = 0.f;
+                for (int c = 0; c < CH; ++c) { a1 += rpart[(tid * CH + c) * 2]; a2 += rpart[(tid * CH + c) * 2 + 1]; }
+                float* ro = p.rstat_out + ((long long)m * tiles_n + (n0 / BN)) * 2;
+                ro[0] = a1; ro[1] = a2;
+            }
+        }
     }
 }
 
@@ -467,6 +512,15 @@ static int dispatch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     return launch_igemm<64, 64, 2, 2, CONV>(p, batch, st);
 }
 
+extern "C" int ief_gemm_tile_bn(int tile_hint) {
+    switch (tile_hint) {
+        case 1: case 2: case 8: case 9: return 128;
+        case 3: case 4: return 64;
+        case 5: case 6: case 7: return 160;
+        default: return 0;
+    }
+}
+
 static int check_common(const IefGemmParams& p) {
     if (!p.A || !p.W || !p.Out || !p.zeros) return IEF_EINVAL;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IEF_ESHAPE;
@@ -477,8 +531,10 @@ static int check_common(const IefGemmParams& p) {
     if (p.splits > 64) return IEF_ESHAPE;
     if (p.stages != 0 && (p.stages < 2 || p.stages > 4)) return IEF_ESHAPE;
     if (p.flags & 2) {  // fused GEGLU epilogue
-        if (!p.bias || p.rowvec || p.residual || p.splits > 1 || (p.N & 15)) return IEF_EINVAL;
+        if (!p.bias || p.rowvec || p.residual || p.splits > 1 || (p.N & 15) || p.rstat_out) return IEF_EINVAL;
     }
+    if (p.rstat_in && (!p.colsum || p.rstat_slots <= 0 || p.splits > 1 || !(p.ln_eps > 0.f))) return IEF_EINVAL;
+    if (p.rstat_out && p.splits > 1) return IEF_EINVAL;
     // 32-bit byte offsets inside each operand
     if ((long long)p.N * p.ldw * 2 >= (1ll << 32)) return IEF_ESHAPE;
     return IEF_OK;

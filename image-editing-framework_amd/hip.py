@@ -33,6 +33,7 @@ class IefGemmParams(Structure):
         ("E1", c_void_p), ("E2", c_void_p), ("CE1", c_int), ("CE2", c_int),
         ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p), ("stages", c_int),
         ("pad_hi_only", c_int),
+        ("rstat_out", c_void_p), ("rstat_in", c_void_p), ("rstat_slots", c_int), ("colsum", c_void_p), ("ln_eps", c_float),
     ]
 
 
@@ -75,7 +76,7 @@ EXPORTS = [
     "ief_softmax_rows_f16", "ief_transpose_f16", "ief_pointwise_f32",
     "ief_attn_bwd_delta_f32", "ief_attn_bwd_f16", "ief_groupnorm_bwd_f16", "ief_layernorm_bwd_f16", "ief_geglu_il_f16",
     "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
-    "ief_nti_loss_grad_f32", "ief_nti_adam_f32",
+    "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn",
 ]
 
 
@@ -397,10 +398,13 @@ def _rows_ld(t, name):
 
 # ------------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0, splits=1,
-         stages=2, geglu=False):
+         stages=2, geglu=False, ln=None, row_stats=False):
     """out[..., n] = (a[..., :] . w[n, :] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale
 
     a: fp16 [..., K] (last dim contiguous, uniform row stride); w: fp16 [N, K]; bias/rowvec fp32.
+    LayerNorm folding (see include/ief_hip.h): `row_stats=True` also returns the per-row moments of the output,
+    a fp32 [M, tiles_n, 2] tensor; `ln=(stats, colsum, eps)` consumes the moments of `a`'s rows: the product is then
+    rstd * (a . w - mean * colsum) + bias, i.e. LayerNorm(a) . W^T when w = W * gamma and bias carries beta . W^T.
     """
     lib = load()
     M, K, lda = _rows_ld(a, "a")
@@ -436,17 +440,29 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
                                                                       geglu=geglu))
             del wc
         p.tile_hint, p.splits, p.stages = pick_plan(M, N, K)
-        if geglu and p.splits > 1:
+        if (geglu or ln is not None or row_stats) and p.splits > 1:
             p.tile_hint, p.splits, p.stages = heuristic_plan(M, N, K)[0], 1, 2
     else:
         p.tile_hint, p.splits, p.stages = tile_hint, max(1, splits), stages
     if p.splits > 1:
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)
         p.ws = ws.data_ptr()
+    stats = None
+    if row_stats:
+        bn = lib.ief_gemm_tile_bn(p.tile_hint)
+        stats = torch.empty(M, -(-N // bn), 2, dtype=torch.float32, device=a.device)
+        p.rstat_out = stats.data_ptr()
+    if ln is not None:
+        st_in, colsum, eps = ln
+        if _dev32(st_in, "ln stats").dim() != 3 or st_in.shape[0] != M or st_in.shape[2] != 2:
+            raise ValueError("gemm: ln stats must be fp32 [M, slots, 2]")
+        if _dev32(colsum, "colsum").numel() != N:
+            raise ValueError("gemm: colsum must have N entries")
+        p.rstat_in, p.rstat_slots, p.colsum, p.ln_eps = st_in.data_ptr(), st_in.shape[1], colsum.data_ptr(), eps
     p.flags, p.zeros = (3 if geglu else 1), _zeros(a.device)
     with _Timed(_kname(p.tile_hint, False, p.stages), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
-    return out
+    return (out, stats) if row_stats else out
 
 
 def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0,

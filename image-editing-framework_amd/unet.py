@@ -27,6 +27,7 @@ Two execution paths share these modules:
 There is no CPU path: tensors must live on the GPU and `libief_hip.so` must be built.
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -34,6 +35,22 @@ from torch import nn
 
 from . import hip
 from .config import UNetConfig
+
+
+# LayerNorm of the transformer blocks folded into the following linear (see include/ief_hip.h, IefGemmParams.rstat_*):
+# removes the 48 LayerNorm launches of a UNet forward and one read + write of the residual stream each.  IEF_FOLD_LN=0
+# keeps the separate kernels (A/B timing; the generic hook path always uses them).
+FOLD_LN = os.environ.get("IEF_FOLD_LN", "1") == "1"
+
+
+def _fold_ln(w16, bias32, gamma, beta):
+    """(W gamma) fp16, bias + W beta, row sums of the fp16 folded weight (what the MFMA actually multiplies)"""
+    wf = w16.float()
+    wp = (wf * gamma[None, :]).half().contiguous()
+    b = wf @ beta
+    if bias32 is not None:
+        b = b + bias32
+    return wp, b.contiguous(), wp.float().sum(1).contiguous()
 
 
 class UNetOutput(dict):
@@ -142,6 +159,14 @@ class Attention(nn.Module):
         self._plan = None          # control.ControlPlan when a lowered controller is registered
         self._kv_key, self._kv = None, None
         self.cache_kv = True       # False when the context changes every step (null-text embeddings)
+        self.ln_w = self.ln_b = self.ln_c1 = None   # input projection with the preceding LayerNorm folded in
+        self.ln_eps = 1e-5
+
+    def fold_layernorm(self, norm):
+        """pack W gamma / beta W^T of the q (cross) or q|k|v (self) projection for the LayerNorm that feeds this module"""
+        w = self.w_qkv if self.w_qkv is not None else self.to_q.weight
+        self.ln_w, self.ln_b, self.ln_c1 = _fold_ln(w, None, norm.weight, norm.bias)
+        self.ln_eps = norm.eps
 
     # ---- protocol used by hook closures (generic path)
     def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
@@ -196,28 +221,34 @@ class Attention(nn.Module):
         return self._kv
 
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, residual=None,
-                **cross_attention_kwargs):
+                ln_stats=None, want_stats=False, **cross_attention_kwargs):
+        """ln_stats: row moments of `hidden_states` (then the RAW residual stream: the LayerNorm is folded into the
+        input projection); want_stats: also return the row moments of the output (for the next folded LayerNorm)."""
         if self.processor is not None:  # Pix2Pix-zero style processors own the dataflow
             return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                                   attention_mask=attention_mask, **cross_attention_kwargs)
         x = hidden_states
         B, N, C = x.shape
         plan = self._plan
+        ln = None if ln_stats is None else (ln_stats, self.ln_c1, self.ln_eps)
         if encoder_hidden_states is None:
-            qkv = hip.gemm(x, self.w_qkv)
+            qkv = hip.gemm(x, self.w_qkv) if ln is None else hip.gemm(x, self.ln_w, bias=self.ln_b, ln=ln)
             q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
             qs = ks = vs = None
             if plan is not None:
                 qs, ks, vs = plan.self_sources(B, N, self)
             o = hip.attn_flash(q, k, v, self.heads, self.scale, q_src=qs, k_src=ks, v_src=vs)
         else:
-            q = hip.gemm(x, self.to_q.weight)
+            q = hip.gemm(x, self.to_q.weight) if ln is None else hip.gemm(x, self.ln_w, bias=self.ln_b, ln=ln)
             kv = self.context_kv(encoder_hidden_states)
             args = plan.cross_edit(B, self) if plan is not None else {}
             o = hip.attn_cross_p2p(q, kv[..., :C], kv[..., C:], self.heads, self.scale, **args)
         if plan is not None:
             plan.layer_done(self)
-        return self.to_out[0](o, residual=residual)
+        lin = self.to_out[0]
+        if want_stats:
+            return hip.gemm(o, lin.weight, bias=lin.bias, residual=residual, row_stats=True)
+        return lin(o, residual=residual)
 
 
 class GEGLU(nn.Module):
@@ -234,7 +265,13 @@ class GEGLU(nn.Module):
         self.proj = Linear(_f16(il(w), dev), _f32(il(b), dev))   # NOTE: rows interleaved [8 hidden | 8 gate] ...
         self.proj.interleaved = True
 
-    def forward(self, x):
+    def fold_layernorm(self, norm):
+        self.ln_w, self.ln_b, self.ln_c1 = _fold_ln(self.proj.weight, self.proj.bias, norm.weight, norm.bias)
+        self.ln_eps = norm.eps
+
+    def forward(self, x, ln_stats=None):
+        if ln_stats is not None:
+            return hip.gemm(x, self.ln_w, bias=self.ln_b, geglu=True, ln=(ln_stats, self.ln_c1, self.ln_eps))
         return hip.gemm(x, self.proj.weight, bias=self.proj.bias, geglu=True)
 
 
@@ -256,6 +293,13 @@ class BasicTransformerBlock(nn.Module):
         self.attn1 = Attention(sd, prefix + ".attn1", dim, heads, None, dev, name + ".attn1")
         self.attn2 = Attention(sd, prefix + ".attn2", dim, heads, cross_dim, dev, name + ".attn2")
         self.ff = FeedForward(sd, prefix + ".ff", dev)
+        if dev.type == "cuda":
+            self.attn1.fold_layernorm(self.norm1)
+            self.attn2.fold_layernorm(self.norm2)
+            self.ff.net[0].fold_layernorm(self.norm3)
+
+    def foldable(self):
+        return FOLD_LN and self.attn1.ln_w is not None and self.attn1.is_native() and self.attn2.is_native()
 
     @staticmethod
     def _attend(attn, x, res, ctx):
@@ -265,7 +309,12 @@ class BasicTransformerBlock(nn.Module):
         out = attn(x, encoder_hidden_states=ctx)
         return hip.add(out.contiguous(), res)
 
-    def forward(self, h, ctx):
+    def forward(self, h, ctx, ln_stats=None):
+        """ln_stats: row moments of h from the GEMM that produced it => the three LayerNorms run folded (no launch)"""
+        if ln_stats is not None:
+            h, st = self.attn1(h, residual=h, ln_stats=ln_stats, want_stats=True)
+            h, st = self.attn2(h, encoder_hidden_states=ctx, residual=h, ln_stats=st, want_stats=True)
+            return self.ff.net[2](self.ff.net[0](h, ln_stats=st), residual=h)
         h = self._attend(self.attn1, self.norm1(h), h, None)
         h = self._attend(self.attn2, self.norm2(h), h, ctx)
         return self.ff(self.norm3(h), residual=h)
@@ -282,6 +331,10 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, encoder_hidden_states=None):
         B, H, W, C = x.shape
+        if all(blk.foldable() for blk in self.transformer_blocks) and len(self.transformer_blocks) == 1:
+            h, st = hip.gemm(self.norm(x), self.proj_in.weight, bias=self.proj_in.bias, row_stats=True)
+            h = self.transformer_blocks[0](h.reshape(B, H * W, C), encoder_hidden_states, ln_stats=st)
+            return self.proj_out(h.reshape(B, H, W, C), residual=x)
         h = self.proj_in(self.norm(x)).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, encoder_hidden_states)

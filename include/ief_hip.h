@@ -76,9 +76,24 @@ typedef struct IefGemmParams {
     int stages;               /* depth of the LDS operand ring: 0/2 (double buffer), 3 or 4 K tiles in flight */
     int pad_hi_only;          /* conv: 1 = zero padding only on the bottom/right edge (pad (0,1,0,1)), as the VAE encoder's
                                * stride-2 Downsample2D uses; 0 = symmetric padding 1 */
+    /* LayerNorm folded into the NEXT linear (BasicTransformerBlock.norm1/2/3 -> to_q / to_qkv / ff.net[0]):
+     *   LN(x) W^T = rstd (x (W gamma)^T - mu colsum) + beta W^T,   colsum[n] = sum_k (W gamma)[n][k]
+     * so the consumer GEMM runs on the RAW residual stream with W gamma as weights and beta W^T folded into its bias, and
+     * corrects per row in its epilogue; the row moments come from the epilogue of the GEMM that PRODUCED x.
+     * rstat_out: producer side, [M][tiles_n][2] fp32 = (sum, sum of squares) of the fp16-rounded outputs over each N tile
+     *            (tiles_n = ceil(N / BN) of the tile this launch uses; ief_gemm_tile_bn(tile_hint) gives BN);
+     * rstat_in / rstat_slots / colsum / ln_eps: consumer side, rstat_in = the producer's rstat_out, rstat_slots its tiles_n;
+     *            the LayerNorm width is this GEMM's K.  Neither side may use split-K; rstat_out excludes the GEGLU epilogue. */
+    float* rstat_out;
+    const float* rstat_in;
+    int rstat_slots;
+    const float* colsum;
+    float ln_eps;
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);
+/* BN (output columns per workgroup) of a tile id, 0 for an unknown id */
+int ief_gemm_tile_bn(int tile_hint);
 /* fills M, K, ldw, Ho, Wo, rows_per_batch itself from the geometry fields */
 int ief_conv3x3_f16(const IefGemmParams* p, void* stream);
 

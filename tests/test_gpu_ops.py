@@ -177,6 +177,39 @@ def test_gemm_fused_geglu(M, C, tile):
     close(out, y[:, :half] * F.gelu(y[:, half:]), 3e-3, 1e-3)
 
 
+@pytest.mark.parametrize("M,C,N2,tile_p,tile_c,geglu", [(1000, 320, 960, 0, 0, False), (300, 640, 640, 3, 5, False),
+                                                         (4096, 320, 2560, 5, 7, True), (256, 1280, 1280, 6, 1, False),
+                                                         (77, 64, 192, 3, 3, False)])
+def test_gemm_layernorm_folded(M, C, N2, tile_p, tile_c, geglu):
+    """producer GEMM (+bias +residual) emits the row moments of its output; the consumer GEMM on W*gamma applies
+    LayerNorm in its epilogue: together they must equal gemm -> layer_norm -> linear (BasicTransformerBlock.norm*)."""
+    o, res = h16(M, C, seed=1), h16(M, C, seed=2)
+    wo, bo = h16(C, C, seed=3, scale=C ** -0.5), f32(C, seed=4, scale=0.1)
+    gamma, beta = 1 + 0.1 * f32(C, seed=5), 0.1 * f32(C, seed=6)
+    w2, b2 = h16(N2, C, seed=7, scale=C ** -0.5), f32(N2, seed=8, scale=0.1)
+    h, st = hip.gemm(dev(o), dev(wo), bias=dev(bo), residual=dev(res), row_stats=True, tile_hint=tile_p)
+    h_ref = (o.float() @ wo.float().t() + bo + res.float())
+    close(h, h_ref, 2e-3, 1e-3)
+    hr = h.float().cpu()
+    assert st.shape[0] == M and st.shape[2] == 2
+    close(st.sum(1)[:, 0], hr.sum(1), 1e-5, 1e-3)
+    close(st.sum(1)[:, 1], (hr * hr).sum(1), 1e-5, 1e-3)
+    wp = (w2.float() * gamma[None, :]).half()
+    bias = w2.float() @ beta + b2
+    c1 = wp.float().sum(1)
+    il = lambda t: t
+    if geglu:
+        half = N2 // 2
+        il = lambda t: torch.stack([t[:half].reshape(half // 8, 8, *t.shape[1:]), t[half:].reshape(half // 8, 8, *t.shape[1:])],
+                                   1).reshape(t.shape).contiguous()
+    out = hip.gemm(h, dev(il(wp)), bias=dev(il(bias)), ln=(st, dev(il(c1)), 1e-5), geglu=geglu, tile_hint=tile_c)
+    y = F.layer_norm(hr, (C,), gamma, beta, 1e-5) @ w2.float().t() + b2
+    if geglu:
+        y = y[:, :N2 // 2] * F.gelu(y[:, N2 // 2:])
+    e = close(out, y, 4e-3, 2e-3)
+    print(f"folded LayerNorm M={M} C={C} N={N2}: max err {e:.2e} of {y.abs().max().item():.2f}")
+
+
 # ----------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, heads, scale, qs=None, ks=None, vs=None, hook=None):
     B, N, C = q.shape
