@@ -223,8 +223,7 @@ extern "C" int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int 
         int PYs = 256 / C8;
         if (PYs > per) PYs = per;
         if (PYs < 1) PYs = 1;
-        int ts = C8 * PYs;
-        if (ts < 64) ts = 64;
+        int ts = ((C8 * PYs + 63) / 64) * 64;   // whole waves: the group fold below uses every lane of a wave
         hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(splits, B), dim3(ts), 0, st, x, x2, C1, C2, dy, gamma, beta, stats,
                            partial, HW, groups, splits, apply_silu, PYs);
         IEF_LAUNCH_CHECK();
@@ -233,8 +232,7 @@ extern "C" int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int 
         if (PYa > HW) PYa = HW;
         int ppb = PYa * 4;
         if (ppb > HW) ppb = HW;
-        int ta = C8 * PYa;
-        if (ta < 64) ta = 64;
+        int ta = ((C8 * PYa + 63) / 64) * 64;   // whole waves (wave_sum over the split partials)
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(ta), 0, st, x, x2, C1, C2, dy, add, dx, dx2,
                            gamma, beta, stats, partial, HW, groups, splits, apply_silu, ppb, PYa);
         IEF_LAUNCH_CHECK();
