@@ -92,6 +92,7 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel(const half_t* __restrict__ 
 // Large slabs: two launches over (pixel split, batch) with 16-byte accesses, like gn_stats / gn_apply in norm.hip.
 // A thread owns ONE 8-channel chunk for all its pixels; (mean, rstd) come from the forward.
 #define GNB_MAX_GROUPS 64
+#define GNB_PART_FLOATS 4096
 __device__ __forceinline__ half8 load_cat8b(const half_t* x, const half_t* x2, int C1, int C2, long long pix, int c) {
     if (c < C1) return *(const half8*)(x + pix * C1 + c);
     return *(const half8*)(x2 + pix * C2 + (c - C1));
@@ -106,9 +107,7 @@ __global__ void gn_bwd_partial_kernel(const half_t* __restrict__ x, const half_t
     const int b = blockIdx.y, sp = blockIdx.x;
     const int cx = threadIdx.x % C8, py = threadIdx.x / C8;
     const int c = cx * 8;
-    __shared__ float g1[GNB_MAX_GROUPS], g2[GNB_MAX_GROUPS];
-    if (threadIdx.x < GNB_MAX_GROUPS) { g1[threadIdx.x] = 0.f; g2[threadIdx.x] = 0.f; }
-    __syncthreads();
+    __shared__ float ps[GNB_PART_FLOATS], pq[GNB_PART_FLOATS];   // per-(pixel lane, channel) partials, summed in a fixed order
     float mean[8], rstd[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -133,19 +132,18 @@ __global__ void gn_bwd_partial_kernel(const half_t* __restrict__ x, const half_t
             s1[e] += g; s2[e] += g * h;
         }
     }
-    int g_prev = c / cpg;
-    float a1 = 0.f, a2 = 0.f;
+    if (py < PY) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (c + e) / cpg;
-        if (g != g_prev) { atomicAdd(&g1[g_prev], a1); atomicAdd(&g2[g_prev], a2); a1 = 0.f; a2 = 0.f; g_prev = g; }
-        a1 += s1[e]; a2 += s2[e];
+        for (int e = 0; e < 8; ++e) { ps[py * C + c + e] = s1[e]; pq[py * C + c + e] = s2[e]; }
     }
-    atomicAdd(&g1[g_prev], a1); atomicAdd(&g2[g_prev], a2);
     __syncthreads();
     if (threadIdx.x < groups) {
-        float* o = partial + (((long long)b * splits + sp) * groups + threadIdx.x) * 2;
-        o[0] = g1[threadIdx.x]; o[1] = g2[threadIdx.x];
+        const int g = threadIdx.x;
+        float t1 = 0.f, t2 = 0.f;
+        for (int r = 0; r < PY; ++r)
+            for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { t1 += ps[r * C + cc]; t2 += pq[r * C + cc]; }
+        float* o = partial + (((long long)b * splits + sp) * groups + g) * 2;
+        o[0] = t1; o[1] = t2;
     }
 }
 
@@ -216,12 +214,13 @@ extern "C" int ief_groupnorm_bwd_f16(const ief_half* x, const ief_half* x2, int 
     const int cpg = C / groups;
     hipStream_t st = (hipStream_t)stream;
     const bool big = (long long)HW * cpg * 2 > 48 * 1024;
-    if (big && stats && partial && !(C1 & 7) && !(C2 & 7) && C <= 8 * 1024) {
+    if (big && stats && partial && !(C1 & 7) && !(C2 & 7) && C <= GNB_PART_FLOATS) {
         const int splits = ief_gn_splits(HW);
         const int C8 = C / 8;
         const int per = (HW + splits - 1) / splits;
         int PYs = 256 / C8;
         if (PYs > per) PYs = per;
+        if (PYs > GNB_PART_FLOATS / C) PYs = GNB_PART_FLOATS / C;
         if (PYs < 1) PYs = 1;
         int ts = ((C8 * PYs + 63) / 64) * 64;   // whole waves: the group fold below uses every lane of a wave
         hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(splits, B), dim3(ts), 0, st, x, x2, C1, C2, dy, gamma, beta, stats,

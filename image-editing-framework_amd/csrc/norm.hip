@@ -12,6 +12,7 @@
 #include "ief_params.h"
 
 #define GN_MAX_GROUPS 64
+#define GN_PART_FLOATS 4096   // LDS partials of the statistics pass: PY * C <= 4096
 
 // pixel splits per image for the statistics pass: enough blocks to cover the chip, at least 16 pixels each
 static inline int gn_splits_host(int HW) {
@@ -37,9 +38,9 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, const half_t* __re
     const int C = C1 + C2, C8 = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, sp = blockIdx.x;
     const int cx = threadIdx.x % C8, py = threadIdx.x / C8;
-    __shared__ float gsum[GN_MAX_GROUPS], gsq[GN_MAX_GROUPS];
-    if (threadIdx.x < GN_MAX_GROUPS) { gsum[threadIdx.x] = 0.f; gsq[threadIdx.x] = 0.f; }
-    __syncthreads();
+    // per-(pixel lane, channel) partials go to LDS and each group is then summed by ONE thread in a fixed order:
+    // no atomics, so the statistics (and everything downstream) are bit-reproducible run to run
+    __shared__ float ps[GN_PART_FLOATS], pq[GN_PART_FLOATS];
     const int per = (HW + splits - 1) / splits;
     const int p0 = sp * per, p1 = min(HW, p0 + per);
     float s[8], q[8];
@@ -50,20 +51,18 @@ __global__ void gn_stats_kernel(const half_t* __restrict__ x, const half_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
     }
-    // fold the 8 channels into their (1..8) groups, then a few LDS atomics per thread
-    int g_prev = (cx * 8) / cpg;
-    float as = 0.f, aq = 0.f;
+    if (py < PY) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (cx * 8 + e) / cpg;
-        if (g != g_prev) { atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq); as = 0.f; aq = 0.f; g_prev = g; }
-        as += s[e]; aq += q[e];
+        for (int e = 0; e < 8; ++e) { ps[py * C + cx * 8 + e] = s[e]; pq[py * C + cx * 8 + e] = q[e]; }
     }
-    atomicAdd(&gsum[g_prev], as); atomicAdd(&gsq[g_prev], aq);
     __syncthreads();
     if (threadIdx.x < groups) {
-        float* o = partial + (((long long)b * splits + sp) * groups + threadIdx.x) * 2;
-        o[0] = gsum[threadIdx.x]; o[1] = gsq[threadIdx.x];
+        const int g = threadIdx.x;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < PY; ++r)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { ts += ps[r * C + c]; tq += pq[r * C + c]; }
+        float* o = partial + (((long long)b * splits + sp) * groups + g) * 2;
+        o[0] = ts; o[1] = tq;
     }
 }
 
@@ -213,8 +212,10 @@ extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int
     const int C8 = C / 8;
     // statistics: up to 1024 threads (C8 * PY), PY bounded by the pixels a block owns
     int per = (HW + splits - 1) / splits;
-    int PYs = 256 / C8;                    // ~256-thread blocks: few LDS atomics per block, several pixels per thread
+    if (C > GN_PART_FLOATS) return IEF_ESHAPE;
+    int PYs = 256 / C8;                    // ~256-thread blocks, several pixels per thread
     if (PYs > per) PYs = per;
+    if (PYs > GN_PART_FLOATS / C) PYs = GN_PART_FLOATS / C;
     if (PYs < 1) PYs = 1;
     int ts = C8 * PYs;
     if (ts < 64) ts = 64;  // the LDS zero-fill / final write use the first 64 threads

@@ -1,7 +1,6 @@
 """Invert a real image, then edit it with Prompt-to-Prompt — CLI of `/root/reference/p2p/edit_real.py`.
 
-Same flags and defaults (`--inversion_type` defaults to "null-text" as in the reference, :26; that mode
-needs the UNet backward and raises until it is built — pass `--inversion_type ddim`), same outputs:
+Same flags and defaults (`--inversion_type` defaults to "null-text" as in the reference, :26), same outputs:
 `./exp/source.png`, `./exp/inversion.png`, `./exp/edit.png`.
 """
 import argparse
@@ -29,6 +28,25 @@ parser.add_argument("--source_image", type=str, default="./test.jpg")
 parser.add_argument("--inversion_type", type=str, default="null-text")
 
 
+def edit_latent(pipe, editor, x_T, source_prompt, target_prompt, edit_type, device, extra=None, num_inference_steps=50,
+                guidance_scale=7.5, cross_replace_steps=0.8, self_replace_steps=0.6):
+    """Prompt-to-Prompt edit from an inverted latent x_T [1,4,h,w] -> uint8 images [2,H,W,3] (reconstruction, edit)"""
+    kw = dict(prompts=source_prompt + target_prompt, tokenizer=pipe.tokenizer, num_steps=num_inference_steps,
+              cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps, device=device)
+    if edit_type == "replace":
+        controller = AttentionReplace(**kw)
+    elif edit_type == "refine":
+        controller = AttentionRefine(**kw)
+    else:
+        raise ValueError("Please choose right eidt type")
+    images, _ = editor.text2image_ldm_stable(pipe, source_prompt + target_prompt, controller, latent=x_T,
+                                             num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                             low_resource=False, **(extra or {}))
+    controller.reset()
+    unregister_attention_control(pipe, controller)
+    return images
+
+
 def edit_one(pipe, editor, invertor, image, source_prompt, target_prompt, inversion_type, edit_type, device,
              num_inference_steps=50, guidance_scale=7.5, cross_replace_steps=0.8, self_replace_steps=0.6,
              num_inner_steps=10, early_stop_epsilon=1e-5):
@@ -41,20 +59,8 @@ def edit_one(pipe, editor, invertor, image, source_prompt, target_prompt, invers
                                                                      early_stop_epsilon, guidance_scale)
     elif inversion_type != "ddim":
         raise ValueError("Please choose right inversion type")
-    kw = dict(prompts=source_prompt + target_prompt, tokenizer=pipe.tokenizer, num_steps=num_inference_steps,
-              cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps, device=device)
-    if edit_type == "replace":
-        controller = AttentionReplace(**kw)
-    elif edit_type == "refine":
-        controller = AttentionRefine(**kw)
-    else:
-        raise ValueError("Please choose right eidt type")
-    images, _ = editor.text2image_ldm_stable(pipe, source_prompt + target_prompt, controller, latent=latents[-1],
-                                             num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                                             low_resource=False, **extra)
-    controller.reset()
-    unregister_attention_control(pipe, controller)
-    return images
+    return edit_latent(pipe, editor, latents[-1], source_prompt, target_prompt, edit_type, device, extra,
+                       num_inference_steps, guidance_scale, cross_replace_steps, self_replace_steps)
 
 
 def main(argv=None):

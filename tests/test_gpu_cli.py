@@ -81,3 +81,19 @@ def test_bench_under_torchrun_one_rank(tmp_path):
                "--config", "small", "--no-cpu-baseline"], cwd=ROOT, timeout=900)
     rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["value"] > 0 and "roofline" in rec
+
+
+def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
+    """--invert_batch K inverts K images in one batched DDIM loop; images are independent, so the PNGs must match the
+    per-image run (up to fp16 tile-shape effects: a few grey levels)."""
+    a, b = tmp_path / "a", tmp_path / "b"
+    run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--exp_path", str(a)], cwd=str(tmp_path))
+    out = run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--invert_batch", "2",
+               "--exp_path", str(b)], cwd=str(tmp_path))
+    assert json.loads(out.strip().splitlines()[-1])["images"] == 3
+    for d in sorted(x for x in os.listdir(a) if x.startswith("syn_")):
+        for name in ("inversion.png", "edit.png"):
+            pa = np.array(Image.open(a / d / name)).astype(int)
+            pb = np.array(Image.open(b / d / name)).astype(int)
+            assert pa.shape == pb.shape
+            assert np.abs(pa - pb).max() <= 6 and np.abs(pa - pb).mean() < 0.5, (d, name, np.abs(pa - pb).max())

@@ -149,6 +149,16 @@ def test_groupnorm(B, HW, C1, C2, silu, eps):
     close(out, ref, 2e-3, 2e-3)
 
 
+def test_groupnorm_is_bit_reproducible():
+    """the statistics pass sums in a fixed order (no atomics): repeated launches must agree bit for bit — a 1-ulp wobble
+    here is amplified by the 100 UNet steps of an inversion + edit into visibly different images"""
+    for HW, C in ((16384, 128), (4096, 320), (4096, 960), (1024, 1920)):
+        x = dev(h16(2, HW, C, seed=1))
+        ga, be = dev(1 + 0.1 * f32(C, seed=2)), dev(0.1 * f32(C, seed=3))
+        outs = [hip.groupnorm(x, ga, be, 32, 1e-5, silu=True).clone() for _ in range(4)]
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), (HW, C)
+
+
 @pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (77, 1280), (5, 64)])
 def test_layernorm(rows, C):
     x = h16(rows, C, seed=1, scale=3.0) + 1.0
