@@ -15,7 +15,7 @@ the one-time RCCL broadcast of the packed weights from rank 0.  value = total st
 divided by the slowest rank's time ("weak" scaling).
 
 The JSON line also carries
-  roofline      dominant kernel (3x3 implicit-GEMM conv, 128x128 tile): algorithmic FLOP per launch
+  roofline      dominant kernel (the 3x3 implicit-GEMM conv template, all tile instantiations): algorithmic FLOP per launch
                 / average launch duration measured live with HIP events on the launch stream,
                 against the 2.5 PFLOP/s dense fp16 MFMA peak
   cpu_baseline  the fp32 CPU oracle (`oracle/`, reference execution semantics: materialised maps +
@@ -149,7 +149,7 @@ def main():
     value = world * args.steps / elapsed
 
     out = {
-        "metric": "denoising steps/sec (SD1.5 512x512 P2P edit step, UNet batch 4)",
+        "metric": f"denoising steps/sec (SD1.5 {hw * 8}x{hw * 8} P2P edit step, UNet batch 4)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
@@ -168,6 +168,13 @@ def main():
         dist.destroy_process_group()
 
 
+def _family(kernel_name: str) -> str:
+    if kernel_name.startswith("igemm_f16_kernel"):
+        return ("igemm_f16_kernel<.., CONV=true> (3x3 implicit-GEMM convolution)" if kernel_name.rstrip(">").endswith("true")
+                else "igemm_f16_kernel<.., CONV=false> (linear / 1x1)")
+    return kernel_name
+
+
 def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
     """dominant kernel's algorithmic FLOP/s from per-launch HIP-event timings of one eager step"""
     from ief_amd import hip
@@ -177,16 +184,23 @@ def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
     loop.lat.copy_(x_T.expand_as(loop.lat)); loop.step.zero_()
     loop._step_body()                      # eager warm-up of the un-captured path
     torch.cuda.synchronize()
+    # keep the GPU busy while the host enqueues the step: with ~430 short launches the host (10 us per launch from
+    # Python) would otherwise starve the stream and every event pair would include the wait for its launch
+    torch.cuda._sleep(int(1.2e8))
     hip.profile_begin()
     loop._step_body()
     rec = hip.profile_end()
-    agg = {}
+    agg, fam = {}, {}
     for name, flops, ms in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += ms
+        f = fam.setdefault(_family(name), [0, 0.0, 0.0])
+        f[0] += 1; f[1] += flops; f[2] += ms
     total_ms = sum(a[2] for a in agg.values())
     alg_flop = sum(a[1] for a in agg.values())   # matmul / conv / attention FLOPs of one step, counted per launch
-    name, (n, flops, ms) = max(agg.items(), key=lambda kv: kv[1][2])
+    # dominant kernel = the MFMA kernel template with the largest share of the step; its tile / ring-depth
+    # instantiations (chosen per layer shape by the tuned plan table) are one kernel for this purpose
+    name, (n, flops, ms) = max(((k, v) for k, v in fam.items() if v[1] > 0), key=lambda kv: kv[1][2])
     achieved = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
     # this process; see profiles/r01_pmc_traffic.json for the command and the gfx950 FETCH_SIZE correction)
@@ -194,11 +208,10 @@ def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pmc = json.load(f)
-        hit = [v for k, v in pmc.items() if not k.startswith("_") and name.split("<")[0] in k and
-               name.split("<")[1].rstrip(">").replace(" ", "") in k.replace(" ", "")]
+        hit = [v for k, v in pmc.items() if not k.startswith("_") and v.get("family") == name]
         if hit:
             traffic = {"hbm_bytes_per_launch": hit[0]["hbm_bytes"], "algorithmic_bytes_per_launch": hit[0]["algorithmic_bytes"],
-                       "source": "profiles/r01_pmc_traffic.json"}
+                       "shape": hit[0]["shape"], "source": "profiles/r01_pmc_traffic.json"}
     except (OSError, ValueError, KeyError):
         traffic = None
     return {
