@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=str, default="sd15")
     ap.add_argument("--latent", type=int, default=0, help="latent side (default: the config's sample_size; 128 = 1024x1024 px)")
+    ap.add_argument("--in-flight", type=str, default="2,4", help="also time E independent edits stepped concurrently per GPU "
+                    "(comma list, '' to skip); reported beside the headline value, which is ONE edit at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -148,6 +150,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
 
+    # throughput schedule: E independent edits in flight per GPU (denoise.run_interleaved); the headline stays E = 1
+    in_flight = {}
+    for E in [int(e) for e in args.in_flight.split(",") if e.strip()]:
+        in_flight[str(E)] = round(edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world), 3)
+    register_attention_control(pipe, ctrl)
+
     out = {
         "metric": f"denoising steps/sec (SD1.5 {hw * 8}x{hw * 8} P2P edit step, UNet batch 4)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,6 +165,9 @@ def main():
                                f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4; "
                                "one independent edit per GPU",
                    "images_per_sec_equiv": round(value / 250.0, 4)},
+        # same edit step, E independent edits stepped concurrently per GPU (steps/s over all ranks); the schedule
+        # `p2p/test.py --in_flight E` uses for PIE-Bench throughput.  The headline `value` above is E = 1.
+        "throughput_edits_in_flight": in_flight,
     }
     if rank == 0:
         out["roofline"] = roofline(pipe, loop, ctrl, x_T, value, world)
@@ -166,6 +177,36 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, steps=40):
+    """steps/s (all ranks) with E independent P2P edits stepped concurrently on each GPU"""
+    from ief_amd.denoise import FusedDenoiser, run_interleaved
+    from ief_amd.p2p.model.attention_control import AttentionRefine
+    from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control
+    loops, ctrls = [], []
+    for _ in range(E):
+        c = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
+        register_attention_control(pipe, c)
+        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5)
+        lp.start(x_T)
+        unregister_attention_control(pipe, None)
+        loops.append(lp); ctrls.append(c)
+    run_interleaved(loops, 4)
+    for lp, c in zip(loops, ctrls):
+        c.reset(); lp.plan.sync_step(); lp.step.zero_(); lp.lat.copy_(x_T.expand_as(lp.lat))
+    barrier()
+    t0 = time.perf_counter()
+    run_interleaved(loops, steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([dt], device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dt = te.item()
+    for lp in loops:
+        lp.release()
+    return world * E * steps / dt
 
 
 def _family(kernel_name: str) -> str:

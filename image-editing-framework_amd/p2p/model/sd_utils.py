@@ -24,8 +24,8 @@ import torch
 from tqdm import tqdm
 
 from ... import hip
-from ...denoise import FusedDenoiser
-from .register import register_attention_control
+from ...denoise import FusedDenoiser, run_interleaved
+from .register import register_attention_control, unregister_attention_control
 
 
 def _encode_prompts(model, prompt: List[str]):
@@ -92,6 +92,38 @@ class P2P:
             return latents, latent
         image = self.latent2image(model.vae, latents)
         return image, latent
+
+    @torch.no_grad()
+    def edit_many(self, model, jobs, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                  height: Optional[int] = None, width: Optional[int] = None):
+        """Several independent edits IN FLIGHT on one GPU (a throughput schedule the reference does not have: its
+        drivers call `text2image_ldm_stable` once per image).  jobs: [(prompts, controller, latent x_T [1,4,h,w])];
+        every controller must be one of the lowered classes.  Each job's loop is captured while its controller is
+        registered, then all loops are stepped in turn on their own streams (`denoise.run_interleaved`).  Returns
+        [(images uint8 [len(prompts),H,W,3], x_T)] — the same values as one `text2image_ldm_stable` call per job."""
+        if height is None:
+            height = width = model.unet.config.sample_size * model.vae_scale_factor
+        model.scheduler.set_timesteps(num_inference_steps)
+        loops, firsts = [], []
+        try:
+            for prompt, controller, latent in jobs:
+                register_attention_control(model, controller)
+                if not _fusable(model, controller, False):
+                    raise RuntimeError("edit_many: only controllers lowered to a device plan can run concurrently")
+                uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+                latent, latents = self.init_latent(latent, model, height, width, None, len(prompt))
+                loop = FusedDenoiser(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
+                                     (height // 8, width // 8), guidance_scale)
+                loop.start(latents)
+                loops.append(loop)
+                firsts.append(latent)
+                unregister_attention_control(model, None)      # the captured graph carries the plan's tables
+            run_interleaved(loops)
+            torch.cuda.synchronize()
+            return [(self.latent2image(model.vae, loop.result()), first) for loop, first in zip(loops, firsts)]
+        finally:
+            for loop in loops:
+                loop.release()
 
     def diffusion_step(self, model, controller, latents, context, t, guidance_scale, low_resource=False):
         """one eager step (`sd_utils.py:67-79`); CFG + DDIM update fused in one kernel."""

@@ -14,6 +14,8 @@ The only collective is the final all_reduce of the image counters / time for the
 `--invert_batch K` (ddim inversion only) inverts K images of a rank's shard in ONE batched DDIM loop (UNet batch K
 instead of K loops at batch 1; images are independent, results are those of the per-image loop) before editing them one
 by one: at batch 1 the UNet is bound by per-kernel latency, so K = 4 nearly quarters the inversion time per image.
+`--in_flight E` (ddim only) keeps E edits in flight on the GPU (`P2P.edit_many`): an edit step is ~380 dependent
+launches, and E independent chains fill each other's dispatch gaps.  Both change the schedule, not the results.
 """
 import argparse
 import json
@@ -26,6 +28,7 @@ from PIL import Image
 from _bootstrap import load_pipe, seed_everything
 
 from edit_real import edit_latent, edit_one
+from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE
 from ief_amd.p2p.inversion.ddim import ddim_inversion
 from ief_amd.p2p.inversion.nti import NTI
@@ -53,6 +56,7 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
     ap.add_argument("--no_save", action="store_true")
     ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop (ddim only)")
+    ap.add_argument("--in_flight", type=int, default=1, help="edits stepped concurrently on one GPU (ddim only)")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,24 +95,47 @@ def main(argv=None):
         save_img(images[0], os.path.join(out_path, "inversion.png"))
         save_img(images[1], os.path.join(out_path, "edit.png"))
 
-    bs = max(1, args.invert_batch) if args.inversion_type == "ddim" else 1
-    for c0 in range(0, len(mine), bs):
-        chunk = [items[i] for i in mine[c0:c0 + bs]]
+    ddim = args.inversion_type == "ddim"
+    bs = max(1, args.invert_batch) if ddim else 1
+    E = max(1, args.in_flight) if ddim else 1
+    group = max(bs, E)
+    for c0 in range(0, len(mine), group):
+        chunk = [items[i] for i in mine[c0:c0 + group]]
         originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
-        if len(chunk) == 1:
+        if group == 1:
             image_path, source_prompt, target_prompt = chunk[0]
             images = edit_one(pipe, editor, invertor, originals[0], [source_prompt], [target_prompt], args.inversion_type,
                               edit_type_of(source_prompt, target_prompt), device)
             save(image_path, originals[0], images)
             continue
-        latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32)
-                            for im in originals])
-        latents, _ = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
-        x_T = latents[-1]
-        for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
-            images = edit_latent(pipe, editor, x_T[j:j + 1].clone(), [source_prompt], [target_prompt],
-                                 edit_type_of(source_prompt, target_prompt), device)
-            save(image_path, originals[j], images)
+        # inversion: batched over `bs` images at a time
+        x_T = []
+        for b0 in range(0, len(chunk), bs):
+            latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32)
+                                for im in originals[b0:b0 + bs]])
+            latents, _ = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk[b0:b0 + bs]])
+            x_T += [latents[-1][j:j + 1].clone() for j in range(latent.shape[0])]
+        # edits: E in flight
+        for e0 in range(0, len(chunk), E):
+            part = list(range(e0, min(e0 + E, len(chunk))))
+            if len(part) == 1:
+                j = part[0]
+                _, src, tgt = chunk[j]
+                results = [edit_latent(pipe, editor, x_T[j], [src], [tgt], edit_type_of(src, tgt), device)]
+            else:
+                jobs, ctrls = [], []
+                for j in part:
+                    _, src, tgt = chunk[j]
+                    cls = AttentionReplace if edit_type_of(src, tgt) == "replace" else AttentionRefine
+                    ctrl = cls(prompts=[src, tgt], tokenizer=pipe.tokenizer, num_steps=50, cross_replace_steps=0.8,
+                               self_replace_steps=0.6, device=device)
+                    ctrls.append(ctrl)
+                    jobs.append(([src, tgt], ctrl, x_T[j]))
+                results = [im for im, _ in editor.edit_many(pipe, jobs, num_inference_steps=50, guidance_scale=7.5)]
+                for ctrl in ctrls:
+                    ctrl.reset()
+            for j, images in zip(part, results):
+                save(chunk[j][0], originals[j], images)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

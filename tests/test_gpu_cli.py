@@ -84,16 +84,22 @@ def test_bench_under_torchrun_one_rank(tmp_path):
 
 
 def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
-    """--invert_batch K inverts K images in one batched DDIM loop; images are independent, so the PNGs must match the
-    per-image run (up to fp16 tile-shape effects: a few grey levels)."""
+    """--invert_batch K inverts K images in one batched DDIM loop and --in_flight E steps E edits concurrently; images
+    are independent, so the PNGs must match the per-image run."""
     a, b = tmp_path / "a", tmp_path / "b"
     run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--exp_path", str(a)], cwd=str(tmp_path))
     out = run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--invert_batch", "2",
                "--exp_path", str(b)], cwd=str(tmp_path))
     assert json.loads(out.strip().splitlines()[-1])["images"] == 3
-    for d in sorted(x for x in os.listdir(a) if x.startswith("syn_")):
-        for name in ("inversion.png", "edit.png"):
-            pa = np.array(Image.open(a / d / name)).astype(int)
-            pb = np.array(Image.open(b / d / name)).astype(int)
-            assert pa.shape == pb.shape
-            assert np.abs(pa - pb).max() <= 6 and np.abs(pa - pb).mean() < 0.5, (d, name, np.abs(pa - pb).max())
+    c = tmp_path / "c"
+    out = run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--invert_batch", "3",
+               "--in_flight", "2", "--exp_path", str(c)], cwd=str(tmp_path))
+    assert json.loads(out.strip().splitlines()[-1])["images"] == 3
+    for other in (b, c):
+        for d in sorted(x for x in os.listdir(a) if x.startswith("syn_")):
+            for name in ("inversion.png", "edit.png"):
+                pa = np.array(Image.open(a / d / name)).astype(int)
+                pb = np.array(Image.open(other / d / name)).astype(int)
+                assert pa.shape == pb.shape
+                # every kernel sums in a fixed order and the schedules only regroup independent images: same pixels
+                assert np.abs(pa - pb).max() <= 1, (other.name, d, name, np.abs(pa - pb).max())
