@@ -14,6 +14,11 @@ the same effect is expressed as small device tables, so no map is ever written t
       source-row table int32 [steps+1, 2B]  (identity rows outside the window)
   MasaCtrl mutual self-attention (/root/reference/masactrl/model/attention_control.py:37-68):
       K,V source rows per (step, layer)
+  Plug-and-Play injection (/root/reference/pnp/model/register.py:27-90,100-182), batch = 4 blocks of s rows
+      [uncond_src, uncond_tgt, cond_src, cond_tgt]: during the first qk_steps timesteps the self-attention of the chosen
+      decoder layers computes rows of blocks 1 and 3 with the Q and K of block 2 (:45-52), and during the first
+      conv_steps timesteps `up_blocks[1].resnets[1]` replaces their conv2 output by block 2's (:161-166):
+      a Q/K source-row table and a feature source-row table, int32 [steps+1, B]
 
 The step index lives in device memory (`step`), the per-step rows are copied into fixed
 "current" buffers by `ief_select_step` at the start of every UNet forward, and the counter is
@@ -49,12 +54,26 @@ def advance_controller(c):
         _step_hook(c)
 
 
+class StepCounter:
+    """the counters of `AttentionControl` (attention_base.py:10-27) for plans that have no controller object (PnP)"""
+
+    def __init__(self, num_att_layers: int = 0):
+        self.cur_step, self.cur_att_layer, self.num_att_layers = 0, 0, num_att_layers
+
+    def between_steps(self):
+        pass
+
+    def reset(self):
+        self.cur_step, self.cur_att_layer = 0, 0
+
+
 class ControlPlan:
-    """kind: 'empty' | 'p2p' | 'masactrl'"""
+    """kind: 'empty' | 'p2p' | 'masactrl' | 'pnp'"""
 
     def __init__(self, controller, kind: str, device, num_prompts: int = 1, num_steps: int = 0,
                  mt: Optional[torch.Tensor] = None, coef_table: Optional[torch.Tensor] = None,
-                 self_window=(0, 0), self_max_tokens: int = 256, masa_steps=(), masa_layers=()):
+                 self_window=(0, 0), self_max_tokens: int = 256, masa_steps=(), masa_layers=(),
+                 pnp_layers=(), pnp_qk_steps: int = 0, pnp_conv_steps: int = 0):
         self.controller = controller
         self.kind = kind
         self.device = torch.device(device)
@@ -95,6 +114,9 @@ class ControlPlan:
         self.masa_layers = set(int(l) for l in masa_layers)
         self._masa = {}
         self._step_synced = -1
+        self.pnp_layers = set(pnp_layers)          # id() of the Attention modules whose Q/K are injected
+        self.pnp_qk_steps, self.pnp_conv_steps = int(pnp_qk_steps), int(pnp_conv_steps)
+        self._pnp = {}                             # B -> (qk_table, qk_cur, conv_table, conv_cur)
 
     def prepare(self, B: int):
         """allocate per-batch device tables OUTSIDE any graph capture"""
@@ -111,11 +133,24 @@ class ControlPlan:
             for st in self.masa_steps:
                 tab[st] = src
             self._masa[B] = (tab.contiguous().to(self.device), ident.clone().to(self.device))
+        if self.kind == "pnp" and B not in self._pnp:
+            ident = torch.arange(B, dtype=torch.int32)
+            inj = ident.clone()
+            s = B // 4
+            if s > 0 and B == 4 * s:
+                inj[s:2 * s] = ident[2 * s:3 * s]
+                inj[3 * s:4 * s] = ident[2 * s:3 * s]
+            n = self.num_steps + 1
+            qk, cv = ident.repeat(n, 1), ident.repeat(n, 1)
+            qk[: self.pnp_qk_steps] = inj
+            cv[: self.pnp_conv_steps] = inj
+            dev = self.device
+            self._pnp[B] = (qk.contiguous().to(dev), ident.clone().to(dev), cv.contiguous().to(dev), ident.clone().to(dev))
     # ------------------------------------------------------------------ per-forward protocol
     def applies(self, B: int) -> bool:
         if self.kind == "empty" or self.muted:
             return False
-        if self.kind == "masactrl":
+        if self.kind in ("masactrl", "pnp"):
             return True
         if B != self.batch:
             raise RuntimeError(
@@ -144,9 +179,19 @@ class ControlPlan:
             if not self.captured and int(self.controller.cur_step) >= tab.shape[0]:
                 self.step.fill_(tab.shape[0] - 1)   # past the last controlled step: identity row
             hip.select_step(tab, cur, self.step)
+        elif self.kind == "pnp":
+            if B not in self._pnp:
+                if self.captured:
+                    raise RuntimeError("ControlPlan.prepare(B) must run before graph capture")
+                self.prepare(B)
+            qk, qk_cur, cv, cv_cur = self._pnp[B]
+            if not self.captured and int(self.controller.cur_step) >= qk.shape[0]:
+                self.step.fill_(qk.shape[0] - 1)    # past the schedule: identity rows
+            hip.select_step(qk, qk_cur, self.step)
+            hip.select_step(cv, cv_cur, self.step)
 
     def end_forward(self, B: int):
-        if self.kind == "masactrl" and not self.muted:
+        if self.kind in ("masactrl", "pnp") and not self.muted:
             hip.advance_step(self.step)
         elif self.kind != "empty" and not self.muted and B == self.batch:
             hip.advance_step(self.step)
@@ -173,7 +218,16 @@ class ControlPlan:
         if self.kind == "masactrl" and not self.muted and (attn._exec_index // 2) in self.masa_layers:
             cur = self._masa[B][1]
             return None, cur, cur
+        if self.kind == "pnp" and not self.muted and id(attn) in self.pnp_layers:
+            cur = self._pnp[B][1]
+            return cur, cur, None
         return None, None, None
+
+    def feature_source(self, B: int):
+        """source rows of the Plug-and-Play feature injection for the CURRENT step (identity outside its schedule)"""
+        if self.kind == "pnp" and not self.muted and B in self._pnp:
+            return self._pnp[B][3]
+        return None
 
     def cross_edit(self, B: int, attn):
         if self.kind == "p2p" and self.applies(B):

@@ -192,6 +192,29 @@ extern "C" int ief_add_f16(const ief_half* a, const ief_half* b, ief_half* out, 
     return IEF_OK;
 }
 
+// out[b][:] = in[src[b]][:]  (batch-row gather; Plug-and-Play's feature injection copies the source image's
+// ResnetBlock2D features over the edited rows: /root/reference/pnp/model/register.py:161-166)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const half_t* __restrict__ in, half_t* __restrict__ out,
+                                                          const int* __restrict__ src, int B, long long row8) {
+    const long long total = (long long)B * row8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / row8);
+        const long long c = i - (long long)b * row8;
+        ((half8*)out)[i] = ((const half8*)in)[(long long)src[b] * row8 + c];
+    }
+}
+extern "C" int ief_gather_rows_f16(const ief_half* in, ief_half* out, const int* src, int B, long long row_elems, void* stream) {
+    if (!in || !out || !src) return IEF_EINVAL;
+    if (B <= 0 || row_elems <= 0 || (row_elems & 7)) return IEF_ESHAPE;
+    if (((uintptr_t)in | (uintptr_t)out) & 15) return IEF_EALIGN;
+    const long long total = (long long)B * (row_elems / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, src, B, row_elems / 8);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 __global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, half_t* __restrict__ o, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = (half_t)x[i];
 }

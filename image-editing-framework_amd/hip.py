@@ -76,7 +76,7 @@ EXPORTS = [
     "ief_softmax_rows_f16", "ief_transpose_f16", "ief_pointwise_f32",
     "ief_attn_bwd_delta_f32", "ief_attn_bwd_f16", "ief_groupnorm_bwd_f16", "ief_layernorm_bwd_f16", "ief_geglu_il_f16",
     "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
-    "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn",
+    "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn", "ief_gather_rows_f16",
 ]
 
 
@@ -136,6 +136,7 @@ def load():
     lib.ief_conv_out_bwd_f32.argtypes = [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
     lib.ief_nti_loss_grad_f32.argtypes = [c_void_p] * 7 + [c_int, c_float, c_void_p]
     lib.ief_nti_adam_f32.argtypes = [c_void_p] * 8 + [c_int, c_void_p]
+    lib.ief_gather_rows_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]
     if lib.ief_abi_version() != 1:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
@@ -591,6 +592,19 @@ def add(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
     _check(lib.ief_add_f16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "ief_add_f16")
+    return out
+
+
+def gather_rows(x, src):
+    """out[b] = x[src[b]] along the batch dimension; src: device int32 [B]"""
+    lib = load()
+    _dev16(x, "x")
+    _devi32(src, "src")
+    if not x.is_contiguous() or src.numel() != x.shape[0]:
+        raise ValueError("gather_rows: contiguous x [B, ...] and src [B] expected")
+    out = torch.empty_like(x)
+    _check(lib.ief_gather_rows_f16(x.data_ptr(), out.data_ptr(), src.data_ptr(), x.shape[0], x.numel() // x.shape[0], _stream()),
+           "ief_gather_rows_f16")
     return out
 
 

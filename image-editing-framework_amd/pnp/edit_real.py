@@ -1,0 +1,56 @@
+"""Invert a real image, then edit it with Plug-and-Play — CLI of `/root/reference/pnp/edit_real.py` for the
+`--inversion_type ddim` branch (:119-129): DDIM inversion under the source prompt, then the PnP sampler from
+`latents = cat([x_T, x_T])`; outputs `./exp/source.png`, `./exp/inversion.png`, `./exp/edit.png`.
+The reference's default here is "null-text" (`PnP_NTI`, per-step unconditional embeddings); that sampler variant is
+not built in this folder yet and is rejected loudly."""
+import argparse
+import os
+import sys
+
+import torch
+from PIL import Image
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "p2p"))
+from _bootstrap import load_pipe, seed_everything  # noqa: E402
+
+from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
+from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
+from ief_amd.pnp.model.sd_utils import PnP  # noqa: E402
+
+parser = argparse.ArgumentParser("General config")
+parser.add_argument("--sd_version", type=str, default="1.5")
+parser.add_argument("--device", type=int, default=0)
+parser.add_argument("--seed", type=int, default=42)
+parser.add_argument("--source_prompt", type=str, default="a gray horse in the field")
+parser.add_argument("--target_prompt", type=str, default="a whie horse in the field")
+parser.add_argument("--source_image", type=str, default="./test.jpg")
+parser.add_argument("--inversion_type", type=str, default="null-text")
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    if args.inversion_type != "ddim":
+        raise NotImplementedError("pnp/edit_real.py: only --inversion_type ddim is built (PnP_NTI is a later row)")
+    device = torch.device("cuda:{}".format(args.device))
+    seed_everything(args.seed)
+    num_inference_steps, GUIDANCE_SCALE = 50, 7.5
+    pnp_attn_t, pnp_f_t = 1.0, 1.0
+    out_path = "./exp"
+    pipe = load_pipe(args.sd_version, device)
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    invertor, editor = ddim_inversion(), PnP(pipe, num_inference_steps)
+    os.makedirs(out_path, exist_ok=True)
+    original_image = Image.open(args.source_image).convert("RGB").resize((size, size))
+    original_image.save(os.path.join(out_path, "source.png"))
+    latent = invertor.image2latent(model=pipe, image=original_image, device=device, dtype=torch.float32)
+    latents, _ = invertor.ddim_inversion_loop(pipe, latent, [args.source_prompt])
+    latent = latents[-1]
+    images = editor(prompt=[args.source_prompt] + [args.target_prompt], num_inference_steps=num_inference_steps,
+                    guidance_scale=GUIDANCE_SCALE, pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t,
+                    latents=torch.cat([latent, latent]))
+    save_img(images[0], os.path.join(out_path, "inversion.png"))
+    save_img(images[1], os.path.join(out_path, "edit.png"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""`PnP` sampler — call signature of `/root/reference/pnp/model/sd_utils.py:11-128` (the arguments its CLIs use).
+
+    editor = PnP(pipe, num_inference_steps)
+    images = editor(prompt=source_prompt + target_prompt, num_inference_steps=50, guidance_scale=7.5,
+                    pnp_attn_t=1.0, pnp_f_t=1.0, latents=None)          # uint8 [2, H, W, 3]
+
+Batch = [uncond_src, uncond_tgt, cond_src, cond_tgt] (`prompt_embeds = cat([negative, positive])`, :72-73), one x_T
+shared by both prompts (:75-83).  The 50 steps of the loop (:93-113) are one captured hipGraph replayed per step; the
+two injection schedules are device tables (`model/register.py`).
+"""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from ...denoise import FusedDenoiser
+from ...p2p.model.sd_utils import _encode_prompts
+from .register import (register_attention_control_efficient, register_conv_control_efficient, register_time,
+                       unregister_attention_control_efficient, unregister_conv_control_efficient)
+
+
+class PnP:
+    def __init__(self, pipeline, num_inference_steps) -> None:
+        self.model = pipeline
+        self.model.scheduler.set_timesteps(num_inference_steps)
+
+    def init_pnp(self, conv_injection_t, qk_injection_t):
+        ts = self.model.scheduler.timesteps
+        self.qk_injection_timesteps = ts[:qk_injection_t] if qk_injection_t >= 0 else []
+        self.conv_injection_timesteps = ts[:conv_injection_t] if conv_injection_t >= 0 else []
+        register_attention_control_efficient(self.model, self.qk_injection_timesteps)
+        register_conv_control_efficient(self.model, self.conv_injection_timesteps)
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, latents: Optional[torch.Tensor] = None,
+                 pnp_attn_t: float = 0.5, pnp_f_t: float = 0.8, use_graph: bool = True, return_latents: bool = False,
+                 **unused):
+        model = self.model
+        dev = model.unet.device
+        model.scheduler.set_timesteps(num_inference_steps)
+        height = height or model.unet.config.sample_size * model.vae_scale_factor
+        width = width or model.unet.config.sample_size * model.vae_scale_factor
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        batch_size = len(prompt)
+        uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+        C = model.unet.config.in_channels
+        if latents is None:
+            latents = torch.randn((1, C, height // 8, width // 8), dtype=torch.float32)     # CPU generator, see p2p
+        latents = latents.to(dev).float() * model.scheduler.init_noise_sigma
+        if latents.shape[0] == 1:
+            latents = latents.expand(batch_size, C, height // 8, width // 8)
+        self.init_pnp(conv_injection_t=int(num_inference_steps * pnp_f_t), qk_injection_t=int(num_inference_steps * pnp_attn_t))
+        try:
+            context = torch.cat([uncond_embeddings, text_embeddings])
+            g = guidance_scale if guidance_scale > 1.0 else None
+            if g is None:
+                context = text_embeddings
+            loop = FusedDenoiser(model, context, batch_size, (height // 8, width // 8), g, use_graph=use_graph)
+            try:
+                if use_graph:
+                    latents = loop.run(latents)
+                else:                                         # the reference's own loop shape (:93-113), step by step
+                    loop.start(latents)
+                    for t in model.scheduler.timesteps:
+                        register_time(model, int(t))
+                        loop.step_once()
+                    latents = loop.result()
+            finally:
+                loop.release()
+        finally:
+            unregister_attention_control_efficient(model)
+            unregister_conv_control_efficient(model)
+        if return_latents:
+            return latents
+        return self.latent2image(latents)
+
+    @torch.no_grad()
+    def latent2image(self, latents, return_type="np"):
+        latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
+        image = self.model.vae.decode(latents)["sample"]
+        image = (image / 2 + 0.5).clamp(0, 1)
+        if return_type == "np":
+            image = image.cpu().permute(0, 2, 3, 1).numpy()
+            image = (image * 255).astype(np.uint8)
+        return image

@@ -373,12 +373,19 @@ class ResnetBlock2D(nn.Module):
             self.w2_fused, self.b2_fused = None, None
         self.conv2 = Conv2d(_f16(w2.reshape(cout, 3, 3, cout), dev), _f32(b2, dev), 3)
         self.temb_slot = temb_slot  # (offset, width) into the UNet's per-step time-embedding row
+        self._inject = None         # control.ControlPlan of a registered Plug-and-Play feature injection
 
     def forward(self, x, temb_row, skip=None):
         """x [B,H,W,C1] (+ skip [B,H,W,C2] = un-materialised channel concat); temb_row fp32 [B or 1, Cout]."""
         h = self.norm1(x, silu=True, x2=skip)
         h = hip.conv3x3(h, self.conv1.weight, self.conv1.bias, rowvec=temb_row)
         h = self.norm2(h, silu=True)
+        if self._inject is not None:
+            # Plug-and-Play replaces conv2's OUTPUT rows by the source image's (pnp/model/register.py:161-166); conv2 acts
+            # per batch row, so gathering its input rows is the same thing and keeps the fused shortcut / residual add
+            src = self._inject.feature_source(h.shape[0])
+            if src is not None:
+                h = hip.gather_rows(h, src)
         if self.conv_shortcut is None:
             return hip.conv3x3(h, self.conv2.weight, self.conv2.bias, residual=x)
         return hip.conv3x3_shortcut(h, self.w2_fused, self.b2_fused, x, skip)

@@ -182,6 +182,9 @@ int ief_cfg_ddim_step_f32(const float* eps_u, const float* eps_c, const float* x
 int ief_timestep_embedding_f16(const float* t, ief_half* out, int B, int dim, void* stream);
 /* out = a + b elementwise on fp16 (residual add when a hook owns Attention.forward) */
 int ief_add_f16(const ief_half* a, const ief_half* b, ief_half* out, long long n, void* stream);
+/* out[b][:] = in[src[b]][:] for fp16 [B][row_elems], src a DEVICE int32 [B] with values in [0, B): Plug-and-Play's
+ * feature injection (/root/reference/pnp/model/register.py:161-166) as a gather in front of conv2 */
+int ief_gather_rows_f16(const ief_half* in, ief_half* out, const int* src, int B, long long row_elems, void* stream);
 /* in-place row softmax over the last dim of fp16 [rows][L] (materialised attention of the VAE mid block, d = 512) */
 int ief_softmax_rows_f16(ief_half* x, int rows, int L, void* stream);
 /* out[c][r] = in[r][c] for fp16 [R][C] (V^T for the P.V GEMM of the VAE attention) */

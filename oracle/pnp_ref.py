@@ -1,0 +1,54 @@
+"""ORACLE (test infrastructure only — never imported by the product path): Plug-and-Play on the fp32 CPU UNet.
+
+Restates `/root/reference/pnp/model/register.py` and the loop of `/root/reference/pnp/model/sd_utils.py:93-113`:
+  - self-attention of `up_blocks[res].attentions[block]` for res, block in {1: [1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}
+    (:84): when the timestep is in the schedule, rows of batch blocks 1 and 3 take the Q and K of block 2 (:45-52);
+  - `up_blocks[1].resnets[1]`: conv2's output rows of blocks 1 and 3 are overwritten with block 2's (:161-166);
+  - batch = [uncond_src, uncond_tgt, cond_src, cond_tgt], CFG, DDIM step (`sd_utils.py:96-110`).
+Parity unpinned: the reference module imports diffusers (not installed), so no fixture could be generated from it;
+the rules above are read off its source.
+"""
+import torch
+
+from . import unet_ref
+from .p2p_ref import DDIMRef
+
+QK_BLOCKS = {1: [1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}
+
+
+def _inject_rows(t, heads=1):
+    """rows of blocks 1 and 3 <- block 2, batch-major layout with `heads` sub-rows per batch row"""
+    B = t.shape[0] // heads
+    s = B // 4
+    if s == 0 or B != 4 * s:
+        return t
+    t = t.clone()
+    v = t.reshape(B, heads, *t.shape[1:])
+    v[s:2 * s] = v[2 * s:3 * s]
+    v[3 * s:4 * s] = v[2 * s:3 * s]
+    return v.reshape(t.shape)
+
+
+def pnp_forward(sd, cfg, sample, t, ctx, inject_qk: bool, inject_conv: bool):
+    layers = {f"up_blocks.{r}.attentions.{b}.transformer_blocks.0.attn1" for r, bs in QK_BLOCKS.items() for b in bs}
+
+    def qkv_path_hook(q, k, v, is_cross, prefix, heads):
+        if inject_qk and not is_cross and prefix in layers:
+            return _inject_rows(q, heads), _inject_rows(k, heads), v
+        return q, k, v
+
+    res = {"up_blocks.1.resnets.1": _inject_rows} if inject_conv else {}
+    return unet_ref.unet_forward(sd, cfg, sample, t, ctx, qkv_path_hook=qkv_path_hook, res_inject=res)
+
+
+@torch.no_grad()
+def pnp_loop(sd, cfg, context, x_T, sched: DDIMRef, guidance_scale=7.5, pnp_attn_t=0.5, pnp_f_t=0.8, num_steps=None):
+    """context [4,77,C] = [uncond_src, uncond_tgt, cond_src, cond_tgt]; x_T [1,4,h,w] -> latents [2,4,h,w]"""
+    n = sched.num_inference_steps
+    qk_n, conv_n = int(n * pnp_attn_t), int(n * pnp_f_t)
+    lat = x_T.expand(2, *x_T.shape[1:]).clone()
+    for i, t in enumerate(sched.timesteps[: (num_steps or n)]):
+        eps = pnp_forward(sd, cfg, torch.cat([lat] * 2), t, context, i < qk_n, i < conv_n)
+        e_u, e_c = eps.chunk(2)
+        lat = sched.step(e_u + guidance_scale * (e_c - e_u), int(t), lat)
+    return lat

@@ -53,7 +53,7 @@ def resnet_block(sd: Dict[str, torch.Tensor], p: str, x, temb, groups: int, eps:
     return x + h
 
 
-def attention(sd, p: str, x, ctx, heads: int, hook, place: str, qkv_hook=None):
+def attention(sd, p: str, x, ctx, heads: int, hook, place: str, qkv_hook=None, qkv_path_hook=None):
     """`/root/reference/p2p/model/register.py:33-62`; x [B,N,C], ctx [B,L,Cc] or None."""
     is_cross = ctx is not None
     B, N, C = x.shape
@@ -68,8 +68,10 @@ def attention(sd, p: str, x, ctx, heads: int, hook, place: str, qkv_hook=None):
         return t.reshape(B, L, heads, d).permute(0, 2, 1, 3).reshape(B * heads, L, d)
 
     q, k, v = h2b(q), h2b(k), h2b(v)
-    if qkv_hook is not None:  # MasaCtrl / PnP style editors act on q,k,v
+    if qkv_hook is not None:  # MasaCtrl style editors act on q,k,v
         q, k, v = qkv_hook(q, k, v, is_cross, place, heads)
+    if qkv_path_hook is not None:  # PnP patches individual modules: the hook is told WHICH one (its parameter prefix)
+        q, k, v = qkv_path_hook(q, k, v, is_cross, p, heads)
     scale = d ** -0.5
     probs = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * scale, dim=-1)
     if hook is not None:
@@ -79,7 +81,7 @@ def attention(sd, p: str, x, ctx, heads: int, hook, place: str, qkv_hook=None):
     return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
 
-def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, qkv_hook=None):
+def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, qkv_hook=None, qkv_path_hook=None):
     B, C, H, W = x.shape
     res = x
     h = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
@@ -87,9 +89,9 @@ def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, q
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     b = p + ".transformer_blocks.0"
     n = F.layer_norm(h, (C,), sd[b + ".norm1.weight"], sd[b + ".norm1.bias"], 1e-5)
-    h = h + attention(sd, b + ".attn1", n, None, heads, hook, place, qkv_hook)
+    h = h + attention(sd, b + ".attn1", n, None, heads, hook, place, qkv_hook, qkv_path_hook)
     n = F.layer_norm(h, (C,), sd[b + ".norm2.weight"], sd[b + ".norm2.bias"], 1e-5)
-    h = h + attention(sd, b + ".attn2", n, ctx, heads, hook, place, qkv_hook)
+    h = h + attention(sd, b + ".attn2", n, ctx, heads, hook, place, qkv_hook, qkv_path_hook)
     n = F.layer_norm(h, (C,), sd[b + ".norm3.weight"], sd[b + ".norm3.bias"], 1e-5)
     g = F.linear(n, sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"])
     hid, gate = g.chunk(2, dim=-1)
@@ -101,7 +103,7 @@ def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, q
 
 
 # --------------------------------------------------------------------------- whole net
-def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=None):
+def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=None, qkv_path_hook=None, res_inject=None):
     """sample [B,4,H,W] fp32, timestep scalar/int tensor, ctx [B,77,Cc] -> eps [B,4,H,W].
 
     `hook(probs, is_cross, place)` is called once per Attention module in module-tree
@@ -109,7 +111,10 @@ def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=
     down_blocks before up_blocks before mid_block as attributes, but the reference iterates
     `named_children()` and the controller only counts calls, and the forward itself always
     executes down, mid, up).
+    `qkv_path_hook(q, k, v, is_cross, prefix, heads)` / `res_inject = {resnet prefix: fn(conv2 output)}` are the
+    per-module patches of Plug-and-Play (`/root/reference/pnp/model/register.py:27-90,100-182`).
     """
+    res_inject = res_inject or {}
     ch = cfg.block_out_channels
     nlev = len(ch)
     G, eps = cfg.norm_num_groups, cfg.norm_eps
@@ -131,7 +136,7 @@ def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=
             x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, temb, G, eps)
             if cfg.down_has_attn[i]:
                 x = transformer(sd, f"down_blocks.{i}.attentions.{j}", x, ctx, cfg.num_heads[i],
-                                G, hook, "down", qkv_hook)
+                                G, hook, "down", qkv_hook, qkv_path_hook)
             skips.append(x)
         if i < nlev - 1:
             p = f"down_blocks.{i}.downsamplers.0.conv"
@@ -139,7 +144,7 @@ def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=
             skips.append(x)
         tap(f"down{i}", x)
     x = resnet_block(sd, "mid_block.resnets.0", x, temb, G, eps)
-    x = transformer(sd, "mid_block.attentions.0", x, ctx, cfg.num_heads[-1], G, hook, "mid", qkv_hook)
+    x = transformer(sd, "mid_block.attentions.0", x, ctx, cfg.num_heads[-1], G, hook, "mid", qkv_hook, qkv_path_hook)
     x = resnet_block(sd, "mid_block.resnets.1", x, temb, G, eps)
     tap("mid", x)
     rev_attn = tuple(reversed(cfg.down_has_attn))
@@ -147,10 +152,10 @@ def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=
     for i in range(nlev):
         for j in range(cfg.layers_per_block + 1):
             x = torch.cat([x, skips.pop()], dim=1)
-            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, temb, G, eps)
+            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, temb, G, eps, res_inject.get(f"up_blocks.{i}.resnets.{j}"))
             if rev_attn[i]:
                 x = transformer(sd, f"up_blocks.{i}.attentions.{j}", x, ctx, rev_heads[i],
-                                G, hook, "up", qkv_hook)
+                                G, hook, "up", qkv_hook, qkv_path_hook)
         if i < nlev - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
             p = f"up_blocks.{i}.upsamplers.0.conv"
