@@ -74,7 +74,7 @@ def build_pipe(cfg_name, dev, rank, world):
         torch.cuda.synchronize()
     pipe = StableDiffusionPipeline(unet, WordPieceTokenizer(cfg.text_max_length),
                                    SyntheticTextEncoder(cfg.cross_attention_dim).to(dev),
-                                   AutoencoderKL(SD_VAE if cfg_name == "sd15" else TINY_VAE, device=dev),
+                                   AutoencoderKL(SD_VAE if cfg_name in ("sd15", "sd21") else TINY_VAE, device=dev),
                                    DDIMScheduler(), cfg, sd if rank == 0 else None)
     return pipe, cfg
 
@@ -101,6 +101,8 @@ def main():
     hip.load()
 
     pipe, cfg = build_pipe(args.config, dev, rank, world)
+    from ief_amd import weights as _w
+    nparams = _w.num_params(cfg)
     pipe.scheduler.set_timesteps(MAX_STEPS)
     hw = args.latent or cfg.sample_size
     # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19)
@@ -157,11 +159,11 @@ def main():
     register_attention_control(pipe, ctrl)
 
     out = {
-        "metric": f"denoising steps/sec (SD1.5 {hw * 8}x{hw * 8} P2P edit step, UNet batch 4)",
+        "metric": f"denoising steps/sec ({MODEL_NAMES.get(args.config, args.config)} {hw * 8}x{hw * 8} P2P edit step, UNet batch 4)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{args.config} UNet (859.5M params) P2P AttentionRefine edit step, 2 prompts x CFG = batch 4, "
+        "config": {"workload": f"{args.config} UNet ({nparams / 1e6:.1f}M params) P2P AttentionRefine edit step, 2 prompts x CFG = batch 4, "
                                f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4; "
                                "one independent edit per GPU",
                    "images_per_sec_equiv": round(value / 250.0, 4)},
@@ -177,6 +179,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+MODEL_NAMES = {"sd15": "SD1.5", "sd21": "SD2.1", "tiny": "tiny", "small": "small", "small21": "small21"}
 
 
 def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, steps=40):

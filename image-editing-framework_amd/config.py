@@ -25,6 +25,9 @@ class UNetConfig:
     norm_eps: float = 1e-5
     time_embed_dim_mult: int = 4
     text_max_length: int = 77
+    # SD2.x: Transformer2DModel.proj_in / proj_out are nn.Linear on tokens ([C, C] weights) instead of 1x1 convs
+    # ([C, C, 1, 1]); the arithmetic is the same GEMM, only the checkpoint's tensor shapes differ
+    use_linear_projection: bool = False
 
     @property
     def time_embed_dim(self) -> int:
@@ -54,6 +57,15 @@ SMALL = UNetConfig(
     num_heads=(8, 8),
 )
 
+# SD2.1 (768-v) shape family — the public `unet/config.json` of stabilityai/stable-diffusion-2-1
+# (`/root/reference/pnp/sd_mapping.py:4`): 96x96 latents (768x768 px), OpenCLIP context 1024, head dim 64
+# (attention_head_dim = [5, 10, 20, 20] = number of heads), linear projections.  865,910,724 parameters.
+SD21 = UNetConfig(sample_size=96, cross_attention_dim=1024, num_heads=(5, 10, 20, 20), use_linear_projection=True)
+
+# SD2.1 head geometry (d = 64) on the small two-level net
+SMALL21 = UNetConfig(sample_size=32, block_out_channels=(320, 640), down_has_attn=(True, True), cross_attention_dim=1024,
+                     num_heads=(5, 10), use_linear_projection=True)
+
 SCHEDULER_CONFIG = {
     "beta_end": 0.012,
     "beta_schedule": "scaled_linear",
@@ -67,4 +79,4 @@ SCHEDULER_CONFIG = {
     "use_karras_sigmas": False,
 }
 
-CONFIGS = {"sd15": SD15, "tiny": TINY, "small": SMALL}
+CONFIGS = {"sd15": SD15, "tiny": TINY, "small": SMALL, "sd21": SD21, "small21": SMALL21}

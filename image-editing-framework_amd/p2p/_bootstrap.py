@@ -30,8 +30,8 @@ def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32):
     from ief_amd.p2p.sd_mapping import sd_maps
     model_key = sd_maps[sd_version]          # KeyError for unknown versions, as in the reference (:26)
     scheduler = DDIMScheduler.from_config(SCHEDULER_CONFIG)
-    if sd_version in ("1.5", "1.4", "tiny", "small"):
+    if sd_version in ("1.5", "1.4", "2.1", "tiny", "small", "small21"):
         return StableDiffusionPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device)
-    if sd_version in ("2.1", "xl-base"):
-        raise ValueError(f"sd_version {sd_version}: SD2.x / SDXL shape families are not built yet (DESIGN.md, next rows)")
+    if sd_version in ("xl-base",):
+        raise ValueError(f"sd_version {sd_version}: the SDXL shape family is not built yet (DESIGN.md, next rows)")
     raise ValueError("please use the right sd_version")

@@ -69,7 +69,7 @@ class StableDiffusionPipeline:
             sd = _weights.synthetic_state_dict(cfg, seed)
             tokenizer = WordPieceTokenizer(cfg.text_max_length)
             text_encoder = SyntheticTextEncoder(cfg.cross_attention_dim)
-            vae = AutoencoderKL(SD_VAE if parts[1] == "sd15" else TINY_VAE, device=device)
+            vae = AutoencoderKL(SD_VAE if parts[1] in ("sd15", "sd21") else TINY_VAE, device=device)
         elif os.path.isdir(model_key):
             cfg, sd = _load_local_unet(model_key)
             tokenizer, text_encoder = _load_local_text(model_key, cfg)
@@ -111,9 +111,8 @@ def _load_local_unet(path):
         block_out_channels=tuple(c["block_out_channels"]),
         down_has_attn=tuple("CrossAttn" in t for t in c["down_block_types"]),
         layers_per_block=c["layers_per_block"], cross_attention_dim=c["cross_attention_dim"], num_heads=heads,
-        norm_num_groups=c["norm_num_groups"], norm_eps=c.get("norm_eps", 1e-5))
-    if c.get("use_linear_projection", False):
-        raise NotImplementedError("linear proj_in/proj_out (SD2.x) is a next-tier shape family (SURVEY.md §8f-4)")
+        norm_num_groups=c["norm_num_groups"], norm_eps=c.get("norm_eps", 1e-5),
+        use_linear_projection=bool(c.get("use_linear_projection", False)))
     sd = load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
     missing = [k for k in _weights.unet_param_shapes(cfg) if k not in sd]
     if missing:

@@ -85,8 +85,11 @@ def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, q
     B, C, H, W = x.shape
     res = x
     h = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
-    h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
-    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    if sd[p + ".proj_in.weight"].dim() == 2:   # SD2.x: use_linear_projection (reshape to tokens, then nn.Linear)
+        h = F.linear(h.permute(0, 2, 3, 1).reshape(B, H * W, C), sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    else:
+        h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     b = p + ".transformer_blocks.0"
     n = F.layer_norm(h, (C,), sd[b + ".norm1.weight"], sd[b + ".norm1.bias"], 1e-5)
     h = h + attention(sd, b + ".attn1", n, None, heads, hook, place, qkv_hook, qkv_path_hook)
@@ -97,8 +100,11 @@ def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, q
     hid, gate = g.chunk(2, dim=-1)
     g = hid * F.gelu(gate)
     h = h + F.linear(g, sd[b + ".ff.net.2.weight"], sd[b + ".ff.net.2.bias"])
-    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-    h = F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    if sd[p + ".proj_out.weight"].dim() == 2:
+        h = F.linear(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    else:
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        h = F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
     return h + res
 
 

@@ -56,6 +56,7 @@ def test_tile_plans():
 
 def test_param_inventory_matches_sd15():
     assert weights.num_params(config.SD15) == 859_520_964      # the published SD1.5 UNet parameter count
+    assert weights.num_params(config.SD21) == 865_910_724      # the published SD2.1 UNet parameter count
     sd = weights.synthetic_state_dict(config.TINY, 0)
     sd2 = weights.synthetic_state_dict(config.TINY, 0)
     assert all(torch.equal(sd[k], sd2[k]) for k in sd)          # deterministic

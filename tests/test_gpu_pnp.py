@@ -125,3 +125,42 @@ def test_pnp_clis(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     for name in ("source.png", "inversion.png", "edit.png"):
         assert (tmp_path / "exp" / name).exists()
+
+
+def test_sd21_shape_family_forward_and_pnp():
+    """SD2.1 geometry (linear proj_in / proj_out, head dim 64, context 1024) on the two-level net: plain and injected
+    forward against the oracle"""
+    pipe = StableDiffusionPipeline.from_pretrained("synthetic:small21", keep_state_dict=True)
+    cfg = pipe.cfg
+    assert cfg.use_linear_projection and pipe._state_dict["mid_block.attentions.0.proj_in.weight"].dim() == 2
+    pipe.scheduler.set_timesteps(10)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    ctx = torch.randn(4, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    t = int(pipe.scheduler.timesteps[0])
+    plain = unet_ref.unet_forward(pipe._state_dict, cfg, x, t, ctx)
+    e0 = rel_err(pipe.unet(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV))["sample"], plain)
+    # the two-level net has a single decoder block with attention at index 1: PnP's block table (1: [1, 2]) applies
+    ref = pnp_ref.pnp_forward(pipe._state_dict, cfg, x, t, ctx, True, True)
+    ts = pipe.scheduler.timesteps
+    register_attention_control_efficient(pipe, ts[:10])
+    register_conv_control_efficient(pipe, ts[:10])
+    try:
+        register_time(pipe, t)
+        e1 = rel_err(pipe.unet(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV))["sample"], ref)
+    finally:
+        unregister_attention_control_efficient(pipe)
+        unregister_conv_control_efficient(pipe)
+    print(f"small21: plain forward {e0:.2e}, PnP forward {e1:.2e}; injection moves the output by {rel_err(plain, ref):.2e}")
+    assert e0 < 2e-2 and e1 < 2e-2
+
+
+def test_pnp_pie_driver_sd21_family(tmp_path):
+    pnp = os.path.join(ROOT, "image-editing-framework_amd", "pnp")
+    r = subprocess.run([sys.executable, os.path.join(pnp, "test.py"), "--sd_version", "small21", "--synthetic", "2",
+                        "--invert_batch", "2", "--exp_path", str(tmp_path / "t")], cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["images"] == 2 and rec["images_per_sec"] > 0
