@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=str, default="sd15")
     ap.add_argument("--latent", type=int, default=0, help="latent side (default: the config's sample_size; 128 = 1024x1024 px)")
+    ap.add_argument("--uncond", choices=["per-step", "fixed"], default="per-step",
+                    help="per-step: the unconditional embedding changes every step, as after null-text inversion "
+                    "(P2P_NTI, BASELINE.json configs[1]): cross-attention K/V are re-projected inside every step; "
+                    "fixed: plain P2P (edit_syn.py), K/V projected once per edit")
     ap.add_argument("--in-flight", type=str, default="2,4", help="also time E independent edits stepped concurrently per GPU "
                     "(comma list, '' to skip); reported beside the headline value, which is ONE edit at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +116,13 @@ def main():
     ctx = torch.cat([u, c])
     ctrl = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
     register_attention_control(pipe, ctrl)
-    loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5)
+    # configs[1] (edit_real.py, null-text inversion): P2P_NTI swaps in one optimised unconditional embedding per step
+    # (/root/reference/p2p/model/sd_utils.py:133-138); synthetic stand-ins of the right shape here
+    uncond_list = None
+    if args.uncond == "per-step":
+        g = torch.Generator().manual_seed(1234 + rank)
+        uncond_list = [(u[:1].cpu() + 0.01 * torch.randn(1, *u.shape[1:], generator=g)).to(dev) for _ in range(MAX_STEPS)]
+    loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list)
 
     def run_steps(n):
         """n steps, restarting the edit (controller + step counters) whenever 50 are used up"""
@@ -155,7 +165,7 @@ def main():
     # throughput schedule: E independent edits in flight per GPU (denoise.run_interleaved); the headline stays E = 1
     in_flight = {}
     for E in [int(e) for e in args.in_flight.split(",") if e.strip()]:
-        in_flight[str(E)] = round(edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world), 3)
+        in_flight[str(E)] = round(edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_list), 3)
     register_attention_control(pipe, ctrl)
 
     out = {
@@ -164,8 +174,10 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{args.config} UNet ({nparams / 1e6:.1f}M params) P2P AttentionRefine edit step, 2 prompts x CFG = batch 4, "
-                               f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4; "
-                               "one independent edit per GPU",
+                               f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4, "
+                               + ("per-step null-text unconditional embeddings (P2P_NTI, edit_real.py); "
+                                  if args.uncond == "per-step" else "fixed unconditional embedding (edit_syn.py); ")
+                               + "one independent edit per GPU",
                    "images_per_sec_equiv": round(value / 250.0, 4)},
         # same edit step, E independent edits stepped concurrently per GPU (steps/s over all ranks); the schedule
         # `p2p/test.py --in_flight E` uses for PIE-Bench throughput.  The headline `value` above is E = 1.
@@ -184,7 +196,7 @@ def main():
 MODEL_NAMES = {"sd15": "SD1.5", "sd21": "SD2.1", "tiny": "tiny", "small": "small", "small21": "small21"}
 
 
-def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, steps=40):
+def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_list=None, steps=40):
     """steps/s (all ranks) with E independent P2P edits stepped concurrently on each GPU"""
     from ief_amd.denoise import FusedDenoiser, run_interleaved
     from ief_amd.p2p.model.attention_control import AttentionRefine
@@ -193,7 +205,7 @@ def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, steps=40):
     for _ in range(E):
         c = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
         register_attention_control(pipe, c)
-        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5)
+        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list)
         lp.start(x_T)
         unregister_attention_control(pipe, None)
         loops.append(lp); ctrls.append(c)

@@ -41,6 +41,7 @@ from .config import UNetConfig
 # removes the 48 LayerNorm launches of a UNet forward and one read + write of the residual stream each.  IEF_FOLD_LN=0
 # keeps the separate kernels (A/B timing; the generic hook path always uses them).
 FOLD_LN = os.environ.get("IEF_FOLD_LN", "1") == "1"
+KV_ONE_GEMM = os.environ.get("IEF_KV_ONE_GEMM", "1") == "1"   # A/B switch of the one-GEMM per-step K/V projection
 
 
 def _fold_ln(w16, bias32, gamma, beta):
@@ -159,6 +160,7 @@ class Attention(nn.Module):
         self._plan = None          # control.ControlPlan when a lowered controller is registered
         self._kv_key, self._kv = None, None
         self.cache_kv = True       # False when the context changes every step (null-text embeddings)
+        self._kv_view = None
         self.ln_w = self.ln_b = self.ln_c1 = None   # input projection with the preceding LayerNorm folded in
         self.ln_eps = 1e-5
 
@@ -210,6 +212,8 @@ class Attention(nn.Module):
 
     # ---- cross-attention K/V of a fixed context are step-invariant: project once per context
     def context_kv(self, ctx):
+        if self._kv_view is not None:       # this forward's slice of the one-GEMM projection of all layers (UNet.forward)
+            return self._kv_view
         if not self.cache_kv:
             return hip.gemm(ctx, self.w_kv)
         # identity (not address) of the context tensor: the cache holds a reference, so the allocator
@@ -603,6 +607,16 @@ class UNet2DConditionModel(nn.Module):
         trow = lambda r: temb_row[:, r.temb_slot[0]:r.temb_slot[0] + r.temb_slot[1]].contiguous()
         if self._plan is not None:
             self._plan.begin_forward(B)
+        # a context that changes every step (null-text embeddings: Attention.cache_kv is off) is projected for ALL 16
+        # cross-attention layers by ONE GEMM; each layer reads its column slice
+        cross = self._cross_modules()
+        per_step_kv = KV_ONE_GEMM and bool(cross) and not cross[0].cache_kv and all(m.is_native() for m in cross)
+        if per_step_kv:
+            kv_all = hip.gemm(ctx, self._kv_all_weight())
+            off = 0
+            for m in cross:
+                m._kv_view = kv_all[..., off:off + 2 * m.inner_dim]
+                off += 2 * m.inner_dim
 
         def tap(name, v):  # debugging / parity aid: same tap points as oracle/unet_ref.py
             if taps is not None:
@@ -635,11 +649,26 @@ class UNet2DConditionModel(nn.Module):
             tap(f"up{bi}", h)
         h = self.conv_norm_out(h, silu=True)
         eps = hip.conv_out(h, self.conv_out.weight, self.conv_out.bias)
+        if per_step_kv:
+            for m in cross:
+                m._kv_view = None
         if self._plan is not None:
             self._plan.end_forward(B)
         if not return_dict:
             return (eps,)
         return UNetOutput(sample=eps)
+
+    def _cross_modules(self):
+        c = getattr(self, "_cross_cache", None)
+        if c is None:
+            c = self._cross_cache = [m for m in self.attention_modules() if m.is_cross]
+        return c
+
+    def _kv_all_weight(self):
+        w = getattr(self, "_w_kv_all", None)
+        if w is None:
+            w = self._w_kv_all = torch.cat([m.w_kv for m in self._cross_modules()], 0).contiguous()
+        return w
 
     def _ctx_f16(self, ctx):
         """fp32 context -> fp16 once per distinct tensor (keeps the cross-attention K/V cache valid)."""
