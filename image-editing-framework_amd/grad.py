@@ -35,15 +35,19 @@ class UNetAdjoint:
     def __init__(self, unet, grad_scale: float = 1.0):
         self.unet = unet
         self.grad_scale = float(grad_scale)
-        self._wt: Dict[int, torch.Tensor] = {}
+        # packed adjoint weights are shared by every adjoint of this UNet (several images in flight: nti.run_many)
+        shared = unet.__dict__.setdefault("_adjoint_shared", {})
+        self._wt: Dict[int, torch.Tensor] = shared.setdefault("wt", {})
         cross = [m for m in unet.attention_modules() if m.is_cross]
         off = 0
         for m in cross:
             m._kv_off = off
             off += 2 * m.inner_dim
         self.kv_width = off
-        self.w_kv_all = torch.cat([m.w_kv for m in cross], 0).contiguous()      # [sum 2C, ctx_dim]
-        self.w_kv_all_t = self.w_kv_all.t().contiguous()                        # [ctx_dim, sum 2C]
+        if "w_kv_all" not in shared:
+            shared["w_kv_all"] = torch.cat([m.w_kv for m in cross], 0).contiguous()      # [sum 2C, ctx_dim]
+            shared["w_kv_all_t"] = shared["w_kv_all"].t().contiguous()                  # [ctx_dim, sum 2C]
+        self.w_kv_all, self.w_kv_all_t = shared["w_kv_all"], shared["w_kv_all_t"]
         # backward stops at the FIRST transformer of the forward order: nothing upstream of it depends on the context
         self._first_tr = None
         for blk in unet.down_blocks:

@@ -97,11 +97,11 @@ class NullTextOptimizer:
         else:
             (self._body_cond, self._body_inner, self._body_tail)[which]()
 
-    # ------------------------------------------------------------------ public
-    def run(self, latents: List[torch.Tensor], uncond: torch.Tensor, num_inner_steps: int, epsilon: float,
-            num_outer: Optional[int] = None) -> List[torch.Tensor]:
-        """latents: the 51 inversion latents (x_0 .. x_T); uncond [1,77,C].  Returns one [1,77,C] fp32 per timestep."""
+    # ------------------------------------------------------------------ public: one image = begin, then per timestep
+    # outer_begin -> inner_step / inner_loss ... -> outer_end  (so several images can be interleaved: `run_many`)
+    def begin(self, latents: List[torch.Tensor], uncond: torch.Tensor):
         dev = self.dev
+        self._latents = latents
         self.lat.copy_(latents[-1].to(dev).float())
         self.param.copy_(uncond.to(dev).float()[:1])
         hip.to_f16(self.param, out=self.p16)
@@ -110,31 +110,90 @@ class NullTextOptimizer:
         elif not self.use_graph:
             for m in self.unet.attention_modules():
                 m.cache_kv = False
-        out = []
+        self.out: List[torch.Tensor] = []
         self.inner_steps_run, self.last_losses = [], []
+
+    def outer_begin(self, i: int):
+        latents = self._latents
+        self.temb.copy_(self.temb_table[i:i + 1])
+        self.coef.copy_(self.coef_table[i])
+        self.target.copy_(latents[len(latents) - i - 2].to(self.dev).float())
+        self.m.zero_(), self.v.zero_(), self.adam_step.zero_()          # `Adam([uncond], lr=...)` anew (nti.py:17)
+        self.hyper[0:1].fill_(1e-2 * (1.0 - i / 100.0))
+        self._run(0)
+        self._done, self._loss = 0, float("nan")
+
+    def inner_step(self):
+        self._run(1)
+        self._done += 1
+
+    def inner_loss(self) -> float:
+        """loss of the embedding BEFORE the Adam step just taken (what the reference's `loss.item()` reads, :31)"""
+        self._loss = float(self.stats[0].item())
+        return self._loss
+
+    def outer_end(self):
+        self.inner_steps_run.append(self._done)
+        self.last_losses.append(self._loss)
+        self.out.append(self.param.clone())
+        self._run(2)
+
+    def run(self, latents: List[torch.Tensor], uncond: torch.Tensor, num_inner_steps: int, epsilon: float,
+            num_outer: Optional[int] = None) -> List[torch.Tensor]:
+        """latents: the 51 inversion latents (x_0 .. x_T); uncond [1,77,C].  Returns one [1,77,C] fp32 per timestep."""
+        self.begin(latents, uncond)
         n = self.num_steps if num_outer is None else num_outer
         for i in range(n):
-            self.temb.copy_(self.temb_table[i:i + 1])
-            self.coef.copy_(self.coef_table[i])
-            self.target.copy_(latents[len(latents) - i - 2].to(dev).float())
-            self.m.zero_(), self.v.zero_(), self.adam_step.zero_()          # `Adam([uncond], lr=...)` anew (nti.py:17)
-            self.hyper[0:1].fill_(1e-2 * (1.0 - i / 100.0))
-            self._run(0)
-            done, loss = 0, float("nan")
+            self.outer_begin(i)
             for j in range(num_inner_steps):
-                self._run(1)
-                done += 1
-                loss = float(self.stats[0].item())
-                if loss < epsilon + i * 2e-5:
+                self.inner_step()
+                if self.inner_loss() < epsilon + i * 2e-5:
                     break
-            self.inner_steps_run.append(done)
-            self.last_losses.append(loss)
-            out.append(self.param.clone())
-            self._run(2)
-        return out
+            self.outer_end()
+        return self.out
 
     def release(self):
         self._graphs = None
         for m in self.unet.attention_modules():
             m.cache_kv = True
             m._kv_key, m._kv = None, None
+
+
+def run_many(opts: List[NullTextOptimizer], latents_list, uncond_list, num_inner_steps: int, epsilon: float,
+             num_outer: Optional[int] = None) -> List[List[torch.Tensor]]:
+    """Null-text optimisation of several independent images in flight, each on its own stream.
+
+    An inner iteration is ~900 dependent launches at UNet batch 1 — almost pure dispatch latency — so E images
+    stepped in turn fill each other's gaps.  Every image keeps its own early stop; per round the host reads one loss
+    per still-active image (the reference's `loss.item()`, one image at a time there).  Same values as `run` per image."""
+    cur = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in opts]
+    for o, lat, unc in zip(opts, latents_list, uncond_list):
+        o.begin(lat, unc)                       # captures on first use (sequential: graphs share the UNet modules)
+    for s in streams:
+        s.wait_stream(cur)
+    n = min(o.num_steps for o in opts) if num_outer is None else num_outer
+    for i in range(n):
+        for o, s in zip(opts, streams):
+            with torch.cuda.stream(s):
+                o.outer_begin(i)
+        active = list(range(len(opts)))
+        for j in range(num_inner_steps):
+            for k in active:
+                with torch.cuda.stream(streams[k]):
+                    opts[k].inner_step()
+            still = []
+            for k in active:
+                with torch.cuda.stream(streams[k]):
+                    if opts[k].inner_loss() >= epsilon + i * 2e-5:
+                        still.append(k)
+            active = still
+            if not active:
+                break
+        for o, s in zip(opts, streams):
+            with torch.cuda.stream(s):
+                o.outer_end()
+    for s in streams:
+        cur.wait_stream(s)
+    torch.cuda.synchronize()
+    return [o.out for o in opts]

@@ -7,7 +7,7 @@ activation-gradient pass -> Adam) and reads the loss back for the reference's ea
 The numerics of the loop are pinned in the oracle against the reference (`oracle/p2p_ref.py:
 null_optimization`, fixture G8); `tests/test_gpu_grad.py` holds this class to that oracle.
 """
-from ...nti import NullTextOptimizer
+from ...nti import NullTextOptimizer, run_many
 from .ddim import ddim_inversion
 
 
@@ -23,3 +23,18 @@ class NTI(ddim_inversion):
             opt.release()
         self.inner_steps_run = opt.inner_steps_run      # diagnostics: Adam steps taken per timestep
         return out
+
+    def null_optimization_many(self, model, latents_list, contexts, num_inner_steps, epsilon, guidance_scale):
+        """`null_optimization` for several independent images IN FLIGHT on one GPU (`ief_amd.nti.run_many`): a
+        throughput schedule the reference does not have; per image the values are those of `null_optimization`.
+        latents_list[k]: the 51 inversion latents of image k; contexts[k]: its [2,77,C] (uncond, cond)."""
+        opts = []
+        try:
+            for latents, context in zip(latents_list, contexts):
+                opts.append(NullTextOptimizer(model, context.chunk(2)[1], guidance_scale, tuple(latents[-1].shape[-2:])))
+            outs = run_many(opts, latents_list, [c.chunk(2)[0] for c in contexts], num_inner_steps, epsilon)
+        finally:
+            for o in opts:
+                o.release()
+        self.inner_steps_run = [o.inner_steps_run for o in opts]
+        return outs

@@ -97,7 +97,8 @@ class P2P:
     def edit_many(self, model, jobs, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                   height: Optional[int] = None, width: Optional[int] = None):
         """Several independent edits IN FLIGHT on one GPU (a throughput schedule the reference does not have: its
-        drivers call `text2image_ldm_stable` once per image).  jobs: [(prompts, controller, latent x_T [1,4,h,w])];
+        drivers call `text2image_ldm_stable` once per image).  jobs: [(prompts, controller, latent x_T [1,4,h,w])] or
+        [(prompts, controller, x_T, uncond_embeddings_list)] (null-text embeddings, as `P2P_NTI`);
         every controller must be one of the lowered classes.  Each job's loop is captured while its controller is
         registered, then all loops are stepped in turn on their own streams (`denoise.run_interleaved`).  Returns
         [(images uint8 [len(prompts),H,W,3], x_T)] — the same values as one `text2image_ldm_stable` call per job."""
@@ -106,14 +107,16 @@ class P2P:
         model.scheduler.set_timesteps(num_inference_steps)
         loops, firsts = [], []
         try:
-            for prompt, controller, latent in jobs:
+            for job in jobs:
+                prompt, controller, latent = job[:3]
+                uncond_list = job[3] if len(job) > 3 else None
                 register_attention_control(model, controller)
                 if not _fusable(model, controller, False):
                     raise RuntimeError("edit_many: only controllers lowered to a device plan can run concurrently")
                 uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
                 latent, latents = self.init_latent(latent, model, height, width, None, len(prompt))
                 loop = FusedDenoiser(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
-                                     (height // 8, width // 8), guidance_scale)
+                                     (height // 8, width // 8), guidance_scale, uncond_list=uncond_list)
                 loop.start(latents)
                 loops.append(loop)
                 firsts.append(latent)

@@ -11,11 +11,12 @@ files; no collective touches the data path.  Launch with
 The only collective is the final all_reduce of the image counters / time for the images/sec report.
 
 `--synthetic N` replaces the (unavailable) PIE download by N generated images so the loop can be timed.
-`--invert_batch K` (ddim inversion only) inverts K images of a rank's shard in ONE batched DDIM loop (UNet batch K
+`--invert_batch K` inverts K images of a rank's shard in ONE batched DDIM loop (UNet batch K
 instead of K loops at batch 1; images are independent, results are those of the per-image loop) before editing them one
 by one: at batch 1 the UNet is bound by per-kernel latency, so K = 4 nearly quarters the inversion time per image.
-`--in_flight E` (ddim only) keeps E edits in flight on the GPU (`P2P.edit_many`): an edit step is ~380 dependent
-launches, and E independent chains fill each other's dispatch gaps.  Both change the schedule, not the results.
+`--in_flight E` keeps E images in flight on the GPU, for the edits (`P2P.edit_many`) and for the null-text
+optimisations (`NTI.null_optimization_many`): a step is hundreds of dependent launches, and E independent chains fill
+each other's dispatch gaps.  Both change the schedule, not the results.
 """
 import argparse
 import json
@@ -55,8 +56,9 @@ def main(argv=None):
     ap.add_argument("--inversion_type", type=str, default="ddim")
     ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
     ap.add_argument("--no_save", action="store_true")
-    ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop (ddim only)")
-    ap.add_argument("--in_flight", type=int, default=1, help="edits stepped concurrently on one GPU (ddim only)")
+    ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop")
+    ap.add_argument("--in_flight", type=int, default=1,
+                    help="independent images stepped concurrently on one GPU (null-text optimisations and edits)")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,9 +97,9 @@ def main(argv=None):
         save_img(images[0], os.path.join(out_path, "inversion.png"))
         save_img(images[1], os.path.join(out_path, "edit.png"))
 
-    ddim = args.inversion_type == "ddim"
-    bs = max(1, args.invert_batch) if ddim else 1
-    E = max(1, args.in_flight) if ddim else 1
+    nti = args.inversion_type == "null-text"
+    bs = max(1, args.invert_batch)
+    E = max(1, args.in_flight)
     group = max(bs, E)
     for c0 in range(0, len(mine), group):
         chunk = [items[i] for i in mine[c0:c0 + group]]
@@ -108,20 +110,34 @@ def main(argv=None):
                               edit_type_of(source_prompt, target_prompt), device)
             save(image_path, originals[0], images)
             continue
-        # inversion: batched over `bs` images at a time
-        x_T = []
+        # inversion: batched over `bs` images at a time (the DDIM loop is the same for both inversion types)
+        traj, ctxs = [], []
         for b0 in range(0, len(chunk), bs):
             latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32)
                                 for im in originals[b0:b0 + bs]])
-            latents, _ = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk[b0:b0 + bs]])
-            x_T += [latents[-1][j:j + 1].clone() for j in range(latent.shape[0])]
+            latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk[b0:b0 + bs]])
+            k = latent.shape[0]
+            unc, cnd = context.chunk(2)
+            for j in range(k):
+                traj.append([t[j:j + 1].clone() for t in latents])
+                ctxs.append(torch.cat([unc[j:j + 1], cnd[j:j + 1]]))
+        x_T = [t[-1] for t in traj]
+        # null-text optimisation: E images in flight
+        uncond = [None] * len(chunk)
+        if nti:
+            for e0 in range(0, len(chunk), E):
+                part = list(range(e0, min(e0 + E, len(chunk))))
+                outs = invertor.null_optimization_many(pipe, [traj[j] for j in part], [ctxs[j] for j in part], 10, 1e-5, 7.5)
+                for j, o in zip(part, outs):
+                    uncond[j] = o
         # edits: E in flight
         for e0 in range(0, len(chunk), E):
             part = list(range(e0, min(e0 + E, len(chunk))))
             if len(part) == 1:
                 j = part[0]
                 _, src, tgt = chunk[j]
-                results = [edit_latent(pipe, editor, x_T[j], [src], [tgt], edit_type_of(src, tgt), device)]
+                extra = {"uncond_embeddings_list": uncond[j]} if nti else None
+                results = [edit_latent(pipe, editor, x_T[j], [src], [tgt], edit_type_of(src, tgt), device, extra)]
             else:
                 jobs, ctrls = [], []
                 for j in part:
@@ -130,7 +146,7 @@ def main(argv=None):
                     ctrl = cls(prompts=[src, tgt], tokenizer=pipe.tokenizer, num_steps=50, cross_replace_steps=0.8,
                                self_replace_steps=0.6, device=device)
                     ctrls.append(ctrl)
-                    jobs.append(([src, tgt], ctrl, x_T[j]))
+                    jobs.append(([src, tgt], ctrl, x_T[j]) + ((uncond[j],) if nti else ()))
                 results = [im for im, _ in editor.edit_many(pipe, jobs, num_inference_steps=50, guidance_scale=7.5)]
                 for ctrl in ctrls:
                     ctrl.reset()

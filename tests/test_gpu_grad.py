@@ -328,3 +328,22 @@ def test_nti_reduces_reconstruction_error(tiny):
         tuned = replay([e.cpu() for e in emb])
     print(f"reconstruction mse per step: plain {base}, null-text optimised {tuned}")
     assert tuned[-1] < base[-1]
+
+
+def test_nti_many_in_flight_matches_single(tiny):
+    """two images optimised concurrently (streams, interleaved graph replays) = each optimised alone, bit for bit"""
+    from ief_amd.nti import run_many
+    steps, inner, gs = 4, 4, 7.5
+    cases = [_nti_case(tiny, steps, inner, seed=s) for s in (1, 2)]
+    singles = []
+    for ctx, lat_ref, _ in cases:
+        opt = NullTextOptimizer(tiny, ctx[1:], gs, tuple(lat_ref[-1].shape[-2:]))
+        singles.append((opt.run([l.to(DEV) for l in lat_ref], ctx[:1], inner, 1e-5), list(opt.inner_steps_run)))
+        opt.release()
+    opts = [NullTextOptimizer(tiny, ctx[1:], gs, tuple(lat_ref[-1].shape[-2:])) for ctx, lat_ref, _ in cases]
+    outs = run_many(opts, [[l.to(DEV) for l in lat_ref] for _, lat_ref, _ in cases], [ctx[:1] for ctx, _, _ in cases], inner, 1e-5)
+    for k, o in enumerate(opts):
+        assert o.inner_steps_run == singles[k][1]
+        for a, b in zip(outs[k], singles[k][0]):
+            assert torch.equal(a, b)
+        o.release()
