@@ -177,8 +177,7 @@ def main():
                                f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4, "
                                + ("per-step null-text unconditional embeddings (P2P_NTI, edit_real.py); "
                                   if args.uncond == "per-step" else "fixed unconditional embedding (edit_syn.py); ")
-                               + "one independent edit per GPU",
-                   "images_per_sec_equiv": round(value / 250.0, 4)},
+                               + "one independent edit per GPU"},
         # same edit step, E independent edits stepped concurrently per GPU (steps/s over all ranks); the schedule
         # `p2p/test.py --in_flight E` uses for PIE-Bench throughput.  The headline `value` above is E = 1.
         "throughput_edits_in_flight": in_flight,
