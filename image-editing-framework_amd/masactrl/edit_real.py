@@ -1,0 +1,81 @@
+"""Invert a real image, then edit it with MasaCtrl — CLI of `/root/reference/masactrl/edit_real.py` (same flags and
+defaults: `--inversion_type` "null-text" (:27), `STEP = 4`, `LAYPER = 10`; outputs `./exp/source.png`,
+`./exp/inversion.png`, `./exp/edit.png`)."""
+import argparse
+import os
+import sys
+
+import torch
+from PIL import Image
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "p2p"))
+from _bootstrap import load_pipe, seed_everything  # noqa: E402
+
+from ief_amd.masactrl.model.attention_control import MutualSelfAttentionControl  # noqa: E402
+from ief_amd.masactrl.model.register import regiter_attention_editor_diffusers, unregister_attention_control  # noqa: E402
+from ief_amd.masactrl.model.sd_utils import MasaCtrl, MasaCtrl_NTI  # noqa: E402
+from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
+from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
+
+parser = argparse.ArgumentParser("General config")
+parser.add_argument("--sd_version", type=str, default="1.5")
+parser.add_argument("--device", type=int, default=0)
+parser.add_argument("--seed", type=int, default=42)
+parser.add_argument("--source_prompt", type=str, default="a gray horse in the field")
+parser.add_argument("--target_prompt", type=str, default="a whie horse in the field")
+parser.add_argument("--source_image", type=str, default="./test.jpg")
+parser.add_argument("--inversion_type", type=str, default="null-text")
+
+STEP, LAYPER = 4, 10
+NUM_INNER_STEPS, EARLY_STOP_EPSILON = 10, 1e-5
+
+
+def edit_one(pipe, editor, invertor, image, source_prompt, target_prompt, inversion_type, device, size,
+             num_inference_steps=50, guidance_scale=7.5):
+    """invert + MasaCtrl-edit one PIL image -> uint8 images [2,H,W,3] (reconstruction, edit); :128-153 of the reference"""
+    latent = invertor.image2latent(model=pipe, image=image, device=device, dtype=torch.float32)
+    latents, context = invertor.ddim_inversion_loop(pipe, latent, source_prompt)
+    extra = {}
+    if inversion_type == "null-text":
+        # before the editor is registered, as in the reference (:143-147)
+        extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, latents, context, NUM_INNER_STEPS,
+                                                                     EARLY_STOP_EPSILON, guidance_scale)
+    elif inversion_type != "ddim":
+        raise ValueError("Please choose right inversion type")
+    init_latent = torch.cat([latents[-1], latents[-1]])
+    controller = MutualSelfAttentionControl(STEP, LAYPER, model_type="SD")
+    regiter_attention_editor_diffusers(editor.model, controller)
+    images, _ = editor(prompt=source_prompt + target_prompt, latents=init_latent, guidance_scale=guidance_scale,
+                       num_inference_steps=num_inference_steps, height=size, width=size, **extra)
+    # the reference leaves the editor hooked; past its last step it is the identity (attention_control.py:56), so
+    # dropping it here changes nothing and lets the next image's inversion take the captured-graph path
+    unregister_attention_control(editor.model, controller)
+    return images
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    device = torch.device("cuda:{}".format(args.device))
+    seed_everything(args.seed)
+    num_inference_steps = 50
+    out_path = "./exp"
+    pipe = load_pipe(args.sd_version, device)
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    if args.inversion_type == "ddim":
+        invertor, editor = ddim_inversion(), MasaCtrl(pipe, num_inference_steps)
+    elif args.inversion_type == "null-text":
+        invertor, editor = NTI(), MasaCtrl_NTI(pipe, num_inference_steps)
+    else:
+        raise ValueError("Please choose right inversion type")
+    os.makedirs(out_path, exist_ok=True)
+    original_image = Image.open(args.source_image).convert("RGB").resize((size, size))
+    original_image.save(os.path.join(out_path, "source.png"))
+    images = edit_one(pipe, editor, invertor, original_image, [args.source_prompt], [args.target_prompt],
+                      args.inversion_type, device, size, num_inference_steps)
+    save_img(images[0], os.path.join(out_path, "inversion.png"))
+    save_img(images[1], os.path.join(out_path, "edit.png"))
+
+
+if __name__ == "__main__":
+    main()

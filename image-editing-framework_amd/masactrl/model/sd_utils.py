@@ -24,7 +24,7 @@ class MasaCtrl:
     @torch.no_grad()
     def __call__(self, prompt, batch_size=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,
                  latents=None, unconditioning=None, neg_prompt=None, ref_intermediate_latents=None,
-                 return_intermediates=False, return_latents=False, **kwds):
+                 return_intermediates=False, return_latents=False, uncond_embeddings_list=None, **kwds):
         model = self.model
         dev = model.unet.device
         if isinstance(prompt, list):
@@ -44,7 +44,10 @@ class MasaCtrl:
             assert tuple(latents.shape) == shape, \
                 f"The shape of input latent tensor {latents.shape} should equal to predefined one."
         init_latent = latents.clone()
-        uncond_list = unconditioning if isinstance(unconditioning, list) else None
+        # per-step null-text embeddings: `MasaCtrl_NTI(..., uncond_embeddings_list=...)` in the reference
+        # (/root/reference/masactrl/model/sd_utils.py:231-245); the same loop serves both classes here
+        uncond_list = uncond_embeddings_list if uncond_embeddings_list is not None else (
+            unconditioning if isinstance(unconditioning, list) else None)
         if guidance_scale > 1.0:
             uc = tok([neg_prompt or ""] * batch_size, padding="max_length", max_length=tok.model_max_length,
                      return_tensors="pt")
@@ -61,3 +64,8 @@ class MasaCtrl:
         if return_latents:
             return latents, init_latent
         return self.latent2image(latents, return_type="np"), init_latent
+
+
+class MasaCtrl_NTI(MasaCtrl):
+    """`MasaCtrl_NTI` of the reference (`masactrl/model/sd_utils.py:229-`): the sampler with per-step unconditional
+    embeddings from null-text inversion; `MasaCtrl.__call__` already takes `uncond_embeddings_list`."""

@@ -1,0 +1,94 @@
+"""PIE-Bench driver for MasaCtrl — `/root/reference/masactrl/test.py` (per image: invert, then the mutual
+self-attention sampler from `cat([x_T, x_T])`), sharded over the GPUs of one node like `p2p/test.py`: rank r of W takes
+items i with i % W == r, no collective on the data path.  `--synthetic N` replaces the (unavailable) PIE download."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+from PIL import Image
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "p2p"))
+from _bootstrap import load_pipe, seed_everything  # noqa: E402
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("masactrl_edit_real",
+                                               os.path.join(os.path.dirname(os.path.abspath(__file__)), "edit_real.py"))
+_mod = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_mod)          # THIS folder's edit_real.py (p2p/ has one of the same name on sys.path)
+edit_one = _mod.edit_one
+from ief_amd.masactrl.model.sd_utils import MasaCtrl, MasaCtrl_NTI  # noqa: E402
+from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
+from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
+from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
+
+CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser("PIE-Bench MasaCtrl")
+    ap.add_argument("--sd_version", type=str, default="1.5")
+    ap.add_argument("--dataset_path", type=str, default="./PIE")
+    ap.add_argument("--exp_path", type=str, default="./test_exp")
+    ap.add_argument("--inversion_type", type=str, default="ddim")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
+    ap.add_argument("--no_save", action="store_true")
+    args = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    seed_everything(42)
+    pipe = load_pipe(args.sd_version, device)
+    if args.inversion_type == "ddim":
+        invertor, editor = ddim_inversion(), MasaCtrl(pipe, 50)
+    elif args.inversion_type == "null-text":
+        invertor, editor = NTI(), MasaCtrl_NTI(pipe, 50)
+    else:
+        raise ValueError("Please choose right inversion type")
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    if args.synthetic > 0:
+        root = os.path.join(args.exp_path, "_synthetic_inputs")
+        items = list(SyntheticPIE(root, args.synthetic, size=size).items)
+    else:
+        items, root = [], os.path.join(args.dataset_path, "annotation_images")
+        for category in CATEGORIES:
+            items += PIE(args.dataset_path, None, category=category).items
+    mine = list(range(rank, len(items), world))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in mine:
+        image_path, source_prompt, target_prompt = items[i]
+        original = Image.open(image_path).convert("RGB").resize((size, size))
+        images = edit_one(pipe, editor, invertor, original, [source_prompt], [target_prompt], args.inversion_type, device, size)
+        if not args.no_save:
+            out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+            os.makedirs(out_path, exist_ok=True)
+            original.save(os.path.join(out_path, "source.png"))
+            save_img(images[0], os.path.join(out_path, "inversion.png"))
+            save_img(images[1], os.path.join(out_path, "edit.png"))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = torch.tensor([float(len(mine)), dt], device=device)
+    if world > 1:
+        cnt = n[:1].clone()
+        dist.all_reduce(cnt)
+        tmax = n[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        n = torch.cat([cnt, tmax])
+    if rank == 0:
+        print(json.dumps({"images": int(n[0].item()), "seconds": round(n[1].item(), 3),
+                          "images_per_sec": round(n[0].item() / max(n[1].item(), 1e-9), 4), "n_gpus": world}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

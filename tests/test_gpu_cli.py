@@ -103,3 +103,19 @@ def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
                 assert pa.shape == pb.shape
                 # every kernel sums in a fixed order and the schedules only regroup independent images: same pixels
                 assert np.abs(pa - pb).max() <= 1, (other.name, d, name, np.abs(pa - pb).max())
+
+
+def test_masactrl_edit_real_and_pie_driver(tmp_path):
+    masa = os.path.join(ROOT, "image-editing-framework_amd", "masactrl")
+    rng = np.random.RandomState(0)
+    img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "test.jpg")
+    for inv in ("ddim", "null-text"):
+        run([os.path.join(masa, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
+             str(tmp_path / "test.jpg")], cwd=str(tmp_path))
+        for name in ("source.png", "inversion.png", "edit.png"):
+            assert (tmp_path / "exp" / name).exists()
+    out = run([os.path.join(masa, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--exp_path", str(tmp_path / "t")],
+              cwd=str(tmp_path))
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rec["images"] == 2 and rec["images_per_sec"] > 0
