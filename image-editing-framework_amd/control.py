@@ -146,6 +146,39 @@ class ControlPlan:
             cv[: self.pnp_conv_steps] = inj
             dev = self.device
             self._pnp[B] = (qk.contiguous().to(dev), ident.clone().to(dev), cv.contiguous().to(dev), ident.clone().to(dev))
+    # ------------------------------------------------------------------ re-use of a captured loop (denoise.acquire)
+    def signature(self, unet):
+        """everything about this plan that is BAKED into a captured step graph (which kernels run, on which modules,
+        with tables of which shape); two plans with equal signatures differ only in table contents"""
+        if self.kind == "p2p":
+            return ("p2p", self.num_prompts, self.num_steps, self.self_max_tokens, tuple(self.mt.shape))
+        if self.kind == "masactrl":
+            return ("masactrl", tuple(sorted(self.masa_layers)), (max(self.masa_steps) + 2) if self.masa_steps else 1)
+        if self.kind == "pnp":
+            idx = {id(m): m._exec_index for m in unet.attention_modules()}
+            inj = unet.up_blocks[1].resnets[1]._inject is self if len(unet.up_blocks) > 1 else False
+            return ("pnp", tuple(sorted(idx[i] for i in self.pnp_layers)), self.num_steps, bool(inj))
+        return (self.kind,)
+
+    def load_from(self, other: "ControlPlan", B: int):
+        """take over `other`'s controller and table CONTENTS (same signature): the captured graph keeps reading this
+        plan's device tensors"""
+        self.controller = other.controller
+        if self.kind == "p2p":
+            self.mt.copy_(other.mt)
+            self.coef_table.copy_(other.coef_table)
+            self.self_table.copy_(other.self_table)
+            self.self_window = other.self_window
+        elif self.kind == "masactrl":
+            other.prepare(B)
+            self.masa_steps = set(other.masa_steps)
+            self._masa[B][0].copy_(other._masa[B][0])
+        elif self.kind == "pnp":
+            other.prepare(B)
+            self.pnp_qk_steps, self.pnp_conv_steps = other.pnp_qk_steps, other.pnp_conv_steps
+            self._pnp[B][0].copy_(other._pnp[B][0])
+            self._pnp[B][2].copy_(other._pnp[B][2])
+
     # ------------------------------------------------------------------ per-forward protocol
     def applies(self, B: int) -> bool:
         if self.kind == "empty" or self.muted:

@@ -15,11 +15,19 @@ so a 50-step edit is 50 graph replays with no host work in between; everything t
 with the step is a per-step table row selected on the device.  Static buffers: latents (fp32
 NCHW), the CFG batch, the fp16 context (per-step rows when null-text embeddings are supplied).
 """
-from typing import List, Optional
+import os
+from typing import Dict, List, Optional
 
 import torch
 
 from . import hip
+
+# Captured step graphs are kept and RE-USED for the next image of the same shape (`acquire` / `release`): capturing
+# costs an eager warm-up step plus the capture pass (tens of ms, ~10 % of a 50-step edit) and, with several images
+# in flight, is the serial part of the schedule.  IEF_REUSE_GRAPHS=0 captures afresh for every loop.
+REUSE_GRAPHS = os.environ.get("IEF_REUSE_GRAPHS", "1") == "1"
+_POOL: Dict[tuple, list] = {}
+_POOL_CAP = 8
 
 
 class FusedDenoiser:
@@ -38,33 +46,67 @@ class FusedDenoiser:
         C = self.unet.config.in_channels
         self.lat = torch.zeros(self.Bp, C, h, w, dtype=torch.float32, device=dev)
         self.lat_in = torch.zeros(self.B, C, h, w, dtype=torch.float32, device=dev) if self.cfg else self.lat
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.coef_cur = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.coef_table = self.temb_table = self.temb_cur = self.ctx = self.ctx_table = None
+        self._fill(context, guidance_scale, uncond_list)
+        self.use_graph = use_graph
+        self.graph = None
+        self.plan = self.unet._plan
+        self._keep, self._pooled_started, self._pool_key = None, False, None
+
+    def _fill(self, context, guidance_scale, uncond_list):
+        """(re)compute every table the step graph reads, IN PLACE once the buffers exist (re-use of a captured loop)"""
+        dev = self.unet.device
         ts = self.sched.timesteps.tolist()
-        if mode == "invert":
+        if self.mode == "invert":
             ts = ts[::-1]
             coef = [self.sched.reverse_coeffs(t) for t in ts]
         else:
             coef = [self.sched.step_coeffs(t) for t in ts]
         g = float(guidance_scale) if self.cfg else 1.0
         self.num_steps = len(ts)
-        self.coef_table = torch.tensor([[a, b, g, 0.0] for a, b in coef], dtype=torch.float32, device=dev)
-        self.coef_cur = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.temb_table = self.unet.time_rows(torch.tensor(ts, dtype=torch.float32, device=dev)).contiguous()
-        self.temb_cur = torch.zeros(1, self.temb_table.shape[1], dtype=torch.float32, device=dev)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def put(name, value):
+            cur = getattr(self, name)
+            if cur is None:
+                setattr(self, name, value)
+            else:
+                cur.copy_(value)
+
+        put("coef_table", torch.tensor([[a, b, g, 0.0] for a, b in coef], dtype=torch.float32, device=dev))
+        put("temb_table", self.unet.time_rows(torch.tensor(ts, dtype=torch.float32, device=dev)).contiguous())
+        if self.temb_cur is None:
+            self.temb_cur = torch.zeros(1, self.temb_table.shape[1], dtype=torch.float32, device=dev)
         ctx16 = hip.to_f16(context.to(dev).float().contiguous())
-        self.ctx_table = None
         if uncond_list is not None:  # null-text embeddings: the uncond half changes every step
             rows = []
             for u in uncond_list:
                 u16 = hip.to_f16(u.to(dev).float().contiguous()).expand(self.Bp, *ctx16.shape[1:])
                 rows.append(torch.cat([u16, ctx16[self.Bp:]], 0))
-            self.ctx_table = torch.stack(rows).contiguous()
-            self.ctx = torch.zeros_like(ctx16)
+            put("ctx_table", torch.stack(rows).contiguous())
+            if self.ctx is None:
+                self.ctx = torch.zeros_like(ctx16)
         else:
-            self.ctx = ctx16
-        self.use_graph = use_graph
-        self.graph = None
-        self.plan = self.unet._plan
+            put("ctx", ctx16)
+
+    def _key(self, context, uncond_list):
+        plan = self.unet._plan
+        return (id(self.unet), self.mode, self.Bp, tuple(self.lat.shape[-2:]), self.cfg, tuple(context.shape),
+                None if uncond_list is None else len(uncond_list), len(self.sched.timesteps),
+                None if plan is None else plan.signature(self.unet))
+
+    def rebind(self, context, guidance_scale, uncond_list):
+        """point a captured loop at the next image: new tables, new cross-attention K/V, the new controller's plan"""
+        self._fill(context, guidance_scale, uncond_list)
+        if self.ctx_table is None:          # K/V of the fixed context live in tensors the graph reads: refresh in place
+            for m, kv in self._keep:
+                hip.gemm(self.ctx, m.w_kv, out=kv)
+        fresh = self.unet._plan
+        if self.plan is not None:
+            self.plan.load_from(fresh, self.B)
+            self.plan.sync_step()
+        self.step.zero_()
 
     # ------------------------------------------------------------------ one step, stream-ordered
     def _step_body(self):
@@ -130,7 +172,11 @@ class FusedDenoiser:
             self._set_kv_cache(self.ctx_table is None)
         # tensors the graph READS but does not own (cross-attention K/V projected during the warm-up): keep them
         # alive for as long as this loop may be replayed, whatever another loop's warm-up caches afterwards
-        self._keep = [m._kv for m in self.unet.attention_modules()]
+        if getattr(self, "_keep", None) is None or not self._pooled_started:
+            self._keep = [(m, m._kv) for m in self.unet.attention_modules() if m.is_cross and m._kv is not None]
+            self._pooled_started = True
+        if self.plan is not None and self.graph is not None:
+            self.plan.sync_step()
 
     def step_once(self):
         if self.graph is not None:
@@ -156,9 +202,42 @@ class FusedDenoiser:
         return (out, traj) if keep_all else out
 
     def release(self):
+        key = getattr(self, "_pool_key", None)
+        if REUSE_GRAPHS and key is not None and self.graph is not None and len(_POOL.setdefault(key, [])) < _POOL_CAP:
+            _POOL[key].append(self)          # keep the captured graph for the next image of this shape
+            return
         if self.plan is not None:
             self.plan.captured = False
         self.graph = None
+
+
+def acquire(model, context, num_latents, latent_hw, guidance_scale, mode="denoise", uncond_list=None,
+            use_graph=True) -> FusedDenoiser:
+    """a FusedDenoiser for this job: a pooled one with a captured graph of the same shape / plan signature, re-pointed
+    at the new context, tables and controller — or a new one"""
+    if REUSE_GRAPHS and use_graph:
+        probe = FusedDenoiser.__new__(FusedDenoiser)
+        probe.unet, probe.sched, probe.mode = model.unet, model.scheduler, mode
+        probe.cfg, probe.Bp = guidance_scale is not None, num_latents
+        probe.lat = torch.empty(0, 0, *latent_hw)
+        key = probe._key(context, uncond_list)
+        free = _POOL.get(key)
+        if free:
+            loop = free.pop()
+            loop.rebind(context, guidance_scale, uncond_list)
+            return loop
+        loop = FusedDenoiser(model, context, num_latents, latent_hw, guidance_scale, mode, uncond_list, use_graph)
+        loop._pool_key = key
+        return loop
+    return FusedDenoiser(model, context, num_latents, latent_hw, guidance_scale, mode, uncond_list, use_graph)
+
+
+def drop_pool():
+    """free every pooled graph (tests; before changing weights)"""
+    for loops in _POOL.values():
+        for l in loops:
+            l.graph = None
+    _POOL.clear()
 
 
 def run_interleaved(loops: List[FusedDenoiser], num_steps: Optional[int] = None):

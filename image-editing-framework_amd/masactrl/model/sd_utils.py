@@ -3,7 +3,7 @@
 import numpy as np
 import torch
 
-from ...denoise import FusedDenoiser
+from ...denoise import acquire
 
 
 class MasaCtrl:
@@ -56,7 +56,7 @@ class MasaCtrl:
         else:
             context, g = text_embeddings, None
         model.scheduler.set_timesteps(num_inference_steps)
-        loop = FusedDenoiser(model, context, batch_size, (height // 8, width // 8), g, uncond_list=uncond_list)
+        loop = acquire(model, context, batch_size, (height // 8, width // 8), g, uncond_list=uncond_list)
         try:
             latents = loop.run(latents)
         finally:

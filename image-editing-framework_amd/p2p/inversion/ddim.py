@@ -12,7 +12,7 @@ import torch
 from tqdm import tqdm
 
 from ... import hip
-from ...denoise import FusedDenoiser
+from ...denoise import acquire
 from ..model.sd_utils import _encode_prompts
 
 
@@ -30,7 +30,7 @@ class ddim_inversion:
         unet = model.unet
         native = all(m.is_native() for m in unet.attention_modules()) and getattr(unet, "_plan", None) is None
         if native:
-            loop = FusedDenoiser(model, cond_embeddings, latent.shape[0], tuple(latent.shape[-2:]), None, mode="invert")
+            loop = acquire(model, cond_embeddings, latent.shape[0], tuple(latent.shape[-2:]), None, mode="invert")
             try:
                 _, all_latent = loop.run(latent, keep_all=True)
             finally:

@@ -24,7 +24,7 @@ import torch
 from tqdm import tqdm
 
 from ... import hip
-from ...denoise import FusedDenoiser, run_interleaved
+from ...denoise import acquire, run_interleaved
 from .register import register_attention_control, unregister_attention_control
 
 
@@ -77,7 +77,7 @@ class P2P:
         model.scheduler.set_timesteps(num_inference_steps)
         context = torch.cat([uncond_embeddings, text_embeddings])
         if _fusable(model, controller, low_resource):
-            loop = FusedDenoiser(model, context, batch_size, (height // 8, width // 8), guidance_scale,
+            loop = acquire(model, context, batch_size, (height // 8, width // 8), guidance_scale,
                                  uncond_list=uncond_embeddings_list)
             try:
                 latents = loop.run(latents)
@@ -115,7 +115,7 @@ class P2P:
                     raise RuntimeError("edit_many: only controllers lowered to a device plan can run concurrently")
                 uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
                 latent, latents = self.init_latent(latent, model, height, width, None, len(prompt))
-                loop = FusedDenoiser(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
+                loop = acquire(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
                                      (height // 8, width // 8), guidance_scale, uncond_list=uncond_list)
                 loop.start(latents)
                 loops.append(loop)

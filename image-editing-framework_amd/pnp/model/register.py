@@ -37,6 +37,9 @@ def _plan(model) -> ControlPlan:
     plan = getattr(unet, "_plan", None)
     if plan is not None and plan.kind != "pnp":
         raise RuntimeError("another attention controller is registered on this UNet; unregister it first")
+    if plan is not None and plan.captured:      # a captured (pooled) loop owns that plan's tables: start a new one
+        _detach(model)
+        plan = None
     if plan is None:
         mods = _attention_modules(unet)
         plan = ControlPlan(StepCounter(len(mods)), "pnp", unet.device, num_steps=len(model.scheduler.timesteps))
@@ -70,6 +73,13 @@ def register_conv_control_efficient(model, injection_schedule):
     plan._pnp.clear()
 
 
+def _detach(model):
+    for m in _attention_modules(model.unet):
+        m._plan = None
+    model.unet._plan = None
+    model.unet.up_blocks[1].resnets[1]._inject = None
+
+
 def _drop_plan_if_idle(model):
     plan = getattr(model.unet, "_plan", None)
     if plan is not None and plan.kind == "pnp" and not plan.pnp_layers and model.unet.up_blocks[1].resnets[1]._inject is None:
@@ -80,6 +90,8 @@ def _drop_plan_if_idle(model):
 
 def unregister_attention_control_efficient(model):
     plan = getattr(model.unet, "_plan", None)
+    if plan is not None and plan.kind == "pnp" and plan.captured:
+        return _detach(model)                  # the tables stay with the captured loop (denoise pool); nothing to undo
     if plan is not None and plan.kind == "pnp":
         plan.pnp_layers = set()
         plan.pnp_qk_steps = 0
@@ -88,8 +100,10 @@ def unregister_attention_control_efficient(model):
 
 
 def unregister_conv_control_efficient(model):
-    model.unet.up_blocks[1].resnets[1]._inject = None
     plan = getattr(model.unet, "_plan", None)
+    if plan is not None and plan.kind == "pnp" and plan.captured:
+        return _detach(model)
+    model.unet.up_blocks[1].resnets[1]._inject = None
     if plan is not None and plan.kind == "pnp":
         plan.pnp_conv_steps = 0
         plan._pnp.clear()

@@ -13,7 +13,7 @@ from typing import List, Optional, Union
 import numpy as np
 import torch
 
-from ...denoise import FusedDenoiser
+from ...denoise import acquire
 from ...p2p.model.sd_utils import _encode_prompts
 from .register import (register_attention_control_efficient, register_conv_control_efficient, register_time,
                        unregister_attention_control_efficient, unregister_conv_control_efficient)
@@ -56,7 +56,7 @@ class PnP:
             g = guidance_scale if guidance_scale > 1.0 else None
             if g is None:
                 context = text_embeddings
-            loop = FusedDenoiser(model, context, batch_size, (height // 8, width // 8), g, use_graph=use_graph)
+            loop = acquire(model, context, batch_size, (height // 8, width // 8), g, use_graph=use_graph)
             try:
                 if use_graph:
                     latents = loop.run(latents)

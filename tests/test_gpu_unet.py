@@ -274,3 +274,45 @@ def test_full_edit_images_vs_oracle(tiny):
     print(f"10-step edit: latents rel err {e:.3e}; uint8 images max diff {diff.max()}, mean {diff.mean():.3f}, "
           f"pixels within 2 levels {(diff <= 2).mean():.4f}")
     assert e < 5e-2 and (diff <= 3).mean() > 0.99
+
+
+def test_pooled_step_graph_reuse_matches_fresh_capture(tiny):
+    """`denoise.acquire` re-points a captured loop at the next image (new context, tables, cross-attention K/V and the
+    new controller's plan): the second edit must equal the same edit on a freshly captured graph, bit for bit — with a
+    replace controller after a refine one, per-step null-text embeddings, and for the inversion loop."""
+    from ief_amd import denoise
+    from ief_amd.p2p.model.register import unregister_attention_control as unreg
+    cfg = tiny.cfg
+    steps = 6
+    editor, inv = P2P(model=tiny, num_inference_steps=steps), ddim_inversion()
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=g) for _ in range(2)]
+    unc = [[torch.randn(1, 77, cfg.cross_attention_dim, generator=g) * 0.1 for _ in range(steps)] for _ in range(2)]
+    jobs = [(PROMPTS, AttentionRefine, xs[0]), (PROMPTS_EQ, AttentionReplace, xs[1])]
+
+    def edit(k, nti):
+        prompts, cls, x = jobs[k]
+        ctrl = cls(prompts, tiny.tokenizer, steps, 0.8, 0.4, device=DEV)
+        lat, _ = editor.text2image_ldm_stable(tiny, prompts, ctrl, latent=x.to(DEV), num_inference_steps=steps,
+                                              guidance_scale=7.5, return_latents=True,
+                                              uncond_embeddings_list=unc[k] if nti else None)
+        ctrl.reset()
+        unreg(tiny, ctrl)
+        return lat.clone()
+
+    for nti in (False, True):
+        denoise.drop_pool()
+        edit(0, nti)
+        reused = edit(1, nti)                       # second image: pooled graph, rebound
+        assert sum(len(v) for v in denoise._POOL.values()) >= 1
+        denoise.drop_pool()
+        fresh = edit(1, nti)                        # same job on a fresh capture
+        assert torch.equal(reused, fresh), f"nti={nti}: max diff {(reused - fresh).abs().max().item():.3e}"
+    denoise.drop_pool()
+    tiny.scheduler.set_timesteps(steps)
+    inv.ddim_inversion_loop(tiny, xs[0].to(DEV), [PROMPTS[0]])
+    a, _ = inv.ddim_inversion_loop(tiny, xs[1].to(DEV), [PROMPTS_EQ[0]])
+    denoise.drop_pool()
+    b, _ = inv.ddim_inversion_loop(tiny, xs[1].to(DEV), [PROMPTS_EQ[0]])
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    denoise.drop_pool()
