@@ -181,3 +181,66 @@ def test_two_rank_sharding_and_broadcast_gloo():
     assert all(r[1] for r in res), "broadcast did not deliver rank 0's tensors"
     assert all(r[2] >= 2 for r in res)                              # several buckets were used
     assert all(r[3] == n_items for r in res)
+
+
+# ------------------------------------------------------------------------------------------------ Plug-and-Play host logic
+class _FakeSched:
+    def __init__(self, n):
+        self.timesteps = torch.arange(n - 1, -1, -1) * 20 + 1
+
+
+class _FakeModel:
+    def __init__(self, unet, n):
+        self.unet, self.scheduler = unet, _FakeSched(n)
+
+
+def test_pnp_plan_tables_and_schedule_rules(cpu_unet):
+    """the injection rows of `/root/reference/pnp/model/register.py:45-52,161-166` as per-step source-row tables:
+    blocks 1 and 3 of the batch take block 2 for the first n steps, identity afterwards; only prefix schedules"""
+    from ief_amd.pnp.model import register as R
+    model = _FakeModel(cpu_unet, 10)
+    ts = model.scheduler.timesteps
+    R.register_attention_control_efficient(model, ts[:4])
+    R.register_conv_control_efficient(model, ts[:7])
+    plan = cpu_unet._plan
+    assert plan.kind == "pnp" and plan.pnp_qk_steps == 4 and plan.pnp_conv_steps == 7
+    want = {id(cpu_unet.up_blocks[r].attentions[b].transformer_blocks[0].attn1) for r, bs in R.QK_BLOCKS.items() for b in bs
+            if r < len(cpu_unet.up_blocks) and b < len(cpu_unet.up_blocks[r].attentions)}
+    assert plan.pnp_layers == want and len(want) > 0
+    plan.prepare(8)
+    qk, _, cv, _ = plan._pnp[8]
+    inj, ident = [0, 1, 4, 5, 4, 5, 4, 5], list(range(8))
+    assert qk.shape == (11, 8) and qk[:4].tolist() == [inj] * 4 and qk[4:].tolist() == [ident] * 7
+    assert cv[:7].tolist() == [inj] * 7 and cv[7:].tolist() == [ident] * 4
+    assert cpu_unet.up_blocks[1].resnets[1]._inject is plan
+    R.register_time(model, int(ts[3]))
+    assert plan.controller.cur_step == 3
+    with pytest.raises(ValueError):
+        R.register_attention_control_efficient(model, ts[2:5])
+    R.unregister_attention_control_efficient(model)
+    assert cpu_unet._plan is plan                      # the conv injection is still registered
+    R.unregister_conv_control_efficient(model)
+    assert cpu_unet._plan is None and cpu_unet.up_blocks[1].resnets[1]._inject is None
+    assert all(m._plan is None for m in cpu_unet.attention_modules())
+
+
+def test_oracle_pnp_and_linear_projection_invariants():
+    """oracle self-checks: PnP with both injections off is the plain forward; with them on, the edited rows differ and
+    the source rows do not; a linear-projection (SD2.x) state dict equals its 1x1-conv twin"""
+    from oracle import pnp_ref, unet_ref
+    cfg = config.TINY
+    sd = weights.synthetic_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 4, 8, 8, generator=g)
+    ctx = torch.randn(4, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    with torch.no_grad():
+        plain = unet_ref.unet_forward(sd, cfg, x, 501, ctx)
+        off = pnp_ref.pnp_forward(sd, cfg, x, 501, ctx, False, False)
+        on = pnp_ref.pnp_forward(sd, cfg, x, 501, ctx, True, True)
+        assert torch.equal(plain, off)
+        assert torch.equal(on[0], plain[0]) and torch.equal(on[2], plain[2])          # blocks 0 and 2 are never written
+        assert (on[1] - plain[1]).abs().max() > 1e-3 and (on[3] - plain[3]).abs().max() > 1e-3
+        sd_lin = {k: (v.reshape(v.shape[0], v.shape[1]) if k.endswith(("proj_in.weight", "proj_out.weight")) else v)
+                  for k, v in sd.items()}
+        lin = unet_ref.unet_forward(sd_lin, cfg, x, 501, ctx)
+        assert (lin - plain).abs().max() < 1e-4 * plain.abs().max()
