@@ -329,6 +329,265 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const IefAttnParams p) 
 }
 
 // ------------------------------------------------------------------------------------------
+// flash attention, ping-pong form (long sequences, grids that fill the chip)
+// ------------------------------------------------------------------------------------------
+// attn_flash_kernel is bound by instruction ISSUE, not by a pipe: per 64-key tile a wave spends ~450 cycles of MFMA
+// and ~550 cycles of VALU (32 v_exp at quarter rate, max, pack) one after the other, and with two free-running waves
+// per SIMD the two pipes were busy 31 % / 56 % of the time without overlapping (rocprofv3 PMC).
+// Here a workgroup is 8 waves = 256 queries; waves w and w+4 share a SIMD and run the SAME per-tile program half a
+// tile apart, in lockstep phases separated by s_barrier:
+//      phase:        0        1        2        3        4      ...
+//      waves 0-3:   S(0)   soft(0)  PV(0)+S(1) soft(1) PV(1)+S(2)        <- matrix / vector / matrix / ...
+//      waves 4-7:    -      S(0)    soft(0)  PV(0)+S(1) soft(1)
+// so in every phase one wave of each SIMD feeds the matrix pipe (PV of the previous tile + scores of the next) while
+// its partner does the softmax VALU work of its own tile.  K tiles are double- and V tiles triple-buffered in LDS;
+// the vector half of phases t = 1, 2 (mod 4) stores the tile it loaded four phases earlier and issues the loads of
+// the one after (global loads stay in flight across the raw barriers).  The online-softmax correction needs no tile
+// redo here: the scores of tile j are still in registers when its maximum is known, so they are shifted in place.
+template <int D>
+__global__ __launch_bounds__(512) void attn_flash_pp_kernel(const IefAttnParams p) {
+    using C = AttnCfg<D>;
+    constexpr int VRS = D <= 32 ? 32 : (D <= 96 ? 96 : 160);   // halves per V row in LDS
+    constexpr int NCH = (64 * C::CPR + 255) / 256;             // staging chunks per thread of one half
+    constexpr int KBUF = 64 * C::KS, VBUF = 64 * VRS;
+    __shared__ __attribute__((aligned(16))) half_t Ks[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) half_t Vs[3 * VBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = wave >> 2;              // 0: waves 0..3, 1: waves 4..7 (the SIMD partners, half a tile late)
+    const int th = tid & 255;             // thread index inside the half (staging map)
+    const int r = lane & 31, h = lane >> 5;
+    const int qblocks = (p.N + 255) / 256;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % qblocks, head = (lid / qblocks) % p.heads, b = lid / (qblocks * p.heads);
+    const int qs = p.q_src ? p.q_src[b] : b;
+    const int ks = p.k_src ? p.k_src[b] : b;
+    const int vs = p.v_src ? p.v_src[b] : b;
+    const int q0 = qblk * 256 + wave * 32;
+    const bool q_ok = q0 + r < p.N;
+
+    for (int i = tid; i < 2 * KBUF / 8; i += 512) ((half8*)Ks)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < 3 * VBUF / 8; i += 512) ((half8*)Vs)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    if constexpr (C::ONES_ROW)
+        if (tid < 192) Vs[(tid >> 6) * VBUF + (tid & 63) * VRS + D] = (half_t)1.0f;
+    if constexpr (C::FOLD_MAX)
+        if (tid >= 256 && tid < 384) Ks[((tid - 256) >> 6) * KBUF + (tid & 63) * C::KS + D] = (half_t)1.0f;
+
+    half8 qf[C::D16];
+    load_q_frags<D>(qf, p.Q, ((long long)qs * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    {
+        const float sc = p.scale * LOG2E;
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)qf[s][e] * sc);
+    }
+
+    const half_t* Kb = p.K + (long long)ks * p.L * p.ldk + head * D;
+    const half_t* Vb = p.V + (long long)vs * p.L * p.ldv + head * D;
+    int st_k[NCH], st_v[NCH], st_row[NCH], st_ch[NCH];
+    bool st_ok[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = th + 256 * i;
+        const int row = c / C::CPR, ch = c - row * C::CPR;
+        st_ok[i] = c < 64 * C::CPR;
+        st_row[i] = st_ok[i] ? row : 0;
+        st_ch[i] = st_ok[i] ? ch * 8 : 0;
+        st_k[i] = row * C::KS + ch * 8;
+        st_v[i] = row * VRS + ch * 8;
+    }
+    half8 kreg[NCH], vreg[NCH];
+    auto load_tile = [&](int kv0) {      // rows past the last key are clamped (their scores are masked)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int row = min(kv0 + st_row[i], p.L - 1);
+            kreg[i] = *(const half8*)(Kb + (long long)row * p.ldk + st_ch[i]);
+            vreg[i] = *(const half8*)(Vb + (long long)row * p.ldv + st_ch[i]);
+        }
+    };
+    auto store_tile = [&](int kslot, int vslot) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (st_ok[i]) {
+                *(half8*)(Ks + kslot * KBUF + st_k[i]) = kreg[i];
+                *(half8*)(Vs + vslot * VBUF + st_v[i]) = vreg[i];
+            }
+        }
+    };
+
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    constexpr float RESCALE_THR = 5.0f;
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+    f32x16 minit, s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { minit[i] = 0.f; s0[i] = 0.f; s1[i] = 0.f; }
+    half8 pb[4] = {};
+
+    const int k_lane = r * C::KS + 8 * h;
+    const int L16 = lane & 15;
+    const int v_lane = (4 * h + (L16 >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (L16 & 3);
+    const int nt = (p.L + 63) / 64;
+
+    auto scores = [&](const half_t* Kc) {
+        if constexpr (C::FOLD_MAX) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        } else {
+            s0 = minit; s1 = minit;
+        }
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s) {
+            const half8 k0 = *(const half8*)(Kc + k_lane + 16 * s);
+            const half8 k1 = *(const half8*)(Kc + k_lane + 32 * C::KS + 16 * s);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+        }
+    };
+    auto pv = [&](const half_t* Vc) {
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const half_t* vp = Vc + v_lane + (16 * kk) * VRS + 32 * t;
+                const half4 lo = lds_tr_read(vp), hi = lds_tr_read(vp + 8 * VRS);
+                const half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kk], o[t], 0, 0, 0);
+            }
+        }
+    };
+    auto softmax = [&](int kv0) {
+        if (kv0 + 64 > p.L) {                    // last, partial key tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (kv0 + kvl >= p.L) s0[i] = -INFINITY;
+                if (kv0 + 32 + kvl >= p.L) s1[i] = -INFINITY;
+            }
+        }
+        float mxa = fmaxf(s0[0], s1[0]), mxb = fmaxf(s0[8], s1[8]);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, s0[i]), s1[i]);
+            mxb = __builtin_fmaxf(__builtin_fmaxf(mxb, s0[8 + i]), s1[8 + i]);
+        }
+        float mx = fmaxf(mxa, mxb);
+        if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {   // wave-uniform; rare after the first tile
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float delta = first ? mx : fmaxf(mx, 0.f);
+            if constexpr (C::FOLD_MAX) {
+                const float m_new = (float)(half_t)(m_run + delta);     // the reference lives in an fp16 operand
+                delta = m_new - m_run;
+                m_run = m_new;
+                if (h == C::PAD_H) qf[C::PAD_S][C::PAD_E] = (half_t)(-m_new);
+            } else {
+                m_run += delta;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) minit[i] = -m_run;
+            }
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+            if constexpr (!C::ONES_ROW) l_run *= alpha;
+#pragma unroll
+            for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }   // this tile's scores, still in registers
+            first = false;
+        }
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i]);
+            s1[i] = __builtin_amdgcn_exp2f(s1[i]);
+            if constexpr (!C::ONES_ROW) ls += s0[i] + s1[i];
+        }
+        if constexpr (!C::ONES_ROW) l_run += ls;
+        pb[0] = pack8(s0, 0); pb[1] = pack8(s0, 8); pb[2] = pack8(s1, 0); pb[3] = pack8(s1, 8);
+    };
+    auto phase_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    __syncthreads();                       // zero fill and the constant columns are in place
+    if (H == 0) {
+        load_tile(0);
+        store_tile(0, 0);
+        if (nt > 1) load_tile(64);         // tile 1: stored in phase 1
+    } else if (nt > 2) {
+        load_tile(128);                    // tile 2: stored in phase 2
+    }
+    phase_barrier();
+    // Both halves run the SAME straight-line program per tile — [PV(j-1), S(j)] | barrier | [staging, softmax(j)] |
+    // barrier — with waves 4..7 one phase late (one extra barrier in front, waves 0..3 one behind): phase t is the
+    // matrix phase of tile (t - H) / 2 for half H.  The vector phases of even tiles carry the staging turn:
+    // tile j + 1 + H is stored (loaded four phases earlier) and tile j + 3 + H requested.
+    auto vector_phase = [&](int j) {
+        if (!(j & 1)) {
+            const int js = j + 1 + H;
+            if (js < nt) {
+                store_tile(js & 1, js % 3);
+                if (js + 2 < nt) load_tile((js + 2) * 64);
+            }
+        }
+        softmax(j * 64);
+    };
+    // the wave in its matrix phase gets issue priority: an MFMA occupies the issue port for 8 of its 32 cycles, the
+    // partner's VALU stream fills the rest; at equal priority the (older) VALU stream starves the MFMAs instead
+    if (H) phase_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    scores(Ks);                                      // tile 0
+    __builtin_amdgcn_s_setprio(0);
+    phase_barrier();
+    vector_phase(0);
+    phase_barrier();
+    for (int j = 1; j < nt; ++j) {
+        __builtin_amdgcn_s_setprio(1);
+        pv(Vs + ((j - 1) % 3) * VBUF);
+        scores(Ks + (j & 1) * KBUF);
+        __builtin_amdgcn_s_setprio(0);
+        phase_barrier();
+        vector_phase(j);
+        phase_barrier();
+    }
+    __builtin_amdgcn_s_setprio(1);
+    pv(Vs + ((nt - 1) % 3) * VBUF);
+    __builtin_amdgcn_s_setprio(0);
+    if (!H) phase_barrier();
+
+    float l_tot;
+    if constexpr (C::ONES_ROW) {
+        constexpr int LT = D / 32, LR = (D % 32) / 2;
+        const float mine = o[LT][LR];
+        const float other = __shfl_xor(mine, 32);
+        l_tot = h ? other : mine;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.0f / l_tot;
+    if (p.lse && q_ok && h == 0) p.lse[((long long)b * p.heads + head) * p.N + q0 + r] = m_run + __log2f(l_tot);
+    if (q_ok) {
+        half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int db = t * 32 + 8 * g + 4 * h;
+                if (db < D) {
+                    half4 v = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv),
+                               (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+                    *(half4*)(orow + db) = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // cross attention (<= 96 keys) with the P2P edit
 // ------------------------------------------------------------------------------------------
 #define XL 96   // padded key count: 3 sub-tiles of 32
@@ -659,6 +918,17 @@ extern "C" int ief_attn_flash_f16(const IefAttnParams* pp, void* stream) {
     const IefAttnParams p = *pp;
     int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldq, p.ldk, p.ldv, p.ldo, p.Q, p.K, p.V, p.Out);
     if (rc) return rc;
+    // long sequences whose 256-query workgroups fill the chip take the ping-pong kernel (IefAttnParams.variant:
+    // 0 auto, 1 forces the 4-wave kernel, 2 the ping-pong one)
+    const long long pp_blocks = (long long)((p.N + 255) / 256) * p.heads * p.B;
+    // d = 160 needs more registers than a 512-thread workgroup has (spills): the 4-wave kernel keeps it
+    const bool use_pp = p.variant == 2 || (p.variant == 0 && p.d <= 80 && pp_blocks >= 256 && p.L >= 256);
+    if (use_pp) {
+        dim3 gridp((unsigned)pp_blocks);
+        DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_pp_kernel<DD>), gridp, dim3(512), 0, (hipStream_t)stream, p));
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
     dim3 grid(((p.N + 127) / 128) * p.heads * p.B);
     DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
     IEF_LAUNCH_CHECK();

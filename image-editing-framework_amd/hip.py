@@ -43,7 +43,7 @@ class IefAttnParams(Structure):
         ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
         ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int),
         ("scale", c_float),
-        ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p), ("lse", c_void_p),
+        ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p), ("lse", c_void_p), ("variant", c_int),
     ]
 
 
@@ -705,7 +705,7 @@ def _attn_common(p, q, k, v, out, heads):
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
 
 
-def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None):
+def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None, variant=0):
     """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok).
     lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes."""
     lib = load()
@@ -714,6 +714,7 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     p = IefAttnParams()
     _attn_common(p, q, k, v, out, heads)
     p.scale = scale
+    p.variant = int(os.environ.get("IEF_FLASH_VARIANT", variant))
     if lse is not None:
         if tuple(_dev32(lse, "lse").shape) != (q.shape[0], heads, q.shape[1]):
             raise ValueError("attn_flash: lse must be fp32 [B, heads, N]")

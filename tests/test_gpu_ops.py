@@ -249,15 +249,49 @@ def test_attn_flash(B, heads, N, L, d):
     close(out, ref, 4e-3, 1e-3)
 
 
-def test_attn_flash_peaky_rows():
+@pytest.mark.parametrize("B,heads,N,L,d", [
+    (1, 8, 1024, 1024, 40), (2, 2, 512, 512, 40), (1, 2, 300, 200, 40), (1, 2, 256, 64, 40), (1, 2, 256, 130, 64),
+    (1, 1, 700, 77, 32), (1, 2, 256, 256, 80), (1, 1, 256, 192, 160), (1, 2, 40, 1, 40), (1, 2, 257, 129, 40),
+])
+def test_attn_flash_pingpong_variant(B, heads, N, L, d):
+    """the 8-wave ping-pong kernel (variant 2) on shapes the dispatcher would not pick it for as well: ragged N and L,
+    one to many key tiles, every head dim; it must agree with the 4-wave kernel's reference and log-sum-exp"""
+    C = heads * d
+    q, k, v = h16(B, N, C, seed=1), h16(B, L, C, seed=2), h16(B, L, C, seed=3)
+    scale = d ** -0.5
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, scale, lse=lse, variant=2)
+    ref, _ = _attn_ref(q, k, v, heads, scale)
+    close(out, ref, 4e-3, 1e-3)
+    lse1 = torch.empty_like(lse)
+    hip.attn_flash(dev(q), dev(k), dev(v), heads, scale, lse=lse1, variant=1)
+    assert (lse - lse1).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attn_flash_peaky_rows(variant):
     """forces the online-softmax rescale: one key per tile dominates, growing tile by tile."""
     B, heads, N, d = 1, 2, 128, 64
     L = 512
     q, k, v = h16(B, N, heads * d, seed=1), h16(B, L, heads * d, seed=2), h16(B, L, heads * d, seed=3)
     for t in range(L // 64):
         k[0, 64 * t + 7, :] = q[0, 5, :] * (0.5 + 0.25 * t)   # rising spikes for query 5 (both heads)
-    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, d ** -0.5 * 4.0)
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, d ** -0.5 * 4.0, variant=variant)
     ref, _ = _attn_ref(q, k, v, heads, d ** -0.5 * 4.0)
+    close(out, ref, 4e-3, 1e-3)
+
+
+def test_attn_flash_pingpong_indirection():
+    """q/k/v source rows (P2P self-replace, MasaCtrl, PnP) through the ping-pong kernel"""
+    B, heads, N, d = 4, 2, 512, 40
+    C = heads * d
+    qkv = h16(B, N, 3 * C, seed=5)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    src = torch.tensor([0, 2, 2, 2], dtype=torch.int32)
+    dq = dev(qkv)
+    out = hip.attn_flash(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], heads, d ** -0.5, q_src=dev(src), k_src=dev(src),
+                         variant=2)
+    ref, _ = _attn_ref(q, k, v, heads, d ** -0.5, qs=src, ks=src)
     close(out, ref, 4e-3, 1e-3)
 
 
