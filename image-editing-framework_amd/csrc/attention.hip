@@ -588,6 +588,258 @@ __global__ __launch_bounds__(512) void attn_flash_pp_kernel(const IefAttnParams 
 }
 
 // ------------------------------------------------------------------------------------------
+// flash attention, software-pipelined form: softmax of tile j in the MFMA shadows of PV(j-1) and S(j+1)
+// ------------------------------------------------------------------------------------------
+// Same tiling as attn_flash_kernel (4 waves x 32 queries), but one loop iteration holds, in ONE basic block, the
+// matrix work of two other tiles — O += P(j-1) V(j-1) and S(j+1) = K(j+1) Q — next to the exp / pack VALU work of
+// tile j, so the compiler can issue the VALU stream between the MFMAs of the same wave (an MFMA keeps the issue port
+// for 8 of its 32 cycles).  The running maximum is checked BEFORE that block; when it moves, O, the packed P(j-1) and
+// the pending scores are corrected first.  K is double-, V quadruple-buffered (V(j-1) .. V(j+2) are live).
+template <int D>
+__global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams p) {
+    using C = AttnCfg<D>;
+    constexpr int VRS = D <= 32 ? 32 : (D <= 96 ? 96 : 160);
+    constexpr int NCH = (64 * C::CPR + 255) / 256;
+    constexpr int KBUF = 64 * C::KS, VBUF = 64 * VRS;
+    __shared__ __attribute__((aligned(16))) half_t Ks[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) half_t Vs[4 * VBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qblocks = (p.N + 127) / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % qblocks, head = (lid / qblocks) % p.heads, b = lid / (qblocks * p.heads);
+    const int qs = p.q_src ? p.q_src[b] : b;
+    const int ks = p.k_src ? p.k_src[b] : b;
+    const int vs = p.v_src ? p.v_src[b] : b;
+    const int q0 = qblk * 128 + wave * 32;
+    const bool q_ok = q0 + r < p.N;
+
+    for (int i = tid; i < 2 * KBUF / 8; i += 256) ((half8*)Ks)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < 4 * VBUF / 8; i += 256) ((half8*)Vs)[i] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    if constexpr (C::ONES_ROW) Vs[(tid >> 6) * VBUF + (tid & 63) * VRS + D] = (half_t)1.0f;
+    if constexpr (C::FOLD_MAX)
+        if (tid < 128) Ks[(tid >> 6) * KBUF + (tid & 63) * C::KS + D] = (half_t)1.0f;
+
+    half8 qf[C::D16];
+    load_q_frags<D>(qf, p.Q, ((long long)qs * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    {
+        const float sc = p.scale * LOG2E;
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)qf[s][e] * sc);
+    }
+    const half_t* Kb = p.K + (long long)ks * p.L * p.ldk + head * D;
+    const half_t* Vb = p.V + (long long)vs * p.L * p.ldv + head * D;
+    int st_k[NCH], st_v[NCH], st_row[NCH], st_ch[NCH];
+    bool st_ok[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / C::CPR, ch = c - row * C::CPR;
+        st_ok[i] = c < 64 * C::CPR;
+        st_row[i] = st_ok[i] ? row : 0;
+        st_ch[i] = st_ok[i] ? ch * 8 : 0;
+        st_k[i] = row * C::KS + ch * 8;
+        st_v[i] = row * VRS + ch * 8;
+    }
+    half8 kreg[NCH], vreg[NCH];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int row = min(kv0 + st_row[i], p.L - 1);
+            kreg[i] = *(const half8*)(Kb + (long long)row * p.ldk + st_ch[i]);
+            vreg[i] = *(const half8*)(Vb + (long long)row * p.ldv + st_ch[i]);
+        }
+    };
+    auto store_tile = [&](int kslot, int vslot) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (st_ok[i]) {
+                *(half8*)(Ks + kslot * KBUF + st_k[i]) = kreg[i];
+                *(half8*)(Vs + vslot * VBUF + st_v[i]) = vreg[i];
+            }
+        }
+    };
+
+    f32x16 o[C::DT];
+#pragma unroll
+    for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    constexpr float RESCALE_THR = 5.0f;
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+    f32x16 minit, s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { minit[i] = 0.f; s0[i] = 0.f; s1[i] = 0.f; }
+    half8 pb[4] = {};
+
+    const int k_lane = r * C::KS + 8 * h;
+    const int L16 = lane & 15;
+    const int v_lane = (4 * h + (L16 >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (L16 & 3);
+    const int nt = (p.L + 63) / 64;
+
+    // scores of one tile into (a0, a1)
+    auto scores = [&](const half_t* Kc, f32x16& a0, f32x16& a1) {
+        if constexpr (C::FOLD_MAX) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+        } else {
+            a0 = minit; a1 = minit;
+        }
+#pragma unroll
+        for (int s = 0; s < C::D16; ++s) {
+            const half8 k0 = *(const half8*)(Kc + k_lane + 16 * s);
+            const half8 k1 = *(const half8*)(Kc + k_lane + 32 * C::KS + 16 * s);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], a1, 0, 0, 0);
+        }
+    };
+    auto pv = [&](const half_t* Vc) {
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const half_t* vp = Vc + v_lane + (16 * kk) * VRS + 32 * t;
+                const half4 lo = lds_tr_read(vp), hi = lds_tr_read(vp + 8 * VRS);
+                const half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kk], o[t], 0, 0, 0);
+            }
+    };
+    // mask (last tile) + running-maximum maintenance for the scores in (s0, s1); touches o, pb when the maximum moves
+    auto settle_max = [&](int kv0) {
+        if (kv0 + 64 > p.L) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kvl = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (kv0 + kvl >= p.L) s0[i] = -INFINITY;
+                if (kv0 + 32 + kvl >= p.L) s1[i] = -INFINITY;
+            }
+        }
+        float mxa = fmaxf(s0[0], s1[0]), mxb = fmaxf(s0[8], s1[8]);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, s0[i]), s1[i]);
+            mxb = __builtin_fmaxf(__builtin_fmaxf(mxb, s0[8 + i]), s1[8 + i]);
+        }
+        float mx = fmaxf(mxa, mxb);
+        if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float delta = first ? mx : fmaxf(mx, 0.f);
+            if constexpr (C::FOLD_MAX) {
+                const float m_new = (float)(half_t)(m_run + delta);
+                delta = m_new - m_run;
+                m_run = m_new;
+                if (h == C::PAD_H) qf[C::PAD_S][C::PAD_E] = (half_t)(-m_new);
+            } else {
+                m_run += delta;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) minit[i] = -m_run;
+            }
+            const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+            if constexpr (!C::ONES_ROW) l_run *= alpha;
+#pragma unroll
+            for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+            const half_t ah = (half_t)alpha;                 // P(j-1), packed and not yet multiplied into O
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[kk][e] = pb[kk][e] * ah;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+            first = false;
+        }
+    };
+    auto exp_pack = [&](half8 (&out)[4]) {
+        float ls = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i]);
+            s1[i] = __builtin_amdgcn_exp2f(s1[i]);
+            if constexpr (!C::ONES_ROW) ls += s0[i] + s1[i];
+        }
+        if constexpr (!C::ONES_ROW) l_run += ls;
+        out[0] = pack8(s0, 0); out[1] = pack8(s0, 8); out[2] = pack8(s1, 0); out[3] = pack8(s1, 8);
+    };
+
+    // prologue: tiles 0 and 1 in LDS, tile 2 in flight; P(0) packed, S(1) pending
+    load_tile(0);
+    store_tile(0, 0);
+    if (nt > 1) { load_tile(64); store_tile(1, 1); }
+    if (nt > 2) load_tile(128);
+    __syncthreads();
+    scores(Ks, s0, s1);
+    settle_max(0);
+    exp_pack(pb);
+    if (nt > 1) scores(Ks + KBUF, s0, s1);
+    if (nt > 2) { store_tile(0, 2); if (nt > 3) load_tile(192); }
+    __syncthreads();
+    for (int j = 1; j < nt; ++j) {
+        settle_max(j * 64);
+        // one basic block: MFMAs of tiles j-1 and j+1 beside the exp / pack of tile j
+        half8 pn[4];
+        f32x16 n0, n1;
+        pv(Vs + ((j - 1) & 3) * VBUF);
+        scores(Ks + ((j + 1) & 1) * KBUF, n0, n1);         // tile j+1 (a stale slot when j+1 == nt: result unused)
+        exp_pack(pn);
+        // interleave: per MFMA two fragment reads and a handful of VALU ops (the exp / pack stream) in its shadow
+#pragma unroll
+        for (int g = 0; g < 8 + 2 * C::D16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        // opaque use: keeps the exp / pack work in THIS block (LLVM would sink it behind the staging branch)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            v4i_t tmp = __builtin_bit_cast(v4i_t, pn[kk]);
+            asm volatile("" : "+v"(tmp));
+            pb[kk] = __builtin_bit_cast(half8, tmp);
+        }
+        s0 = n0; s1 = n1;
+        if (j + 2 < nt) {
+            store_tile(j & 1, (j + 2) & 3);
+            if (j + 3 < nt) load_tile((j + 3) * 64);
+        }
+        __syncthreads();
+    }
+    pv(Vs + ((nt - 1) & 3) * VBUF);
+
+    float l_tot;
+    if constexpr (C::ONES_ROW) {
+        constexpr int LT = D / 32, LR = (D % 32) / 2;
+        const float mine = o[LT][LR];
+        const float other = __shfl_xor(mine, 32);
+        l_tot = h ? other : mine;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.0f / l_tot;
+    if (p.lse && q_ok && h == 0) p.lse[((long long)b * p.heads + head) * p.N + q0 + r] = m_run + __log2f(l_tot);
+    if (q_ok) {
+        half_t* orow = p.Out + ((long long)b * p.N + q0 + r) * p.ldo + head * D;
+#pragma unroll
+        for (int t = 0; t < C::DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int db = t * 32 + 8 * g + 4 * h;
+                if (db < D) {
+                    half4 v = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv),
+                               (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+                    *(half4*)(orow + db) = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // cross attention (<= 96 keys) with the P2P edit
 // ------------------------------------------------------------------------------------------
 #define XL 96   // padded key count: 3 sub-tiles of 32
@@ -918,19 +1170,23 @@ extern "C" int ief_attn_flash_f16(const IefAttnParams* pp, void* stream) {
     const IefAttnParams p = *pp;
     int rc = check_attn(p.B, p.heads, p.N, p.L, p.d, p.ldq, p.ldk, p.ldv, p.ldo, p.Q, p.K, p.V, p.Out);
     if (rc) return rc;
-    // long sequences whose 256-query workgroups fill the chip take the ping-pong kernel (IefAttnParams.variant:
-    // 0 auto, 1 forces the 4-wave kernel, 2 the ping-pong one)
-    const long long pp_blocks = (long long)((p.N + 255) / 256) * p.heads * p.B;
-    // d = 160 needs more registers than a 512-thread workgroup has (spills): the 4-wave kernel keeps it
-    const bool use_pp = p.variant == 2 || (p.variant == 0 && p.d <= 80 && pp_blocks >= 256 && p.L >= 256);
-    if (use_pp) {
-        dim3 gridp((unsigned)pp_blocks);
+    // IefAttnParams.variant: 0 = default, the software-pipelined kernel (fastest on every shape of the three workloads,
+    // DESIGN.md section 3); 1 forces the plain 4-wave kernel, 2 the 8-wave ping-pong kernel, 3 = 0.  All three produce
+    // the same softmax within fp16 rounding and are held to the same oracle by tests/test_gpu_ops.py.
+    if (p.variant == 2) {
+        dim3 gridp((unsigned)((long long)((p.N + 255) / 256) * p.heads * p.B));
         DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_pp_kernel<DD>), gridp, dim3(512), 0, (hipStream_t)stream, p));
         IEF_LAUNCH_CHECK();
         return IEF_OK;
     }
     dim3 grid(((p.N + 127) / 128) * p.heads * p.B);
-    DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
+    if (p.variant == 1) {
+        DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
+    if (p.variant != 0 && p.variant != 3) return IEF_EINVAL;
+    DISPATCH_D(p.d, hipLaunchKernelGGL((attn_flash_sp_kernel<DD>), grid, dim3(256), 0, (hipStream_t)stream, p));
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

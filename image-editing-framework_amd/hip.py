@@ -714,7 +714,7 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     p = IefAttnParams()
     _attn_common(p, q, k, v, out, heads)
     p.scale = scale
-    p.variant = int(os.environ.get("IEF_FLASH_VARIANT", variant))
+    p.variant = variant if variant else int(os.environ.get("IEF_FLASH_VARIANT", 0))     # env: A/B runs only
     if lse is not None:
         if tuple(_dev32(lse, "lse").shape) != (q.shape[0], heads, q.shape[1]):
             raise ValueError("attn_flash: lse must be fp32 [B, heads, N]")

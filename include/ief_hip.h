@@ -138,7 +138,8 @@ typedef struct IefAttnParams {
     float scale;
     const int* q_src; const int* k_src; const int* v_src;
     float* lse;   /* ief_attn_flash_f16 only, may be NULL: fp32 [B][heads][N] row log-sum-exp (log2 units) for ief_attn_bwd_f16 */
-    int variant;  /* ief_attn_flash_f16 only: 0 = choose by shape, 1 = 4-wave kernel, 2 = 8-wave ping-pong kernel */
+    int variant;  /* ief_attn_flash_f16 only: 0 = default (software-pipelined 4-wave kernel), 1 = plain 4-wave kernel,
+                     2 = 8-wave ping-pong kernel; same results within fp16 rounding, kept for A/B measurement */
 } IefAttnParams;
 int ief_attn_flash_f16(const IefAttnParams* p, void* stream);
 

@@ -253,14 +253,16 @@ def test_attn_flash(B, heads, N, L, d):
     (1, 8, 1024, 1024, 40), (2, 2, 512, 512, 40), (1, 2, 300, 200, 40), (1, 2, 256, 64, 40), (1, 2, 256, 130, 64),
     (1, 1, 700, 77, 32), (1, 2, 256, 256, 80), (1, 1, 256, 192, 160), (1, 2, 40, 1, 40), (1, 2, 257, 129, 40),
 ])
-def test_attn_flash_pingpong_variant(B, heads, N, L, d):
-    """the 8-wave ping-pong kernel (variant 2) on shapes the dispatcher would not pick it for as well: ragged N and L,
-    one to many key tiles, every head dim; it must agree with the 4-wave kernel's reference and log-sum-exp"""
+@pytest.mark.parametrize("variant", [0, 2])
+def test_attn_flash_variants(B, heads, N, L, d, variant):
+    """the software-pipelined kernel (variant 0, the default) and the 8-wave ping-pong kernel (2) on ragged N and L, one
+    to many key tiles, every head dim: both must agree with the reference and with the plain 4-wave kernel's (variant 1)
+    log-sum-exp"""
     C = heads * d
     q, k, v = h16(B, N, C, seed=1), h16(B, L, C, seed=2), h16(B, L, C, seed=3)
     scale = d ** -0.5
     lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
-    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, scale, lse=lse, variant=2)
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, scale, lse=lse, variant=variant)
     ref, _ = _attn_ref(q, k, v, heads, scale)
     close(out, ref, 4e-3, 1e-3)
     lse1 = torch.empty_like(lse)
@@ -268,7 +270,7 @@ def test_attn_flash_pingpong_variant(B, heads, N, L, d):
     assert (lse - lse1).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attn_flash_peaky_rows(variant):
     """forces the online-softmax rescale: one key per tile dominates, growing tile by tile."""
     B, heads, N, d = 1, 2, 128, 64
