@@ -277,6 +277,7 @@ extern "C" int ief_struct_size(int which) {
         case 1: return (int)sizeof(IefAttnParams);
         case 2: return (int)sizeof(IefCrossParams);
         case 3: return (int)sizeof(IefAttnBwdParams);
+        case 4: return (int)sizeof(IefMapLossParams);
         default: return -1;
     }
 }

@@ -32,8 +32,17 @@ from . import hip
 
 
 class UNetAdjoint:
-    def __init__(self, unet, grad_scale: float = 1.0):
+    """mode "context" (default): d objective / d encoder_hidden_states given d objective / d eps (null-text inversion).
+    mode "input": d objective / d sample where the objective is Pix2Pix-zero's cross-attention-map term
+    (`/root/reference/pix2pix-zero/model/sd_utils.py:166-173`): the gradient ENTERS at the queries of every cross-attention
+    module (`hip.attn_map_loss_bwd` against the reference maps), nothing enters at eps, and the chain runs all the way
+    down through the first resnet and conv_in."""
+
+    def __init__(self, unet, grad_scale: float = 1.0, mode: str = "context"):
+        if mode not in ("context", "input"):
+            raise ValueError("UNetAdjoint: mode must be 'context' or 'input'")
         self.unet = unet
+        self.mode = mode
         self.grad_scale = float(grad_scale)
         # packed adjoint weights are shared by every adjoint of this UNet (several images in flight: nti.run_many)
         shared = unet.__dict__.setdefault("_adjoint_shared", {})
@@ -54,6 +63,11 @@ class UNetAdjoint:
             if blk.has_cross_attention:
                 self._first_tr = blk.attentions[0]
                 break
+        if mode == "input":
+            self._first_tr = None
+        self.cross = cross
+        self.ref_maps = None               # mode "input": per cross module (forward order) fp16 [B*heads, N, 77]
+        self.loss_parts = None             # mode "input": fp32 partial sums of the objective (sum() = the loss)
         self.rec: Dict[int, tuple] = {}
         self.taps: Optional[dict] = None   # name -> max |grad| (debug / scale selection)
 
@@ -68,6 +82,13 @@ class UNetAdjoint:
         t = self._wt.get(id(w))
         if t is None:
             t = self._wt[id(w)] = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        return t
+
+    def wt_conv_in(self, w):
+        """conv_in [3,3,Cin,Cout] -> the [Cin,3,3,Cout] weight of its data gradient (a Cout -> Cin 3x3 conv = `hip.conv_out`)"""
+        t = self._wt.get(id(w))
+        if t is None:
+            t = self._wt[id(w)] = w.flip(0, 1).permute(2, 0, 1, 3).contiguous()
         return t
 
     def prepack(self):
@@ -88,6 +109,8 @@ class UNetAdjoint:
                 for w in (t.proj_in.weight, t.proj_out.weight, b.attn1.w_qkv, b.attn1.to_out[0].weight, b.attn2.to_q.weight,
                           b.attn2.to_out[0].weight, b.ff.net[0].proj.weight, b.ff.net[2].weight):
                     self.wt_lin(w)
+        if self.mode == "input":
+            self.wt_conv_in(u.conv_in.weight)
 
     def _tap(self, name, t):
         if self.taps is not None and t is not None:
@@ -185,9 +208,19 @@ class UNetAdjoint:
         d_h2 = hip.layernorm_bwd(h2, d_n3, blk.norm3.weight, blk.norm3.eps, add=d_h3)
         d_o2 = hip.gemm(d_h2, self.wt_lin(a2.to_out[0].weight))
         off = a2._kv_off
-        dq2, _, _ = hip.attn_bwd(q2, self.kv_all[..., off:off + C], self.kv_all[..., off + C:off + 2 * C], o2, d_o2, lse2,
-                                 a2.heads, a2.scale, dk=self.dkv_all[..., off:off + C],
-                                 dv=self.dkv_all[..., off + C:off + 2 * C], want_dq=not stop)
+        k2 = self.kv_all[..., off:off + C]
+        if self.mode == "input":
+            dq2, _, _ = hip.attn_bwd(q2, k2, self.kv_all[..., off + C:off + 2 * C], o2, d_o2, lse2, a2.heads, a2.scale,
+                                     want_dkv=False)
+            i = self._cross_index[id(a2)]
+            parts = self.loss_parts[self._loss_off[i]:self._loss_off[i + 1]]
+            hip.attn_map_loss_bwd(q2, k2, self.ref_maps[i], dq2, a2.heads, a2.scale,
+                                  gcoef=2.0 * self.grad_scale / (B * a2.heads), accumulate=True, loss=parts,
+                                  loss_coef=1.0 / (B * a2.heads))
+        else:
+            dq2, _, _ = hip.attn_bwd(q2, k2, self.kv_all[..., off + C:off + 2 * C], o2, d_o2, lse2,
+                                     a2.heads, a2.scale, dk=self.dkv_all[..., off:off + C],
+                                     dv=self.dkv_all[..., off + C:off + 2 * C], want_dq=not stop)
         if stop:
             return None
         d_h1 = hip.layernorm_bwd(h1, hip.gemm(dq2, self.wt_lin(a2.to_q.weight)), blk.norm2.weight, blk.norm2.eps, add=d_h2)
@@ -200,13 +233,32 @@ class UNetAdjoint:
         n = t.norm
         return hip.groupnorm_bwd(x, d_hn, n.weight, n.bias, n.num_groups, n.eps, silu=False, add=d_out, stats=st0)
 
+    def set_reference_maps(self, ref_maps):
+        """mode "input": the maps the objective compares against, one per cross-attention module in forward order"""
+        if len(ref_maps) != len(self.cross):
+            raise ValueError(f"UNetAdjoint: {len(self.cross)} cross-attention modules, {len(ref_maps)} reference maps")
+        self.ref_maps = list(ref_maps)
+        self._cross_index = {id(m): i for i, m in enumerate(self.cross)}
+        off = [0]
+        for m, r in zip(self.cross, ref_maps):
+            off.append(off[-1] + r.shape[0] * (-(-r.shape[1] // 256)))
+        self._loss_off = off
+        if self.loss_parts is None or self.loss_parts.numel() != off[-1]:
+            self.loss_parts = torch.zeros(off[-1], dtype=torch.float32, device=ref_maps[0].device)
+
     def backward(self, d_eps):
-        """d_eps fp32 NCHW (gradient of the objective w.r.t. the UNet output, already scaled) -> fp16 [B,77,Cc]:
-        the gradient w.r.t. the fp16 context the last `forward` ran on, in the same scale."""
+        """mode "context": d_eps fp32 NCHW (gradient of the objective w.r.t. the UNet output, already scaled) -> fp16
+        [B,77,Cc]: the gradient w.r.t. the fp16 context the last `forward` ran on, in the same scale.
+        mode "input": d_eps is the (usually zero) gradient entering at eps; -> fp32 NCHW gradient w.r.t. `sample`,
+        times `grad_scale`; `loss_parts.sum()` is the objective's value."""
         u = self.unet
         hf, stf = self.rec["final"]
         B = hf.shape[0]
-        self.dkv_all = torch.empty(B, self.kv_all.shape[1], self.kv_width, dtype=torch.float16, device=hf.device)
+        if self.mode == "input":
+            if self.ref_maps is None:
+                raise RuntimeError("UNetAdjoint(mode='input'): set_reference_maps() first")
+        else:
+            self.dkv_all = torch.empty(B, self.kv_all.shape[1], self.kv_width, dtype=torch.float16, device=hf.device)
         n = u.conv_norm_out
         d = hip.conv_out_bwd(d_eps, u.conv_out.weight)
         d = hip.groupnorm_bwd(hf, d, n.weight, n.bias, n.num_groups, n.eps, silu=True, stats=stf)
@@ -245,4 +297,7 @@ class UNetAdjoint:
             self._tap(f"down{bi}", d)
             if done:
                 break
+        if self.mode == "input":
+            d = hip.add(d, dskips.pop())               # conv_in's output is also the first skip connection
+            return hip.conv_out(d, self.wt_conv_in(u.conv_in.weight), None)
         return hip.gemm(self.dkv_all, self.w_kv_all_t)

@@ -57,6 +57,15 @@ class IefAttnBwdParams(Structure):
     ]
 
 
+class IefMapLossParams(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("ref", c_void_p), ("dQ", c_void_p), ("loss", c_void_p),
+        ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
+        ("ldq", c_int), ("ldk", c_int), ("lddq", c_int),
+        ("scale", c_float), ("gcoef", c_float), ("loss_coef", c_float), ("accumulate", c_int),
+    ]
+
+
 class IefCrossParams(Structure):
     _fields_ = [
         ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("Out", c_void_p),
@@ -77,6 +86,7 @@ EXPORTS = [
     "ief_attn_bwd_delta_f32", "ief_attn_bwd_f16", "ief_groupnorm_bwd_f16", "ief_layernorm_bwd_f16", "ief_geglu_il_f16",
     "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
     "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn", "ief_gather_rows_f16",
+    "ief_attn_map_loss_bwd_f16", "ief_axpy_f32",
 ]
 
 
@@ -126,6 +136,8 @@ def load():
     lib.ief_pointwise_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.ief_attn_bwd_delta_f32.argtypes = [c_void_p] * 3 + [c_int] * 6 + [c_void_p]
     lib.ief_attn_bwd_f16.argtypes = [POINTER(IefAttnBwdParams), c_int, c_void_p]
+    lib.ief_attn_map_loss_bwd_f16.argtypes = [POINTER(IefMapLossParams), c_void_p]
+    lib.ief_axpy_f32.argtypes = [c_void_p, c_void_p, c_float, c_longlong, c_void_p]
     lib.ief_groupnorm_bwd_f16.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_float,
                                                                                               c_int, c_void_p]
     lib.ief_layernorm_bwd_f16.argtypes = [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]
@@ -164,6 +176,7 @@ def _stream() -> int:
 # bench.py brackets individual launches with HIP events ON THE STREAM THE KERNEL RUNS ON to get the
 # dominant kernel's average launch duration (roofline.achieved).  Off by default (zero overhead).
 _prof = None
+PROF_SHAPES = os.environ.get("IEF_PROF_SHAPES", "0") == "1"     # append MxNxK to the timed kernel names (tests/exp_shapes.py)
 # tile id -> (BM, BN, WAVES_M, WAVES_N), as in csrc/gemm_conv.hip
 _TILES = {1: (128, 128, 2, 2), 2: (64, 128, 2, 2), 3: (64, 64, 2, 2), 4: (128, 64, 2, 2), 5: (64, 160, 2, 2),
           6: (128, 160, 2, 2), 7: (128, 160, 4, 2), 8: (256, 128, 4, 2), 9: (128, 128, 4, 2)}
@@ -461,7 +474,7 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
             raise ValueError("gemm: colsum must have N entries")
         p.rstat_in, p.rstat_slots, p.colsum, p.ln_eps = st_in.data_ptr(), st_in.shape[1], colsum.data_ptr(), eps
     p.flags, p.zeros = (3 if geglu else 1), _zeros(a.device)
-    with _Timed(_kname(p.tile_hint, False, p.stages), 2.0 * M * N * K):
+    with _Timed(_kname(p.tile_hint, False, p.stages) + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     return (out, stats) if row_stats else out
 
@@ -537,7 +550,7 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
         p.ws = ws.data_ptr()
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
-    with _Timed(_kname(p.tile_hint, True, p.stages), 2.0 * M * Cout * K):
+    with _Timed(_kname(p.tile_hint, True, p.stages) + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
     return out
 
@@ -745,12 +758,17 @@ def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None
     return out
 
 
-def attn_probs(q, k, heads, scale):
-    """materialised maps [B*heads, N, L] fp16 for the generic controller path."""
+def attn_probs(q, k, heads, scale, out=None):
+    """materialised maps [B*heads, N, L] fp16 for the generic controller path (out: where to write them)."""
     lib = load()
     B, N, C = q.shape
     L = k.shape[1]
-    probs = torch.empty(B * heads, N, L, dtype=torch.float16, device=q.device)
+    if out is None:
+        probs = torch.empty(B * heads, N, L, dtype=torch.float16, device=q.device)
+    else:
+        probs = _dev16(out, "out")
+        if tuple(probs.shape) != (B * heads, N, L) or not probs.is_contiguous():
+            raise ValueError("attn_probs: out must be contiguous fp16 [B*heads, N, L]")
     p = IefAttnParams()
     _attn_common(p, q, k, k, q, heads)
     p.scale = scale
@@ -852,6 +870,45 @@ def advance_step(step):
 
 
 # ------------------------------------------------------------------------------- activation gradients (null-text inversion)
+def attn_map_loss_bwd(q, k, ref, dq, heads, scale, gcoef, accumulate=True, loss=None, loss_coef=1.0):
+    """Pix2Pix-zero map objective of one cross-attention module: dq (+)= gcoef * d/dq sum (softmax(scale q k^T) - ref)^2 / 2...
+    see include/ief_hip.h (IefMapLossParams).  q [B,N,h*d], k [B,L,h*d] (strided views ok), ref fp16 [B*heads,N,L];
+    loss: optional fp32 [B*heads*ceil(N/256)] partials (each times loss_coef)."""
+    lib = load()
+    _dev16(q, "q"), _dev16(k, "k"), _dev16(ref, "ref"), _dev16(dq, "dq")
+    B, N, C = q.shape
+    L = k.shape[1]
+    d = C // heads
+    if tuple(ref.shape) != (B * heads, N, L) or not ref.is_contiguous():
+        raise ValueError("attn_map_loss_bwd: ref must be contiguous fp16 [B*heads, N, L]")
+    if tuple(dq.shape) != (B, N, C) or k.shape[0] != B or k.shape[2] != C:
+        raise ValueError("attn_map_loss_bwd: shape mismatch")
+    for nm, t in (("q", q), ("k", k), ("dq", dq)):
+        if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
+            raise ValueError(f"attn_map_loss_bwd: {nm} must be [B, rows, h*d] with batch stride rows * ld")
+    p = IefMapLossParams()
+    p.Q, p.K, p.ref, p.dQ = q.data_ptr(), k.data_ptr(), ref.data_ptr(), dq.data_ptr()
+    p.B, p.heads, p.N, p.L, p.d = B, heads, N, L, d
+    p.ldq, p.ldk, p.lddq = q.stride(1), k.stride(1), dq.stride(1)
+    p.scale, p.gcoef, p.loss_coef, p.accumulate = scale, gcoef, loss_coef, 1 if accumulate else 0
+    if loss is not None:
+        if _dev32(loss, "loss").numel() < B * heads * (-(-N // 256)):
+            raise ValueError("attn_map_loss_bwd: loss needs B*heads*ceil(N/256) floats")
+        p.loss = loss.data_ptr()
+    _check(lib.ief_attn_map_loss_bwd_f16(byref(p), _stream()), "ief_attn_map_loss_bwd_f16")
+    return dq
+
+
+def axpy(y, x, a):
+    """y += a * x (fp32, in place)"""
+    lib = load()
+    _dev32(y, "y"), _dev32(x, "x")
+    if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
+        raise ValueError("axpy: operands must be contiguous and of equal shape")
+    _check(lib.ief_axpy_f32(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream()), "ief_axpy_f32")
+    return y
+
+
 def attn_bwd(q, k, v, o, do, lse, heads, scale, dq=None, dk=None, dv=None, ds_mul=None, want_dq=True, want_dkv=True):
     """Gradients of out = softmax(q k^T scale) v w.r.t. q, k, v given dO (`do`), the forward output `o` and its `lse`.
     q/do/o [B,N,h*d], k/v [B,L,h*d] (strided views ok); dq/dk/dv may be column slices of larger buffers."""

@@ -1,0 +1,204 @@
+"""`P2P_Zero` / `P2P_Zero_NTI` samplers — call signature of `/root/reference/pix2pix-zero/model/sd_utils.py:6-197,426-617`
+(SD1.x / 2.x family; the SDXL classes `P2P_Zero_XL*` belong to a shape family that is not built yet).
+
+    editor = P2P_Zero(pipe, num_inference_steps)
+    image_rec, image_edit = editor(prompt=source_prompt + target_prompt, num_inference_steps=50, guidance_scale=7.5,
+                                   only_sample=False, edit_dir=None, latents=x_T)     # uint8 [1, H, W, 3] each
+
+Two loops over the same x_T:
+  reference pass (:92-122)  plain CFG sampler (UNet batch 2) under prompt[0]; every cross-attention module's softmax maps
+                            of every step are KEPT ON THE DEVICE (the reference moves them to the CPU and back, :110,171):
+                            one fp16 tensor [steps, B*heads, N, 77] per module, 3.3 GB for SD1.5 at 512x512.
+  edit pass (:152-188)      per step: x_in = cat([latents] * 2); UNet under prompt[1]; objective = sum over modules of
+                            ((maps - reference maps) ** 2).sum((1, 2)).mean(0); ONE plain SGD step on x_in with
+                            lr = guidance_amount; noise recomputed on the updated x_in; latents = x_in[0]; CFG; DDIM step.
+The reference differentiates with torch autograd.  Here `grad.UNetAdjoint(mode="input")` chains the hand-written
+activation-gradient kernels from the queries of the 16 cross-attention modules down to the latent; each loop body is one
+captured hipGraph replayed per step (per-step rows — time embedding, DDIM coefficients, reference maps, null-text row —
+are copied into the static buffers the graph reads).
+"""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from ... import hip
+from ...grad import UNetAdjoint
+from ...p2p.model.sd_utils import _encode_prompts
+from .attention_control import prep_unet, restore_original_processors
+
+GRAD_SCALE = 1024.0     # the fp16 gradients of the map objective are carried times this (undone in the SGD step)
+
+
+class P2P_Zero:
+    def __init__(self, pipeline, num_inference_steps):
+        self.model = pipeline
+        self.model.scheduler.set_timesteps(num_inference_steps)
+        self.last_losses: List[float] = []
+
+    # ------------------------------------------------------------------ one loop body = one graph
+    def _graph(self, body, use_graph):
+        if not use_graph:
+            return body
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            body()                                  # warm-up: allocator pools, packed adjoint weights
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        return g.replay
+
+    def __call__(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, latents: Optional[torch.Tensor] = None,
+                 guidance_amount: float = 0.1, edit_dir=None, only_sample: bool = False, uncond_embeddings_list=None,
+                 use_graph: bool = True, return_latents: bool = False, num_steps: Optional[int] = None, **unused):
+        model = self.model
+        unet, sched = model.unet, model.scheduler
+        dev = unet.device
+        if not guidance_scale > 1.0:
+            raise NotImplementedError("P2P_Zero: the reference's CLIs run with classifier-free guidance (7.5)")
+        sched.set_timesteps(num_inference_steps)
+        height = height or unet.config.sample_size * model.vae_scale_factor
+        width = width or unet.config.sample_size * model.vae_scale_factor
+        h, w = height // 8, width // 8
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        C = unet.config.in_channels
+        if latents is None:
+            latents = torch.randn((1, C, h, w), dtype=torch.float32)        # CPU generator, see p2p
+        latents_init = (latents.to(dev).float() * sched.init_noise_sigma).contiguous()
+        ts = sched.timesteps.tolist()
+        if num_steps is not None:
+            ts = ts[:num_steps]
+        f32 = dict(dtype=torch.float32, device=dev)
+        coef_table = torch.tensor([[*sched.step_coeffs(t), float(guidance_scale), 0.0] for t in ts], **f32)
+        temb_table = unet.time_rows(torch.tensor(ts, **f32)).contiguous()
+        coef, temb = torch.zeros(4, **f32), torch.zeros(1, temb_table.shape[1], **f32)
+        lat = torch.zeros(1, C, h, w, **f32)
+        x_in = torch.zeros(2, C, h, w, **f32)
+        ctx16 = torch.zeros(2, 77, unet.config.cross_attention_dim, dtype=torch.float16, device=dev)
+        null_rows = None
+        if uncond_embeddings_list is not None:       # P2P_Zero_NTI: `prompt_embeds[0] = uncond_embeddings_list[i]` (:518,582)
+            null_rows = [hip.to_f16(u.to(dev).float().contiguous())[0] for u in uncond_embeddings_list]
+
+        def set_context(p):
+            with torch.no_grad():
+                u, c = _encode_prompts(model, [p])
+            emb = torch.cat([u, c]).to(dev).float()
+            return emb
+
+        cross = [m for m in unet.attention_modules() if m.is_cross]
+        unet, self.original_processors = prep_unet(unet)
+        saved_cache = [(m, m.cache_kv) for m in unet.attention_modules()]
+        for m in unet.attention_modules():
+            m.cache_kv = False          # the context buffer is rewritten in place (prompt switch, null-text rows)
+            m._kv_key, m._kv = None, None
+        try:
+            # ---------------- reference pass: record the maps
+            emb = set_context(prompt[0])
+            hip.to_f16(emb.contiguous(), out=ctx16)
+            stage, maps = [], []
+            with torch.no_grad():       # one dry forward: allocator warm-up, and every module notes its query count
+                temb.copy_(temb_table[0:1])
+                x_in.copy_(latents_init.expand_as(x_in))
+                unet(x_in, encoder_hidden_states=ctx16, temb_row=temb)
+            for m in cross:
+                n = m.last_tokens
+                stage.append(torch.zeros(2 * m.heads, n, 77, dtype=torch.float16, device=dev))
+                maps.append(torch.zeros(len(ts), 2 * m.heads, n, 77, dtype=torch.float16, device=dev))
+            for m, st in zip(cross, stage):
+                m.map_out = st
+
+            def ref_body():
+                x_in.copy_(lat.expand_as(x_in))
+                eps = unet(x_in, encoder_hidden_states=ctx16, temb_row=temb)["sample"]
+                hip.cfg_ddim_step(eps[0:1], eps[1:2], lat, coef, out=lat)
+
+            lat.copy_(latents_init)
+            with torch.no_grad():
+                run = self._graph(ref_body, use_graph)
+                lat.copy_(latents_init)
+                for i in range(len(ts)):
+                    temb.copy_(temb_table[i:i + 1]), coef.copy_(coef_table[i])
+                    if null_rows is not None:
+                        ctx16[0].copy_(null_rows[i])
+                    run()
+                    for st, mp in zip(stage, maps):
+                        mp[i].copy_(st)
+            for m in cross:
+                m.map_out = None
+            rec_latents = lat.clone()
+            if only_sample:
+                return rec_latents if return_latents else self.latent2image(rec_latents)
+
+            # ---------------- edit pass
+            emb = set_context(prompt[1])
+            if edit_dir is not None:            # `prompt_embeds_edit += edit_dir` (:145-146)
+                emb = emb + edit_dir.to(dev).float()
+            hip.to_f16(emb.contiguous(), out=ctx16)
+            adj = UNetAdjoint(unet, GRAD_SCALE, mode="input")
+            adj.prepack()
+            adj.set_reference_maps(stage)       # the graph reads the staged maps of the current step
+            zero_eps = torch.zeros(2, C, h, w, **f32)
+            loss_log = torch.zeros(len(ts), **f32)
+            step_loss = torch.zeros(1, **f32)
+
+            def edit_body():
+                x_in.copy_(lat.expand_as(x_in))
+                adj.forward(x_in, temb, ctx16)
+                d_x = adj.backward(zero_eps)
+                torch.sum(adj.loss_parts, dim=0, keepdim=True, out=step_loss)
+                hip.axpy(x_in, d_x, -guidance_amount / GRAD_SCALE)          # SGD, lr = guidance_amount (:160,174)
+                eps = unet(x_in, encoder_hidden_states=ctx16, temb_row=temb)["sample"]
+                hip.cfg_ddim_step(eps[0:1], eps[1:2], x_in[0:1], coef, out=lat)   # latents = x_in.chunk(2)[0] (:180)
+
+            lat.copy_(latents_init)
+            with torch.no_grad():
+                for st, mp in zip(stage, maps):
+                    st.copy_(mp[0])
+                temb.copy_(temb_table[0:1]), coef.copy_(coef_table[0])
+                if null_rows is not None:
+                    ctx16[0].copy_(null_rows[0])
+                run = self._graph(edit_body, use_graph)
+                lat.copy_(latents_init)
+                for i in range(len(ts)):
+                    temb.copy_(temb_table[i:i + 1]), coef.copy_(coef_table[i])
+                    if null_rows is not None:
+                        ctx16[0].copy_(null_rows[i])
+                    for st, mp in zip(stage, maps):
+                        st.copy_(mp[i])
+                    run()
+                    loss_log[i:i + 1].copy_(step_loss)
+            self.last_losses = loss_log.tolist()
+            edit_latents = lat.clone()
+        finally:
+            for m in cross:
+                m.map_out = None
+            for m, c in saved_cache:
+                m.cache_kv = c
+                m._kv_key, m._kv = None, None
+            restore_original_processors(unet, self.original_processors)
+        if return_latents:
+            return rec_latents, edit_latents
+        return self.latent2image(rec_latents), self.latent2image(edit_latents)
+
+    @torch.no_grad()
+    def latent2image(self, latents, return_type="np"):
+        latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
+        image = self.model.vae.decode(latents)["sample"]
+        image = (image / 2 + 0.5).clamp(0, 1)
+        if return_type == "np":
+            image = image.cpu().permute(0, 2, 3, 1).numpy()
+            image = (image * 255).astype(np.uint8)
+        return image
+
+
+class P2P_Zero_NTI(P2P_Zero):
+    """`P2P_Zero` with row 0 of the context replaced per step by the null-text embedding (`uncond_embeddings_list`)."""
+
+    def __call__(self, *args, uncond_embeddings_list=None, **kw):
+        if uncond_embeddings_list is None:
+            raise ValueError("P2P_Zero_NTI: uncond_embeddings_list is required")
+        return super().__call__(*args, uncond_embeddings_list=uncond_embeddings_list, **kw)

@@ -158,6 +158,7 @@ class Attention(nn.Module):
         self.rescale_output_factor = 1.0
         self.processor = None
         self._plan = None          # control.ControlPlan when a lowered controller is registered
+        self.map_out = None        # cross modules: fp16 [B*heads, N, 77] receiving this call's softmax maps (Pix2Pix-zero)
         self._kv_key, self._kv = None, None
         self.cache_kv = True       # False when the context changes every step (null-text embeddings)
         self._kv_view = None
@@ -233,6 +234,7 @@ class Attention(nn.Module):
                                   attention_mask=attention_mask, **cross_attention_kwargs)
         x = hidden_states
         B, N, C = x.shape
+        self.last_tokens = N       # query count at this module's resolution level (sizes the Pix2Pix-zero map buffers)
         plan = self._plan
         ln = None if ln_stats is None else (ln_stats, self.ln_c1, self.ln_eps)
         if encoder_hidden_states is None:
@@ -246,6 +248,8 @@ class Attention(nn.Module):
             q = hip.gemm(x, self.to_q.weight) if ln is None else hip.gemm(x, self.ln_w, bias=self.ln_b, ln=ln)
             kv = self.context_kv(encoder_hidden_states)
             args = plan.cross_edit(B, self) if plan is not None else {}
+            if self.map_out is not None:     # `attn.attn_probs = attention_probs` (pix2pix-zero/model/attention_control.py:47)
+                hip.attn_probs(q, kv[..., :C], self.heads, self.scale, out=self.map_out)
             o = hip.attn_cross_p2p(q, kv[..., :C], kv[..., C:], self.heads, self.scale, **args)
         if plan is not None:
             plan.layer_done(self)

@@ -32,7 +32,8 @@ extern "C" {
 int ief_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char* ief_target_arch(void);
-/* sizeof the parameter structs as compiled (0: IefGemmParams, 1: IefAttnParams, 2: IefCrossParams, 3: IefAttnBwdParams) */
+/* sizeof the parameter structs as compiled (0: IefGemmParams, 1: IefAttnParams, 2: IefCrossParams, 3: IefAttnBwdParams,
+ * 4: IefMapLossParams) */
 int ief_struct_size(int which);
 
 /* ------------------------------------------------------------------ GEMM / conv3x3
@@ -230,6 +231,24 @@ int ief_attn_bwd_delta_f32(const ief_half* O, const ief_half* dO, float* delta, 
                            int ldo, int lddo, void* stream);
 /* what: 1 = dQ, 2 = dK and dV, 3 = all.  d in {32,40,64,80,160}; any N, L >= 1. */
 int ief_attn_bwd_f16(const IefAttnBwdParams* p, int what, void* stream);
+/* Pix2Pix-zero cross-attention guidance (/root/reference/pix2pix-zero/model/sd_utils.py:166-173): for one cross-attention
+ * module, loss = mean over (batch, head) of sum_{n,j} (P - ref)^2 with P = softmax(scale Q K^T), and its gradient w.r.t.
+ * Q:  dQ (+)= gcoef * scale * dS K,  dS = P * (e - sum_j e_j P_j),  e = P - ref.  The caller passes
+ * gcoef = 2 / (B heads) * gradient scale.  ref: fp16 [B*heads][N][L] contiguous (what ief_attn_probs_f16 wrote during
+ * the reference pass); loss (optional): one partial per workgroup, [B][heads][ceil(N/256)] floats, each already multiplied
+ * by loss_coef; L <= 96; d in {32,40,64,80,160}. */
+typedef struct IefMapLossParams {
+    const ief_half* Q; const ief_half* K; const ief_half* ref;
+    ief_half* dQ;
+    float* loss;
+    int B, heads, N, L, d;
+    int ldq, ldk, lddq;
+    float scale, gcoef, loss_coef;
+    int accumulate;       /* 1: add to the gradient already in dQ; 0: overwrite */
+} IefMapLossParams;
+int ief_attn_map_loss_bwd_f16(const IefMapLossParams* p, void* stream);
+/* y[i] += a * x[i] (fp32): the plain SGD step on the UNet input (sd_utils.py:160,174) */
+int ief_axpy_f32(float* y, const float* x, float a, long long n, void* stream);
 /* GroupNorm(+SiLU) backward w.r.t. the input: x (+x2 channel concat) is the forward INPUT, dy [B][HW][C1+C2] the gradient
  * of the output, `add` (optional, same shape as dy) is added to the result; dx [B][HW][C1], dx2 [B][HW][C2].
  * stats: (mean, rstd) [B][groups][2] saved by the forward, or NULL (recomputed); partial: scratch of

@@ -244,3 +244,42 @@ def test_oracle_pnp_and_linear_projection_invariants():
                   for k, v in sd.items()}
         lin = unet_ref.unet_forward(sd_lin, cfg, x, 501, ctx)
         assert (lin - plain).abs().max() < 1e-4 * plain.abs().max()
+
+
+def test_oracle_p2pzero_invariants():
+    """oracle self-checks for Pix2Pix-zero: against its own maps the objective and its gradient vanish; the autograd
+    gradient agrees with a central finite difference along a random direction; guidance_amount = 0 turns the edit pass into
+    the plain CFG sampler under the target prompt"""
+    from oracle import p2p_ref, p2pzero_ref
+    cfg = config.TINY
+    sd = weights.synthetic_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 8, 8, generator=g)
+    ctx_s = torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    ctx_t = torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    sched = p2p_ref.DDIMRef(10)
+    t0 = int(sched.timesteps[0])
+    _, maps = p2pzero_ref.reference_pass(sd, cfg, ctx_s, x, sched, 7.5, num_steps=2)
+    assert len(maps) == 2 and len(maps[0]) == sum(1 for k in sd if k.endswith("attn2.to_q.weight"))
+    x_in = torch.cat([x] * 2)
+    loss, grad = p2pzero_ref.input_gradient(sd, cfg, x_in, t0, ctx_s, maps[0])
+    assert loss == 0.0 and grad.abs().max() == 0.0
+    loss, grad = p2pzero_ref.input_gradient(sd, cfg, x_in, t0, ctx_t, maps[0])
+    assert loss > 0 and grad.abs().max() > 0
+    v = torch.randn(x_in.shape, generator=g)
+    v = v / v.norm()
+    h = 2e-2
+    with torch.no_grad():
+        lp = float(p2pzero_ref.map_loss(p2pzero_ref.forward_with_maps(sd, cfg, x_in + h * v, t0, ctx_t)[1], maps[0]))
+        lm = float(p2pzero_ref.map_loss(p2pzero_ref.forward_with_maps(sd, cfg, x_in - h * v, t0, ctx_t)[1], maps[0]))
+    fd, an = (lp - lm) / (2 * h), float((grad * v).sum())
+    assert abs(fd - an) <= 0.1 * abs(an) + 1e-6, (fd, an)
+    e0, _ = p2pzero_ref.edit_pass(sd, cfg, ctx_t, x, maps, sched, 7.5, 0.0, num_steps=2)
+    lat = x.clone()
+    with torch.no_grad():
+        from oracle import unet_ref
+        for t in sched.timesteps[:2]:
+            eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), int(t), ctx_t)
+            eu, ec = eps.chunk(2)
+            lat = sched.step(eu + 7.5 * (ec - eu), int(t), lat)
+    assert torch.allclose(e0, lat, atol=1e-6)

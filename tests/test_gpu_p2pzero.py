@@ -1,0 +1,213 @@
+"""Pix2Pix-zero (SURVEY.md §8f rank 4, SD1.x family) on a real MI355X against the fp32 CPU oracle (`oracle/p2pzero_ref.py`,
+torch autograd through `oracle/unet_ref.py`).
+
+Stated tolerances (relative to max |reference|):
+    map-objective kernel (dq, loss) vs torch autograd on the same fp16 inputs      <= 1e-2
+    d objective / d latent, whole UNet (16 gradient sources, fp16 gradients)       <= 5e-2
+    recorded cross-attention maps vs the oracle's fp32 maps                        <= 2e-3 absolute (fp16 storage)
+    reconstruction / edited latents of a short two-pass run                        <= 5e-2
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from ief_amd import hip  # noqa: E402
+from ief_amd.grad import UNetAdjoint  # noqa: E402
+from ief_amd.pipeline import StableDiffusionPipeline  # noqa: E402
+from ief_amd.p2p.model.sd_utils import _encode_prompts  # noqa: E402
+from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI  # noqa: E402
+from oracle import p2p_ref, p2pzero_ref  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROMPTS = ["a round cake on a wooden plate", "a square cake on a wooden plate"]
+
+
+def rel_err(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return StableDiffusionPipeline.from_pretrained("synthetic:tiny", keep_state_dict=True)
+
+
+def _exec_order(modules):
+    """the product lists Attention modules in the reference's registration order; the oracle's hook fires in execution
+    order (down, mid, up)"""
+    rank = lambda m: (0 if m.layer_name.startswith("down") else 1 if m.layer_name.startswith("mid") else 2)
+    return sorted(range(len(modules)), key=lambda i: (rank(modules[i]), i))
+
+
+@pytest.mark.parametrize("B,heads,N,L,d,acc", [(2, 2, 300, 77, 40, True), (1, 2, 64, 77, 160, False), (2, 1, 256, 77, 64, True),
+                                               (2, 3, 1030, 77, 32, False), (1, 1, 100, 20, 80, True)])
+def test_map_loss_kernel_vs_autograd(B, heads, N, L, d, acc):
+    g = torch.Generator().manual_seed(0)
+    C = heads * d
+    q = torch.randn(B, N, C, generator=g).half()
+    k = torch.randn(B, L, C, generator=g).half()
+    ref = torch.softmax(torch.randn(B * heads, N, L, generator=g) * 2.0, -1).half()
+    dq0 = (torch.randn(B, N, C, generator=g) * 0.01).half()
+    scale, gs = d ** -0.5, 64.0
+    qf = q.float().requires_grad_(True)
+    sp = lambda t, n: t.reshape(B, n, heads, d).transpose(1, 2).reshape(B * heads, n, d)
+    P = torch.softmax(sp(qf, N) @ sp(k.float(), L).transpose(1, 2) * scale, -1)
+    loss = ((P - ref.float()) ** 2).sum((1, 2)).mean(0)
+    loss.backward()
+    want = qf.grad * gs + (dq0.float() if acc else 0.0)
+    dq = dq0.clone().to(DEV)
+    parts = torch.zeros(B * heads * (-(-N // 256)), dtype=torch.float32, device=DEV)
+    hip.attn_map_loss_bwd(q.to(DEV), k.to(DEV), ref.to(DEV), dq, heads, scale, gcoef=2.0 * gs / (B * heads), accumulate=acc,
+                          loss=parts, loss_coef=1.0 / (B * heads))
+    e, el = rel_err(dq, want), abs(parts.sum().item() - loss.item()) / loss.item()
+    print(f"map loss B={B} h={heads} N={N} L={L} d={d}: dq {e:.2e}, loss {el:.2e}")
+    assert e < 1e-2 and el < 1e-3
+
+
+def _maps_like(pipe, B, seed):
+    """random softmax-like reference maps, one per cross module, in the product's module order"""
+    cfg = pipe.cfg
+    unet = pipe.unet
+    x = torch.zeros(B, 4, cfg.sample_size, cfg.sample_size, device=DEV)
+    ctx = torch.zeros(B, 77, cfg.cross_attention_dim, device=DEV)
+    unet(x, 500, encoder_hidden_states=ctx)
+    cross = [m for m in unet.attention_modules() if m.is_cross]
+    g = torch.Generator().manual_seed(seed)
+    return cross, [torch.softmax(torch.randn(B * m.heads, m.last_tokens, 77, generator=g) * 1.5, -1).half() for m in cross]
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_unet_input_gradient_tiny(tiny, B):
+    cfg = tiny.cfg
+    tiny.scheduler.set_timesteps(10)
+    t = int(tiny.scheduler.timesteps[2])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    ctx = (torch.randn(B, 77, cfg.cross_attention_dim, generator=g) * 0.1).half().float()
+    cross, refs = _maps_like(tiny, B, seed=2)
+    order = _exec_order(cross)
+    loss_ref, grad_ref = p2pzero_ref.input_gradient(tiny._state_dict, cfg, x, t, ctx, [refs[i].float() for i in order])
+    gs = 1024.0
+    adj = UNetAdjoint(tiny.unet, gs, mode="input")
+    adj.set_reference_maps([r.to(DEV) for r in refs])
+    adj.taps = {}
+    temb = tiny.unet.time_rows(torch.tensor([float(t)], device=DEV))
+    adj.forward(x.to(DEV), temb, ctx.half().to(DEV))
+    d_x = adj.backward(torch.zeros_like(x, device=DEV)) / gs
+    e, el = rel_err(d_x, grad_ref), abs(adj.loss_parts.sum().item() - loss_ref) / loss_ref
+    print(f"tiny B={B}: d objective / d latent {e:.2e} (max |grad| {grad_ref.abs().max():.3e}); objective {el:.2e}; "
+          f"taps {adj.taps}")
+    assert e < 5e-2 and el < 1e-2
+
+
+def test_recorded_maps_and_two_pass_run_vs_oracle(tiny):
+    cfg = tiny.cfg
+    steps, run_steps, gscale, amount = 10, 3, 7.5, 0.1
+    sched = p2p_ref.DDIMRef(num_inference_steps=steps)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        u0, c0 = _encode_prompts(tiny, PROMPTS[:1])
+        u1, c1 = _encode_prompts(tiny, PROMPTS[1:])
+    ctx_src, ctx_tgt = torch.cat([u0, c0]).float().cpu(), torch.cat([u1, c1]).float().cpu()
+    rec_ref, edit_ref, losses_ref = p2pzero_ref.p2pzero(tiny._state_dict, cfg, ctx_src, ctx_tgt, x_T, sched, gscale, amount,
+                                                        num_steps=run_steps)
+    plain_ref, _ = p2pzero_ref.edit_pass(tiny._state_dict, cfg, ctx_tgt, x_T,
+                                         p2pzero_ref.reference_pass(tiny._state_dict, cfg, ctx_src, x_T, sched, gscale,
+                                                                    num_steps=run_steps)[1],
+                                         sched, gscale, 0.0, num_steps=run_steps)
+    editor = P2P_Zero(tiny, steps)
+    rec, edit = editor(prompt=PROMPTS, num_inference_steps=steps, guidance_scale=gscale, guidance_amount=amount, latents=x_T,
+                       return_latents=True, num_steps=run_steps)
+    losses = list(editor.last_losses)
+    rec2, edit2 = editor(prompt=PROMPTS, num_inference_steps=steps, guidance_scale=gscale, guidance_amount=amount, latents=x_T,
+                         return_latents=True, num_steps=run_steps, use_graph=False)
+    e_rec, e_edit, moved = rel_err(rec, rec_ref), rel_err(edit, edit_ref), rel_err(plain_ref, edit_ref)
+    e_loss = max(abs(a - b) / b for a, b in zip(losses, losses_ref))
+    print(f"Pix2Pix-zero {run_steps} steps: reconstruction {e_rec:.2e}, edit {e_edit:.2e}, objective {e_loss:.2e} "
+          f"({losses_ref}); the guidance moves the latents by {moved:.2e}")
+    assert e_rec < 5e-2 and e_edit < 5e-2 and e_loss < 2e-2
+    assert torch.equal(rec, rec2) and torch.equal(edit, edit2)          # graph replay == eager launches
+    assert tiny.unet._plan is None and all(m.map_out is None and m.cache_kv for m in tiny.unet.attention_modules())
+    imgs = editor(prompt=PROMPTS, num_inference_steps=steps, guidance_scale=gscale, latents=x_T, num_steps=2)
+    assert imgs[0].shape == (1, cfg.sample_size * 8, cfg.sample_size * 8, 3) and imgs[1].dtype == np.uint8
+
+
+def test_recorded_maps_match_oracle(tiny):
+    cfg = tiny.cfg
+    steps = 10
+    sched = p2p_ref.DDIMRef(num_inference_steps=steps)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        u0, c0 = _encode_prompts(tiny, PROMPTS[:1])
+    ctx = torch.cat([u0, c0]).float().cpu()
+    _, maps_ref = p2pzero_ref.reference_pass(tiny._state_dict, cfg, ctx, x_T, sched, 7.5, num_steps=1)
+    tiny.scheduler.set_timesteps(steps)
+    unet = tiny.unet
+    cross = [m for m in unet.attention_modules() if m.is_cross]
+    x = torch.cat([x_T] * 2).to(DEV)
+    unet(x, int(sched.timesteps[0]), encoder_hidden_states=ctx.to(DEV))
+    bufs = [torch.zeros(2 * m.heads, m.last_tokens, 77, dtype=torch.float16, device=DEV) for m in cross]
+    for m, b in zip(cross, bufs):
+        m.map_out = b
+    try:
+        unet(x, int(sched.timesteps[0]), encoder_hidden_states=ctx.to(DEV))
+    finally:
+        for m in cross:
+            m.map_out = None
+    worst = 0.0
+    for j, i in enumerate(_exec_order(cross)):
+        worst = max(worst, (bufs[i].float().cpu() - maps_ref[0][j]).abs().max().item())
+    print(f"recorded cross-attention maps vs oracle: max abs diff {worst:.2e}")
+    assert worst < 2e-3
+
+
+def test_nti_variant_uses_the_per_step_rows(tiny):
+    cfg = tiny.cfg
+    steps, run_steps = 10, 2
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(7))
+    sched = p2p_ref.DDIMRef(num_inference_steps=steps)
+    g = torch.Generator().manual_seed(8)
+    rows = [torch.randn(1, 77, cfg.cross_attention_dim, generator=g) * 0.1 for _ in range(steps)]
+    with torch.no_grad():
+        u0, c0 = _encode_prompts(tiny, PROMPTS[:1])
+        u1, c1 = _encode_prompts(tiny, PROMPTS[1:])
+    ctx_src, ctx_tgt = torch.cat([u0, c0]).float().cpu(), torch.cat([u1, c1]).float().cpu()
+    rec_ref, edit_ref, _ = p2pzero_ref.p2pzero(tiny._state_dict, cfg, ctx_src, ctx_tgt, x_T, sched, 7.5, 0.1, uncond_list=rows,
+                                               num_steps=run_steps)
+    editor = P2P_Zero_NTI(tiny, steps)
+    rec, edit = editor(prompt=PROMPTS, num_inference_steps=steps, guidance_scale=7.5, latents=x_T, return_latents=True,
+                       num_steps=run_steps, uncond_embeddings_list=rows)
+    e_rec, e_edit = rel_err(rec, rec_ref), rel_err(edit, edit_ref)
+    print(f"Pix2Pix-zero + null-text rows: reconstruction {e_rec:.2e}, edit {e_edit:.2e}")
+    assert e_rec < 5e-2 and e_edit < 5e-2
+    with pytest.raises(ValueError):
+        editor(prompt=PROMPTS, num_inference_steps=steps, latents=x_T)
+
+
+def test_p2pzero_clis(tmp_path):
+    folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
+    r = subprocess.run([sys.executable, os.path.join(folder, "edit_syn.py"), "--sd_version", "tiny"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    src = np.array(Image.open(tmp_path / "exp" / "source.png")).astype(int)
+    edit = np.array(Image.open(tmp_path / "exp" / "edit.png")).astype(int)
+    assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
+    rng = np.random.RandomState(0)
+    img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "test.jpg")
+    for inv in ("ddim", "null-text"):
+        r = subprocess.run([sys.executable, os.path.join(folder, "edit_real.py"), "--sd_version", "tiny", "--inversion_type",
+                            inv, "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        for name in ("source.png", "inversion.png", "edit.png"):
+            assert (tmp_path / "exp" / name).exists()
