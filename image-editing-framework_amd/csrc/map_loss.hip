@@ -6,10 +6,12 @@
 // path from this term into the network is through the queries:
 //     P = softmax(scale q K^T)      e = P - ref      dP = 2 e / (B heads)
 //     dS = P * (dP - sum_j dP_j P_j)                  dq = scale * dS K
-// With <= 96 keys a query row is tiny: one LANE owns one query of one (batch, head); K of that (batch, head) sits in LDS
-// and is read as a broadcast, the lane's 77 scores / dS live in a private LDS column (S[j][lane]: conflict free), and the
-// two contractions over d run on `DC`-wide register chunks.  No map is written anywhere; the reference maps are the
-// fp16 maps `ief_attn_probs_f16` recorded during the reference pass.  dq is ADDED to the gradient already sitting in dQ
+// With <= 96 keys a query row is tiny: G = D / DC adjacent LANES own one query of one (batch, head), each a DC-wide slice of
+// the head dim (DC = 40 or 32: G = 1, 2, 4 for D = 40, 80, 160 — the per-lane work is the same for every head dim, and
+// the low-resolution levels, where D is large and queries are few, still spread over enough waves); K of that
+// (batch, head) sits in LDS and is read as a broadcast, the scores are completed by a butterfly over the G lanes, every
+// lane keeps the 77 scores / dS in a private LDS column (S[j][lane]: conflict free), and writes its own slice of dq.
+// No map is written anywhere; the reference maps are the fp16 maps `ief_attn_probs_f16` recorded during the reference pass.  dq is ADDED to the gradient already sitting in dQ
 // (the softmax-backward of the value path) when `accumulate` is set.  Loss partials: one float per workgroup, each summed
 // in a fixed order (deterministic); the host adds them.
 #include "ief_common.h"
@@ -22,9 +24,11 @@ __global__ __launch_bounds__(256) void attn_map_loss_bwd_kernel(const IefMapLoss
     half_t* Ks = (half_t*)smem_raw;                                   // [L][D]
     float* S = (float*)(smem_raw + (((size_t)p.L * D * 2 + 15) & ~(size_t)15));   // [L][256]
     __shared__ float red[4];
+    constexpr int G = D / DC;                         // lanes per query
     const int tid = threadIdx.x;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int n = blockIdx.x * 256 + tid;
+    const int n = (blockIdx.x * 256 + tid) / G;
+    const int part_id = tid % G;                      // which DC-wide slice of the head dim this lane owns
     const bool live = n < p.N;
     // K of this (batch, head): L x D halves, 16-byte pieces
     constexpr int D8 = D / 8;
@@ -34,32 +38,33 @@ __global__ __launch_bounds__(256) void attn_map_loss_bwd_kernel(const IefMapLoss
     }
     __syncthreads();
     float part = 0.f;
-    if (live) {
-        const half_t* q = p.Q + ((long long)b * p.N + n) * p.ldq + head * D;
+    {
+        const int nq = live ? n : p.N - 1;            // dead lanes shadow the last query (they take part in the butterfly)
+        const int c0 = part_id * DC;
+        const half_t* q = p.Q + ((long long)b * p.N + nq) * p.ldq + head * D + c0;
         float* s = S + tid;
-        // scores
-        for (int c0 = 0; c0 < D; c0 += DC) {
-            float qv[DC];
+        float qv[DC];
 #pragma unroll
-            for (int c = 0; c < DC; c += 8) {
-                const half8 h = *(const half8*)(q + c0 + c);
+        for (int c = 0; c < DC; c += 8) {
+            const half8 h = *(const half8*)(q + c);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qv[c + e] = (float)h[e];
-            }
-            for (int j = 0; j < p.L; ++j) {
-                const half_t* kr = Ks + j * D + c0;
-                float a = 0.f;
-#pragma unroll
-                for (int c = 0; c < DC; c += 8) {
-                    const half8 h = *(const half8*)(kr + c);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a += qv[c + e] * (float)h[e];
-                }
-                s[j * 256] = (c0 == 0 ? 0.f : s[j * 256]) + a;
-            }
+            for (int e = 0; e < 8; ++e) qv[c + e] = (float)h[e];
         }
         float mx = -3.0e38f;
-        for (int j = 0; j < p.L; ++j) mx = fmaxf(mx, s[j * 256]);
+        for (int j = 0; j < p.L; ++j) {
+            const half_t* kr = Ks + j * D + c0;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < DC; c += 8) {
+                const half8 h = *(const half8*)(kr + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qv[c + e] * (float)h[e];
+            }
+            if (G >= 2) a += __shfl_xor(a, 1);
+            if (G >= 4) a += __shfl_xor(a, 2);
+            s[j * 256] = a;
+            mx = fmaxf(mx, a);
+        }
         float sum = 0.f;
         for (int j = 0; j < p.L; ++j) {
             const float e = __expf((s[j * 256] - mx) * p.scale);
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void attn_map_loss_bwd_kernel(const IefMapLoss
             sum += e;
         }
         const float inv = 1.f / sum;
-        const half_t* rf = p.ref + (((long long)b * p.heads + head) * p.N + n) * p.L;
+        const half_t* rf = p.ref + (((long long)b * p.heads + head) * p.N + nq) * p.L;
         float dot = 0.f;
         for (int j = 0; j < p.L; ++j) {
             const float P = s[j * 256] * inv;
@@ -81,35 +86,36 @@ __global__ __launch_bounds__(256) void attn_map_loss_bwd_kernel(const IefMapLoss
             const float e = P - (float)rf[j];
             s[j * 256] = P * (e - dot);                 // dS up to the common factor
         }
-        // dq = gcoef * scale * dS K
-        half_t* dq = p.dQ + ((long long)b * p.N + n) * p.lddq + head * D;
-        const float g = p.gcoef * p.scale;
-        for (int c0 = 0; c0 < D; c0 += DC) {
-            float acc[DC];
+        if (!live || part_id != 0) part = 0.f;          // one lane per query carries the objective
+        // this lane's slice of dq = gcoef * scale * dS K
+        float acc[DC];
 #pragma unroll
-            for (int c = 0; c < DC; ++c) acc[c] = 0.f;
-            for (int j = 0; j < p.L; ++j) {
-                const float w = s[j * 256];
-                const half_t* kr = Ks + j * D + c0;
+        for (int c = 0; c < DC; ++c) acc[c] = 0.f;
+        for (int j = 0; j < p.L; ++j) {
+            const float w = s[j * 256];
+            const half_t* kr = Ks + j * D + c0;
 #pragma unroll
-                for (int c = 0; c < DC; c += 8) {
-                    const half8 h = *(const half8*)(kr + c);
+            for (int c = 0; c < DC; c += 8) {
+                const half8 h = *(const half8*)(kr + c);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[c + e] += w * (float)h[e];
-                }
+                for (int e = 0; e < 8; ++e) acc[c + e] += w * (float)h[e];
             }
+        }
+        if (live) {
+            half_t* dq = p.dQ + ((long long)b * p.N + n) * p.lddq + head * D + c0;
+            const float g = p.gcoef * p.scale;
 #pragma unroll
             for (int c = 0; c < DC; c += 8) {
                 half8 o;
                 if (p.accumulate) {
-                    const half8 old = *(const half8*)(dq + c0 + c);
+                    const half8 old = *(const half8*)(dq + c);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)fminf(fmaxf((float)old[e] + g * acc[c + e], -65504.f), 65504.f);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)fminf(fmaxf(g * acc[c + e], -65504.f), 65504.f);
                 }
-                *(half8*)(dq + c0 + c) = o;
+                *(half8*)(dq + c) = o;
             }
         }
     }
@@ -122,6 +128,12 @@ __global__ __launch_bounds__(256) void attn_map_loss_bwd_kernel(const IefMapLoss
         p.loss[((long long)b * p.heads + head) * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * p.loss_coef;
 }
 
+extern "C" int ief_map_loss_blocks(int N, int d) {
+    if (N <= 0 || d <= 0) return 0;
+    const int G = d / ((d % 40 == 0) ? 40 : 32);
+    return (int)(((long long)N * G + 255) / 256);
+}
+
 extern "C" int ief_attn_map_loss_bwd_f16(const IefMapLossParams* pp, void* stream) {
     if (!pp) return IEF_EINVAL;
     const IefMapLossParams p = *pp;
@@ -130,7 +142,8 @@ extern "C" int ief_attn_map_loss_bwd_f16(const IefMapLossParams* pp, void* strea
     if ((p.ldq & 7) || (p.ldk & 7) || (p.lddq & 7)) return IEF_EALIGN;
     if (p.heads * p.d > p.ldq || p.heads * p.d > p.ldk || p.heads * p.d > p.lddq) return IEF_ESHAPE;
     const size_t lds = (((size_t)p.L * p.d * 2 + 15) & ~(size_t)15) + (size_t)p.L * 256 * 4;
-    dim3 grid((p.N + 255) / 256, p.heads, p.B);
+    const int G = p.d / ((p.d % 40 == 0) ? 40 : 32);          // lanes per query, as in the kernel
+    dim3 grid(((long long)p.N * G + 255) / 256, p.heads, p.B);
     hipStream_t st = (hipStream_t)stream;
 #define ML_LAUNCH(DD)                                                                                              \
     {                                                                                                              \

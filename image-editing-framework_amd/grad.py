@@ -241,7 +241,7 @@ class UNetAdjoint:
         self._cross_index = {id(m): i for i, m in enumerate(self.cross)}
         off = [0]
         for m, r in zip(self.cross, ref_maps):
-            off.append(off[-1] + r.shape[0] * (-(-r.shape[1] // 256)))
+            off.append(off[-1] + r.shape[0] * hip.map_loss_blocks(r.shape[1], m.dim_head))
         self._loss_off = off
         if self.loss_parts is None or self.loss_parts.numel() != off[-1]:
             self.loss_parts = torch.zeros(off[-1], dtype=torch.float32, device=ref_maps[0].device)

@@ -86,7 +86,7 @@ EXPORTS = [
     "ief_attn_bwd_delta_f32", "ief_attn_bwd_f16", "ief_groupnorm_bwd_f16", "ief_layernorm_bwd_f16", "ief_geglu_il_f16",
     "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
     "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn", "ief_gather_rows_f16",
-    "ief_attn_map_loss_bwd_f16", "ief_axpy_f32",
+    "ief_attn_map_loss_bwd_f16", "ief_axpy_f32", "ief_map_loss_blocks",
 ]
 
 
@@ -138,6 +138,8 @@ def load():
     lib.ief_attn_bwd_f16.argtypes = [POINTER(IefAttnBwdParams), c_int, c_void_p]
     lib.ief_attn_map_loss_bwd_f16.argtypes = [POINTER(IefMapLossParams), c_void_p]
     lib.ief_axpy_f32.argtypes = [c_void_p, c_void_p, c_float, c_longlong, c_void_p]
+    lib.ief_map_loss_blocks.restype = c_int
+    lib.ief_map_loss_blocks.argtypes = [c_int, c_int]
     lib.ief_groupnorm_bwd_f16.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_float,
                                                                                               c_int, c_void_p]
     lib.ief_layernorm_bwd_f16.argtypes = [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]
@@ -870,10 +872,16 @@ def advance_step(step):
 
 
 # ------------------------------------------------------------------------------- activation gradients (null-text inversion)
+def map_loss_blocks(N, d):
+    """loss partials per (batch, head) that `attn_map_loss_bwd` writes"""
+    return load().ief_map_loss_blocks(int(N), int(d))
+
+
 def attn_map_loss_bwd(q, k, ref, dq, heads, scale, gcoef, accumulate=True, loss=None, loss_coef=1.0):
-    """Pix2Pix-zero map objective of one cross-attention module: dq (+)= gcoef * d/dq sum (softmax(scale q k^T) - ref)^2 / 2...
-    see include/ief_hip.h (IefMapLossParams).  q [B,N,h*d], k [B,L,h*d] (strided views ok), ref fp16 [B*heads,N,L];
-    loss: optional fp32 [B*heads*ceil(N/256)] partials (each times loss_coef)."""
+    """Pix2Pix-zero map objective of one cross-attention module (include/ief_hip.h, IefMapLossParams): with
+    P = softmax(scale q k^T) and e = P - ref,  dq (+)= gcoef * scale * (P * (e - sum_j e_j P_j)) k.
+    q [B,N,h*d], k [B,L,h*d] (strided views ok), ref fp16 [B*heads,N,L];
+    loss: optional fp32 [B*heads*map_loss_blocks(N, d)] partials of sum e^2 (each times loss_coef)."""
     lib = load()
     _dev16(q, "q"), _dev16(k, "k"), _dev16(ref, "ref"), _dev16(dq, "dq")
     B, N, C = q.shape
@@ -892,8 +900,8 @@ def attn_map_loss_bwd(q, k, ref, dq, heads, scale, gcoef, accumulate=True, loss=
     p.ldq, p.ldk, p.lddq = q.stride(1), k.stride(1), dq.stride(1)
     p.scale, p.gcoef, p.loss_coef, p.accumulate = scale, gcoef, loss_coef, 1 if accumulate else 0
     if loss is not None:
-        if _dev32(loss, "loss").numel() < B * heads * (-(-N // 256)):
-            raise ValueError("attn_map_loss_bwd: loss needs B*heads*ceil(N/256) floats")
+        if _dev32(loss, "loss").numel() < B * heads * lib.ief_map_loss_blocks(N, d):
+            raise ValueError("attn_map_loss_bwd: loss needs B*heads*map_loss_blocks(N, d) floats")
         p.loss = loss.data_ptr()
     _check(lib.ief_attn_map_loss_bwd_f16(byref(p), _stream()), "ief_attn_map_loss_bwd_f16")
     return dq

@@ -15,7 +15,7 @@ Two loops over the same x_T:
 The reference differentiates with torch autograd.  Here `grad.UNetAdjoint(mode="input")` chains the hand-written
 activation-gradient kernels from the queries of the 16 cross-attention modules down to the latent; each loop body is one
 captured hipGraph replayed per step (per-step rows — time embedding, DDIM coefficients, reference maps, null-text row —
-are copied into the static buffers the graph reads).
+are copied into the static buffers the graph reads); buffers and graphs are kept by the editor across images (`_Engine`).
 """
 from typing import List, Optional, Union
 
@@ -30,15 +30,50 @@ from .attention_control import prep_unet, restore_original_processors
 GRAD_SCALE = 1024.0     # the fp16 gradients of the map objective are carried times this (undone in the SGD step)
 
 
-class P2P_Zero:
-    def __init__(self, pipeline, num_inference_steps):
-        self.model = pipeline
-        self.model.scheduler.set_timesteps(num_inference_steps)
-        self.last_losses: List[float] = []
+class _Engine:
+    """static buffers + the two captured loop bodies for one (latent size, step count, guidance_amount): built on first
+    use and kept across images, since everything an image changes is a buffer the graphs READ"""
 
-    # ------------------------------------------------------------------ one loop body = one graph
-    def _graph(self, body, use_graph):
-        if not use_graph:
+    def __init__(self, model, h, w, nsteps, guidance_amount, use_graph):
+        unet = model.unet
+        dev = unet.device
+        C = unet.config.in_channels
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.unet, self.use_graph, self.guidance_amount = unet, use_graph, float(guidance_amount)
+        self.coef = torch.zeros(4, **f32)
+        self.temb = torch.zeros(1, unet.time_rows(torch.zeros(1, **f32)).shape[1], **f32)
+        self.lat = torch.zeros(1, C, h, w, **f32)
+        self.x_in = torch.zeros(2, C, h, w, **f32)
+        self.zero_eps = torch.zeros(2, C, h, w, **f32)
+        self.step_loss = torch.zeros(1, **f32)
+        self.ctx16 = torch.zeros(2, 77, unet.config.cross_attention_dim, dtype=torch.float16, device=dev)
+        self.cross = [m for m in unet.attention_modules() if m.is_cross]
+        with torch.no_grad():           # one dry forward: allocator warm-up, and every module notes its query count
+            unet(self.x_in, encoder_hidden_states=self.ctx16, temb_row=self.temb)
+        self.stage = [torch.zeros(2 * m.heads, m.last_tokens, 77, dtype=torch.float16, device=dev) for m in self.cross]
+        self.maps = [torch.zeros(nsteps, *st.shape, dtype=torch.float16, device=dev) for st in self.stage]
+        self.adj = UNetAdjoint(unet, GRAD_SCALE, mode="input")
+        self.adj.prepack()
+        self.adj.set_reference_maps(self.stage)      # the edit graph reads the staged maps of the current step
+        self._ref = self._edit = None
+
+    def _ref_body(self):
+        self.x_in.copy_(self.lat.expand_as(self.x_in))
+        eps = self.unet(self.x_in, encoder_hidden_states=self.ctx16, temb_row=self.temb)["sample"]
+        hip.cfg_ddim_step(eps[0:1], eps[1:2], self.lat, self.coef, out=self.lat)
+
+    def _edit_body(self):
+        adj, x_in = self.adj, self.x_in
+        x_in.copy_(self.lat.expand_as(x_in))
+        adj.forward(x_in, self.temb, self.ctx16)
+        d_x = adj.backward(self.zero_eps)
+        torch.sum(adj.loss_parts, dim=0, keepdim=True, out=self.step_loss)
+        hip.axpy(x_in, d_x, -self.guidance_amount / GRAD_SCALE)              # SGD, lr = guidance_amount (:160,174)
+        eps = self.unet(x_in, encoder_hidden_states=self.ctx16, temb_row=self.temb)["sample"]
+        hip.cfg_ddim_step(eps[0:1], eps[1:2], x_in[0:1], self.coef, out=self.lat)   # latents = x_in.chunk(2)[0] (:180)
+
+    def _capture(self, body):
+        if not self.use_graph:
             return body
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -50,6 +85,32 @@ class P2P_Zero:
         with torch.cuda.graph(g):
             body()
         return g.replay
+
+    def ref_step(self):
+        if self._ref is None:           # captured with the map buffers installed (the caller sets `map_out`)
+            saved = self.lat.clone()
+            self._ref = self._capture(self._ref_body)
+            self.lat.copy_(saved)
+        self._ref()
+
+    def edit_step(self):
+        if self._edit is None:
+            saved = self.lat.clone()
+            self._edit = self._capture(self._edit_body)
+            self.lat.copy_(saved)
+        self._edit()
+
+
+class P2P_Zero:
+    def __init__(self, pipeline, num_inference_steps):
+        self.model = pipeline
+        self.model.scheduler.set_timesteps(num_inference_steps)
+        self.last_losses: List[float] = []
+        self._engines = {}
+
+    def release(self):
+        """drop the cached graphs and map buffers (3.3 GB for SD1.5 at 512x512)"""
+        self._engines.clear()
 
     def __call__(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, latents: Optional[torch.Tensor] = None,
@@ -75,106 +136,67 @@ class P2P_Zero:
         f32 = dict(dtype=torch.float32, device=dev)
         coef_table = torch.tensor([[*sched.step_coeffs(t), float(guidance_scale), 0.0] for t in ts], **f32)
         temb_table = unet.time_rows(torch.tensor(ts, **f32)).contiguous()
-        coef, temb = torch.zeros(4, **f32), torch.zeros(1, temb_table.shape[1], **f32)
-        lat = torch.zeros(1, C, h, w, **f32)
-        x_in = torch.zeros(2, C, h, w, **f32)
-        ctx16 = torch.zeros(2, 77, unet.config.cross_attention_dim, dtype=torch.float16, device=dev)
         null_rows = None
         if uncond_embeddings_list is not None:       # P2P_Zero_NTI: `prompt_embeds[0] = uncond_embeddings_list[i]` (:518,582)
             null_rows = [hip.to_f16(u.to(dev).float().contiguous())[0] for u in uncond_embeddings_list]
 
-        def set_context(p):
+        def context_of(p):
             with torch.no_grad():
                 u, c = _encode_prompts(model, [p])
-            emb = torch.cat([u, c]).to(dev).float()
-            return emb
+            return torch.cat([u, c]).to(dev).float()
 
-        cross = [m for m in unet.attention_modules() if m.is_cross]
         unet, self.original_processors = prep_unet(unet)
         saved_cache = [(m, m.cache_kv) for m in unet.attention_modules()]
         for m in unet.attention_modules():
             m.cache_kv = False          # the context buffer is rewritten in place (prompt switch, null-text rows)
             m._kv_key, m._kv = None, None
+        key = (h, w, len(ts), float(guidance_amount), bool(use_graph))
         try:
+            E = self._engines.get(key)
+            if E is None:
+                self._engines.clear()                       # one shape at a time: the map buffers are large
+                E = self._engines[key] = _Engine(model, h, w, len(ts), guidance_amount, use_graph)
+
+            def set_step(i):
+                E.temb.copy_(temb_table[i:i + 1]), E.coef.copy_(coef_table[i])
+                if null_rows is not None:
+                    E.ctx16[0].copy_(null_rows[i])
+
             # ---------------- reference pass: record the maps
-            emb = set_context(prompt[0])
-            hip.to_f16(emb.contiguous(), out=ctx16)
-            stage, maps = [], []
-            with torch.no_grad():       # one dry forward: allocator warm-up, and every module notes its query count
-                temb.copy_(temb_table[0:1])
-                x_in.copy_(latents_init.expand_as(x_in))
-                unet(x_in, encoder_hidden_states=ctx16, temb_row=temb)
-            for m in cross:
-                n = m.last_tokens
-                stage.append(torch.zeros(2 * m.heads, n, 77, dtype=torch.float16, device=dev))
-                maps.append(torch.zeros(len(ts), 2 * m.heads, n, 77, dtype=torch.float16, device=dev))
-            for m, st in zip(cross, stage):
+            hip.to_f16(context_of(prompt[0]).contiguous(), out=E.ctx16)
+            for m, st in zip(E.cross, E.stage):
                 m.map_out = st
-
-            def ref_body():
-                x_in.copy_(lat.expand_as(x_in))
-                eps = unet(x_in, encoder_hidden_states=ctx16, temb_row=temb)["sample"]
-                hip.cfg_ddim_step(eps[0:1], eps[1:2], lat, coef, out=lat)
-
-            lat.copy_(latents_init)
             with torch.no_grad():
-                run = self._graph(ref_body, use_graph)
-                lat.copy_(latents_init)
+                E.lat.copy_(latents_init)
                 for i in range(len(ts)):
-                    temb.copy_(temb_table[i:i + 1]), coef.copy_(coef_table[i])
-                    if null_rows is not None:
-                        ctx16[0].copy_(null_rows[i])
-                    run()
-                    for st, mp in zip(stage, maps):
+                    set_step(i)
+                    E.ref_step()
+                    for st, mp in zip(E.stage, E.maps):
                         mp[i].copy_(st)
-            for m in cross:
+            for m in E.cross:
                 m.map_out = None
-            rec_latents = lat.clone()
+            rec_latents = E.lat.clone()
             if only_sample:
                 return rec_latents if return_latents else self.latent2image(rec_latents)
 
             # ---------------- edit pass
-            emb = set_context(prompt[1])
+            emb = context_of(prompt[1])
             if edit_dir is not None:            # `prompt_embeds_edit += edit_dir` (:145-146)
                 emb = emb + edit_dir.to(dev).float()
-            hip.to_f16(emb.contiguous(), out=ctx16)
-            adj = UNetAdjoint(unet, GRAD_SCALE, mode="input")
-            adj.prepack()
-            adj.set_reference_maps(stage)       # the graph reads the staged maps of the current step
-            zero_eps = torch.zeros(2, C, h, w, **f32)
+            hip.to_f16(emb.contiguous(), out=E.ctx16)
             loss_log = torch.zeros(len(ts), **f32)
-            step_loss = torch.zeros(1, **f32)
-
-            def edit_body():
-                x_in.copy_(lat.expand_as(x_in))
-                adj.forward(x_in, temb, ctx16)
-                d_x = adj.backward(zero_eps)
-                torch.sum(adj.loss_parts, dim=0, keepdim=True, out=step_loss)
-                hip.axpy(x_in, d_x, -guidance_amount / GRAD_SCALE)          # SGD, lr = guidance_amount (:160,174)
-                eps = unet(x_in, encoder_hidden_states=ctx16, temb_row=temb)["sample"]
-                hip.cfg_ddim_step(eps[0:1], eps[1:2], x_in[0:1], coef, out=lat)   # latents = x_in.chunk(2)[0] (:180)
-
-            lat.copy_(latents_init)
             with torch.no_grad():
-                for st, mp in zip(stage, maps):
-                    st.copy_(mp[0])
-                temb.copy_(temb_table[0:1]), coef.copy_(coef_table[0])
-                if null_rows is not None:
-                    ctx16[0].copy_(null_rows[0])
-                run = self._graph(edit_body, use_graph)
-                lat.copy_(latents_init)
+                E.lat.copy_(latents_init)
                 for i in range(len(ts)):
-                    temb.copy_(temb_table[i:i + 1]), coef.copy_(coef_table[i])
-                    if null_rows is not None:
-                        ctx16[0].copy_(null_rows[i])
-                    for st, mp in zip(stage, maps):
+                    set_step(i)
+                    for st, mp in zip(E.stage, E.maps):
                         st.copy_(mp[i])
-                    run()
-                    loss_log[i:i + 1].copy_(step_loss)
+                    E.edit_step()
+                    loss_log[i:i + 1].copy_(E.step_loss)
             self.last_losses = loss_log.tolist()
-            edit_latents = lat.clone()
+            edit_latents = E.lat.clone()
         finally:
-            for m in cross:
+            for m in unet.attention_modules():
                 m.map_out = None
             for m, c in saved_cache:
                 m.cache_kv = c

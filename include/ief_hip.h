@@ -235,8 +235,8 @@ int ief_attn_bwd_f16(const IefAttnBwdParams* p, int what, void* stream);
  * module, loss = mean over (batch, head) of sum_{n,j} (P - ref)^2 with P = softmax(scale Q K^T), and its gradient w.r.t.
  * Q:  dQ (+)= gcoef * scale * dS K,  dS = P * (e - sum_j e_j P_j),  e = P - ref.  The caller passes
  * gcoef = 2 / (B heads) * gradient scale.  ref: fp16 [B*heads][N][L] contiguous (what ief_attn_probs_f16 wrote during
- * the reference pass); loss (optional): one partial per workgroup, [B][heads][ceil(N/256)] floats, each already multiplied
- * by loss_coef; L <= 96; d in {32,40,64,80,160}. */
+ * the reference pass); loss (optional): one partial per workgroup, [B][heads][ief_map_loss_blocks(N, d)] floats, each
+ * already multiplied by loss_coef; L <= 96; d in {32,40,64,80,160}. */
 typedef struct IefMapLossParams {
     const ief_half* Q; const ief_half* K; const ief_half* ref;
     ief_half* dQ;
@@ -247,6 +247,8 @@ typedef struct IefMapLossParams {
     int accumulate;       /* 1: add to the gradient already in dQ; 0: overwrite */
 } IefMapLossParams;
 int ief_attn_map_loss_bwd_f16(const IefMapLossParams* p, void* stream);
+/* workgroups per (batch, head) of the kernel above = loss partials per (batch, head) */
+int ief_map_loss_blocks(int N, int d);
 /* y[i] += a * x[i] (fp32): the plain SGD step on the UNet input (sd_utils.py:160,174) */
 int ief_axpy_f32(float* y, const float* x, float a, long long n, void* stream);
 /* GroupNorm(+SiLU) backward w.r.t. the input: x (+x2 channel concat) is the forward INPUT, dy [B][HW][C1+C2] the gradient

@@ -65,7 +65,7 @@ def test_map_loss_kernel_vs_autograd(B, heads, N, L, d, acc):
     loss.backward()
     want = qf.grad * gs + (dq0.float() if acc else 0.0)
     dq = dq0.clone().to(DEV)
-    parts = torch.zeros(B * heads * (-(-N // 256)), dtype=torch.float32, device=DEV)
+    parts = torch.zeros(B * heads * hip.map_loss_blocks(N, d), dtype=torch.float32, device=DEV)
     hip.attn_map_loss_bwd(q.to(DEV), k.to(DEV), ref.to(DEV), dq, heads, scale, gcoef=2.0 * gs / (B * heads), accumulate=acc,
                           loss=parts, loss_coef=1.0 / (B * heads))
     e, el = rel_err(dq, want), abs(parts.sum().item() - loss.item()) / loss.item()
@@ -211,3 +211,17 @@ def test_p2pzero_clis(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         for name in ("source.png", "inversion.png", "edit.png"):
             assert (tmp_path / "exp" / name).exists()
+
+
+def test_p2pzero_pie_driver(tmp_path):
+    import json
+    folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
+    for inv in ("ddim", "null-text"):
+        r = subprocess.run([sys.executable, os.path.join(folder, "test.py"), "--sd_version", "tiny", "--synthetic", "2",
+                            "--invert_batch", "2", "--inversion_type", inv, "--exp_path", str(tmp_path / inv)],
+                           cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rec["images"] == 2 and rec["images_per_sec"] > 0
+        pngs = [f for _, _, fs in os.walk(tmp_path / inv) for f in fs if f == "edit.png"]
+        assert len(pngs) == 2

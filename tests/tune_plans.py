@@ -39,6 +39,17 @@ eps = adj.forward(x, temb, ctx16)
 adj.backward(torch.randn_like(eps).contiguous())
 torch.cuda.synchronize()
 print(f"NTI reverse pass: {len(hip._plan_table())} shapes tuned", flush=True)
+# Pix2Pix-zero: the same reverse pass at batch 2, continued down to the latent (grad.UNetAdjoint mode "input")
+adj2 = UNetAdjoint(pipe.unet, 1024.0, mode="input")
+x2 = torch.randn(2, 4, hw, hw, device=dev)
+ctx2 = (torch.randn(2, 77, cfg.cross_attention_dim, device=dev) * 0.1).half()
+pipe.unet(x2, 501, encoder_hidden_states=ctx2)
+cross = [m for m in pipe.unet.attention_modules() if m.is_cross]
+adj2.set_reference_maps([torch.softmax(torch.randn(2 * m.heads, m.last_tokens, 77, device=dev), -1).half() for m in cross])
+adj2.forward(x2, temb, ctx2)
+adj2.backward(torch.zeros_like(x2))
+torch.cuda.synchronize()
+print(f"Pix2Pix-zero reverse pass: {len(hip._plan_table())} shapes tuned", flush=True)
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 hip.save_plans(out)
 for k, v in sorted(hip._plan_table().items()):
