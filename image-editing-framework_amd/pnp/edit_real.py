@@ -1,8 +1,7 @@
-"""Invert a real image, then edit it with Plug-and-Play — CLI of `/root/reference/pnp/edit_real.py` for the
-`--inversion_type ddim` branch (:119-129): DDIM inversion under the source prompt, then the PnP sampler from
-`latents = cat([x_T, x_T])`; outputs `./exp/source.png`, `./exp/inversion.png`, `./exp/edit.png`.
-The reference's default here is "null-text" (`PnP_NTI`, per-step unconditional embeddings); that sampler variant is
-not built in this folder yet and is rejected loudly."""
+"""Invert a real image, then edit it with Plug-and-Play — CLI of `/root/reference/pnp/edit_real.py` (:119-143): DDIM
+inversion under the source prompt (`--inversion_type null-text`, the reference's default, adds the null-text
+optimisation and samples with `PnP_NTI`), then the PnP sampler from `latents = cat([x_T, x_T])`; outputs
+`./exp/source.png`, `./exp/inversion.png`, `./exp/edit.png`."""
 import argparse
 import os
 import sys
@@ -15,7 +14,8 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.pnp.model.sd_utils import PnP  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
+from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI  # noqa: E402
 
 parser = argparse.ArgumentParser("General config")
 parser.add_argument("--sd_version", type=str, default="1.5")
@@ -29,25 +29,32 @@ parser.add_argument("--inversion_type", type=str, default="null-text")
 
 def main(argv=None):
     args = parser.parse_args(argv)
-    if args.inversion_type != "ddim":
-        raise NotImplementedError("pnp/edit_real.py: only --inversion_type ddim is built (PnP_NTI is a later row)")
+    if args.inversion_type not in ("ddim", "null-text"):
+        raise ValueError("--inversion_type must be ddim or null-text")
+    nti = args.inversion_type == "null-text"
     device = torch.device("cuda:{}".format(args.device))
     seed_everything(args.seed)
     num_inference_steps, GUIDANCE_SCALE = 50, 7.5
+    num_inner_steps, early_stop_epsilon = 10, 1e-5
     pnp_attn_t, pnp_f_t = 1.0, 1.0
     out_path = "./exp"
     pipe = load_pipe(args.sd_version, device)
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor
-    invertor, editor = ddim_inversion(), PnP(pipe, num_inference_steps)
+    invertor = NTI() if nti else ddim_inversion()
+    editor = (PnP_NTI if nti else PnP)(pipe, num_inference_steps)
     os.makedirs(out_path, exist_ok=True)
     original_image = Image.open(args.source_image).convert("RGB").resize((size, size))
     original_image.save(os.path.join(out_path, "source.png"))
     latent = invertor.image2latent(model=pipe, image=original_image, device=device, dtype=torch.float32)
-    latents, _ = invertor.ddim_inversion_loop(pipe, latent, [args.source_prompt])
+    latents, context = invertor.ddim_inversion_loop(pipe, latent, [args.source_prompt])
+    extra = {}
+    if nti:
+        extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, latents, context, num_inner_steps,
+                                                                     early_stop_epsilon, GUIDANCE_SCALE)
     latent = latents[-1]
     images = editor(prompt=[args.source_prompt] + [args.target_prompt], num_inference_steps=num_inference_steps,
                     guidance_scale=GUIDANCE_SCALE, pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t,
-                    latents=torch.cat([latent, latent]))
+                    latents=torch.cat([latent, latent]), **extra)
     save_img(images[0], os.path.join(out_path, "inversion.png"))
     save_img(images[1], os.path.join(out_path, "edit.png"))
 

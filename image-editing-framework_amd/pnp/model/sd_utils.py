@@ -35,7 +35,7 @@ class PnP:
     def __call__(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, latents: Optional[torch.Tensor] = None,
                  pnp_attn_t: float = 0.5, pnp_f_t: float = 0.8, use_graph: bool = True, return_latents: bool = False,
-                 **unused):
+                 uncond_embeddings_list=None, **unused):
         model = self.model
         dev = model.unet.device
         model.scheduler.set_timesteps(num_inference_steps)
@@ -56,7 +56,9 @@ class PnP:
             g = guidance_scale if guidance_scale > 1.0 else None
             if g is None:
                 context = text_embeddings
-            loop = acquire(model, context, batch_size, (height // 8, width // 8), g, use_graph=use_graph)
+            # `PnP_NTI`: `prompt_embeds[0:2] = uncond_embeddings_list[i]` every step (:340) = per-step unconditional rows
+            loop = acquire(model, context, batch_size, (height // 8, width // 8), g, use_graph=use_graph,
+                           uncond_list=uncond_embeddings_list)
             try:
                 if use_graph:
                     latents = loop.run(latents)
@@ -84,3 +86,13 @@ class PnP:
             image = image.cpu().permute(0, 2, 3, 1).numpy()
             image = (image * 255).astype(np.uint8)
         return image
+
+
+class PnP_NTI(PnP):
+    """`PnP_NTI` of the reference (`pnp/model/sd_utils.py:262-`): the sampler with the per-step unconditional embeddings
+    of null-text inversion on both unconditional rows; `PnP.__call__` already takes `uncond_embeddings_list`."""
+
+    def __call__(self, *args, uncond_embeddings_list=None, **kw):
+        if uncond_embeddings_list is None:
+            raise ValueError("PnP_NTI: uncond_embeddings_list is required")
+        return super().__call__(*args, uncond_embeddings_list=uncond_embeddings_list, **kw)

@@ -1,4 +1,4 @@
-"""PIE-Bench driver for Plug-and-Play — `/root/reference/pnp/test.py:112-131` (ddim branch), sharded over the GPUs of
+"""PIE-Bench driver for Plug-and-Play — `/root/reference/pnp/test.py:112-` (ddim and null-text branches), sharded over the GPUs of
 one node exactly as `p2p/test.py`: rank r of W takes items i with i % W == r, no collective on the data path.
 
 Per image: DDIM inversion under the source prompt (50 steps, UNet batch 1) -> PnP sampler from
@@ -21,7 +21,8 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.pnp.model.sd_utils import PnP  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
+from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI  # noqa: E402
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
 
@@ -36,8 +37,9 @@ def main(argv=None):
     ap.add_argument("--no_save", action="store_true")
     ap.add_argument("--invert_batch", type=int, default=1)
     args = ap.parse_args(argv)
-    if args.inversion_type != "ddim":
-        raise NotImplementedError("pnp/test.py: only --inversion_type ddim is built (PnP_NTI is a later row)")
+    if args.inversion_type not in ("ddim", "null-text"):
+        raise ValueError("--inversion_type must be ddim or null-text")
+    nti = args.inversion_type == "null-text"
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(f"cuda:{local}")
@@ -48,7 +50,9 @@ def main(argv=None):
     seed_everything(42)
     pipe = load_pipe(args.sd_version, device)
     num_inference_steps, guidance_scale, pnp_attn_t, pnp_f_t = 50, 7.5, 1.0, 1.0
-    invertor, editor = ddim_inversion(), PnP(pipe, num_inference_steps)
+    num_inner_steps, early_stop_epsilon = 10, 1e-5
+    invertor = NTI() if nti else ddim_inversion()
+    editor = (PnP_NTI if nti else PnP)(pipe, num_inference_steps)
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor
     if args.synthetic > 0:
         root = os.path.join(args.exp_path, "_synthetic_inputs")
@@ -65,12 +69,18 @@ def main(argv=None):
         chunk = [items[i] for i in mine[c0:c0 + bs]]
         originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
         latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32) for im in originals])
-        latents, _ = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
+        latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
         for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
             x_T = latents[-1][j:j + 1].clone()
+            extra = {}
+            if nti:         # `PnP_NTI` (`/root/reference/pnp/test.py:132-`): null-text optimisation of this image first
+                lat_j = [l[j:j + 1].clone() for l in latents]
+                ctx_j = torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]])
+                extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, lat_j, ctx_j, num_inner_steps,
+                                                                             early_stop_epsilon, guidance_scale)
             images = editor(prompt=[source_prompt] + [target_prompt], num_inference_steps=num_inference_steps,
                             guidance_scale=guidance_scale, pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t,
-                            latents=torch.cat([x_T, x_T]))
+                            latents=torch.cat([x_T, x_T]), **extra)
             if not args.no_save:
                 out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
                 os.makedirs(out_path, exist_ok=True)

@@ -42,12 +42,18 @@ def pnp_forward(sd, cfg, sample, t, ctx, inject_qk: bool, inject_conv: bool):
 
 
 @torch.no_grad()
-def pnp_loop(sd, cfg, context, x_T, sched: DDIMRef, guidance_scale=7.5, pnp_attn_t=0.5, pnp_f_t=0.8, num_steps=None):
-    """context [4,77,C] = [uncond_src, uncond_tgt, cond_src, cond_tgt]; x_T [1,4,h,w] -> latents [2,4,h,w]"""
+def pnp_loop(sd, cfg, context, x_T, sched: DDIMRef, guidance_scale=7.5, pnp_attn_t=0.5, pnp_f_t=0.8, num_steps=None,
+             uncond_list=None):
+    """context [4,77,C] = [uncond_src, uncond_tgt, cond_src, cond_tgt]; x_T [1,4,h,w] -> latents [2,4,h,w].
+    uncond_list: `PnP_NTI` — both unconditional rows take the null-text embedding of step i
+    (`/root/reference/pnp/model/sd_utils.py:340`)."""
     n = sched.num_inference_steps
     qk_n, conv_n = int(n * pnp_attn_t), int(n * pnp_f_t)
     lat = x_T.expand(2, *x_T.shape[1:]).clone()
+    context = context.clone()
     for i, t in enumerate(sched.timesteps[: (num_steps or n)]):
+        if uncond_list is not None:
+            context[0:2] = uncond_list[i].expand(2, -1, -1)
         eps = pnp_forward(sd, cfg, torch.cat([lat] * 2), t, context, i < qk_n, i < conv_n)
         e_u, e_c = eps.chunk(2)
         lat = sched.step(e_u + guidance_scale * (e_c - e_u), int(t), lat)

@@ -20,7 +20,7 @@ from ief_amd.p2p.model.sd_utils import _encode_prompts  # noqa: E402
 from ief_amd.pnp.model.register import (register_attention_control_efficient, register_conv_control_efficient,  # noqa: E402
                                         register_time, unregister_attention_control_efficient,
                                         unregister_conv_control_efficient)
-from ief_amd.pnp.model.sd_utils import PnP  # noqa: E402
+from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI  # noqa: E402
 from oracle import p2p_ref, pnp_ref, unet_ref  # noqa: E402
 
 DEV = torch.device("cuda:0")
@@ -98,6 +98,29 @@ def test_pnp_loop_vs_oracle_graph_and_eager(tiny):
     assert images.shape == (2, cfg.sample_size * 8, cfg.sample_size * 8, 3) and images.dtype == np.uint8
 
 
+def test_pnp_nti_per_step_unconditional_rows(tiny):
+    """`PnP_NTI`: both unconditional rows take the null-text embedding of step i (`pnp/model/sd_utils.py:340`)"""
+    cfg = tiny.cfg
+    steps = 5
+    sched = p2p_ref.DDIMRef(num_inference_steps=steps)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(4))
+    g = torch.Generator().manual_seed(9)
+    rows = [torch.randn(1, 77, cfg.cross_attention_dim, generator=g) * 0.1 for _ in range(steps)]
+    editor = PnP_NTI(tiny, steps)
+    with torch.no_grad():
+        u, c = _encode_prompts(tiny, PROMPTS)
+    ctx = torch.cat([u, c]).float().cpu()
+    ref = pnp_ref.pnp_loop(tiny._state_dict, cfg, ctx, x_T, sched, 7.5, pnp_attn_t=1.0, pnp_f_t=1.0, uncond_list=rows)
+    fixed = pnp_ref.pnp_loop(tiny._state_dict, cfg, ctx, x_T, sched, 7.5, pnp_attn_t=1.0, pnp_f_t=1.0)
+    got = editor(prompt=PROMPTS, num_inference_steps=steps, guidance_scale=7.5, pnp_attn_t=1.0, pnp_f_t=1.0, latents=x_T,
+                 return_latents=True, uncond_embeddings_list=rows)
+    e, moved = rel_err(got, ref), rel_err(fixed, ref)
+    print(f"PnP_NTI {steps}-step loop: {e:.2e}; the per-step rows move the latents by {moved:.2e}")
+    assert e < 5e-2 and moved > 2 * e
+    with pytest.raises(ValueError):
+        editor(prompt=PROMPTS, num_inference_steps=steps, latents=x_T)
+
+
 def test_pnp_rejects_non_prefix_schedule(tiny):
     tiny.scheduler.set_timesteps(10)
     ts = tiny.scheduler.timesteps
@@ -119,12 +142,14 @@ def test_pnp_clis(tmp_path):
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
-    r = subprocess.run([sys.executable, os.path.join(pnp, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", "ddim",
-                        "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    for name in ("source.png", "inversion.png", "edit.png"):
-        assert (tmp_path / "exp" / name).exists()
+    for inv in ("ddim", "null-text"):
+        r = subprocess.run([sys.executable, os.path.join(pnp, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv,
+                            "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        for name in ("source.png", "inversion.png", "edit.png"):
+            assert (tmp_path / "exp" / name).exists()
+            os.remove(tmp_path / "exp" / name)
 
 
 def test_sd21_shape_family_forward_and_pnp():
