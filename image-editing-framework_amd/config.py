@@ -28,10 +28,24 @@ class UNetConfig:
     # SD2.x: Transformer2DModel.proj_in / proj_out are nn.Linear on tokens ([C, C] weights) instead of 1x1 convs
     # ([C, C, 1, 1]); the arithmetic is the same GEMM, only the checkpoint's tensor shapes differ
     use_linear_projection: bool = False
+    # SDXL: BasicTransformerBlocks per Transformer2DModel, per level (empty = one everywhere); the mid block takes the last
+    transformer_layers: Tuple[int, ...] = ()
+    # SDXL `addition_embed_type = "text_time"`: emb += add_embedding(cat([pooled text embeds, sinusoids of the 6 time ids]))
+    addition_embed: bool = False
+    addition_time_embed_dim: int = 256
+    pooled_text_dim: int = 1280
 
     @property
     def time_embed_dim(self) -> int:
         return self.block_out_channels[0] * self.time_embed_dim_mult
+
+    def depth(self, level: int) -> int:
+        return self.transformer_layers[level] if self.transformer_layers else 1
+
+    @property
+    def addition_input_dim(self) -> int:
+        """`projection_class_embeddings_input_dim`: pooled text + 6 time ids x addition_time_embed_dim (2816 for SDXL)"""
+        return self.pooled_text_dim + 6 * self.addition_time_embed_dim
 
 
 SD15 = UNetConfig()
@@ -66,6 +80,19 @@ SD21 = UNetConfig(sample_size=96, cross_attention_dim=1024, num_heads=(5, 10, 20
 SMALL21 = UNetConfig(sample_size=32, block_out_channels=(320, 640), down_has_attn=(True, True), cross_attention_dim=1024,
                      num_heads=(5, 10), use_linear_projection=True)
 
+# SDXL base shape family — the public `unet/config.json` of stabilityai/stable-diffusion-xl-base-1.0
+# (`/root/reference/pix2pix-zero/sd_mapping.py:2`, BASELINE.json config 5): 128x128 latents (1024x1024 px), three levels,
+# no attention at the first, transformer depth 1 / 2 / 10, head dim 64 (attention_head_dim = [5, 10, 20]), context 2048
+# (two text encoders concatenated), linear projections, text-time additional embedding.  2,567,463,684 parameters.
+SDXL = UNetConfig(sample_size=128, block_out_channels=(320, 640, 1280), down_has_attn=(False, True, True),
+                  cross_attention_dim=2048, num_heads=(5, 10, 20), use_linear_projection=True,
+                  transformer_layers=(1, 2, 10), addition_embed=True)
+
+# SDXL geometry (no attention at level 0, depth > 1, d = 64, additional embedding) small enough for the CPU oracle
+SMALLXL = UNetConfig(sample_size=16, block_out_channels=(64, 128, 256), down_has_attn=(False, True, True),
+                     cross_attention_dim=128, num_heads=(1, 2, 4), use_linear_projection=True,
+                     transformer_layers=(1, 2, 3), addition_embed=True, addition_time_embed_dim=32, pooled_text_dim=64)
+
 SCHEDULER_CONFIG = {
     "beta_end": 0.012,
     "beta_schedule": "scaled_linear",
@@ -79,4 +106,4 @@ SCHEDULER_CONFIG = {
     "use_karras_sigmas": False,
 }
 
-CONFIGS = {"sd15": SD15, "tiny": TINY, "small": SMALL, "sd21": SD21, "small21": SMALL21}
+CONFIGS = {"sd15": SD15, "tiny": TINY, "small": SMALL, "sd21": SD21, "small21": SMALL21, "sdxl": SDXL, "smallxl": SMALLXL}

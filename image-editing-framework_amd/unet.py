@@ -317,31 +317,44 @@ class BasicTransformerBlock(nn.Module):
         out = attn(x, encoder_hidden_states=ctx)
         return hip.add(out.contiguous(), res)
 
-    def forward(self, h, ctx, ln_stats=None):
-        """ln_stats: row moments of h from the GEMM that produced it => the three LayerNorms run folded (no launch)"""
+    def forward(self, h, ctx, ln_stats=None, want_stats=False):
+        """ln_stats: row moments of h from the GEMM that produced it => the three LayerNorms run folded (no launch);
+        want_stats: also return the row moments of the output (the next block of a deeper Transformer2DModel folds on them)"""
         if ln_stats is not None:
             h, st = self.attn1(h, residual=h, ln_stats=ln_stats, want_stats=True)
             h, st = self.attn2(h, encoder_hidden_states=ctx, residual=h, ln_stats=st, want_stats=True)
-            return self.ff.net[2](self.ff.net[0](h, ln_stats=st), residual=h)
+            g = self.ff.net[0](h, ln_stats=st)
+            lin = self.ff.net[2]
+            if want_stats:
+                return hip.gemm(g, lin.weight, bias=lin.bias, residual=h, row_stats=True)
+            return lin(g, residual=h)
         h = self._attend(self.attn1, self.norm1(h), h, None)
         h = self._attend(self.attn2, self.norm2(h), h, ctx)
         return self.ff(self.norm3(h), residual=h)
 
 
 class Transformer2DModel(nn.Module):
-    def __init__(self, sd, prefix, dim, heads, cross_dim, groups, dev, name):
+    def __init__(self, sd, prefix, dim, heads, cross_dim, groups, dev, name, depth=1):
         super().__init__()
         self.norm = GroupNorm(_f32(sd[prefix + ".norm.weight"], dev), _f32(sd[prefix + ".norm.bias"], dev), groups, 1e-6)
         c1 = lambda n: Conv2d(_f16(sd[f"{prefix}.{n}.weight"].reshape(dim, dim), dev), _f32(sd[f"{prefix}.{n}.bias"], dev), 1)
         self.proj_in, self.proj_out = c1("proj_in"), c1("proj_out")
+        # SDXL stacks several blocks per Transformer2DModel (config.transformer_layers); block 0 keeps the SD1.x layer name
         self.transformer_blocks = nn.ModuleList(
-            [BasicTransformerBlock(sd, prefix + ".transformer_blocks.0", dim, heads, cross_dim, dev, name)])
+            [BasicTransformerBlock(sd, f"{prefix}.transformer_blocks.{k}", dim, heads, cross_dim, dev,
+                                   name if k == 0 else f"{name}.b{k}") for k in range(depth)])
 
     def forward(self, x, encoder_hidden_states=None):
         B, H, W, C = x.shape
-        if all(blk.foldable() for blk in self.transformer_blocks) and len(self.transformer_blocks) == 1:
+        if all(blk.foldable() for blk in self.transformer_blocks):
             h, st = hip.gemm(self.norm(x), self.proj_in.weight, bias=self.proj_in.bias, row_stats=True)
-            h = self.transformer_blocks[0](h.reshape(B, H * W, C), encoder_hidden_states, ln_stats=st)
+            h = h.reshape(B, H * W, C)
+            last = len(self.transformer_blocks) - 1
+            for k, blk in enumerate(self.transformer_blocks):
+                if k < last:
+                    h, st = blk(h, encoder_hidden_states, ln_stats=st, want_stats=True)
+                else:
+                    h = blk(h, encoder_hidden_states, ln_stats=st)
             return self.proj_out(h.reshape(B, H, W, C), residual=x)
         h = self.proj_in(self.norm(x)).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
@@ -458,11 +471,11 @@ class Timesteps(nn.Module):
 
 
 class TimestepEmbedding(nn.Module):
-    def __init__(self, sd, dev):
+    def __init__(self, sd, dev, prefix="time_embedding"):
         super().__init__()
-        self.linear_1 = Linear(_f16(sd["time_embedding.linear_1.weight"], dev), _f32(sd["time_embedding.linear_1.bias"], dev))
+        self.linear_1 = Linear(_f16(sd[prefix + ".linear_1.weight"], dev), _f32(sd[prefix + ".linear_1.bias"], dev))
         self.act = SiLU()
-        self.linear_2 = Linear(_f16(sd["time_embedding.linear_2.weight"], dev), _f32(sd["time_embedding.linear_2.bias"], dev))
+        self.linear_2 = Linear(_f16(sd[prefix + ".linear_2.weight"], dev), _f32(sd[prefix + ".linear_2.bias"], dev))
 
     def forward(self, x):
         return self.linear_2(self.act(self.linear_1(x)))
@@ -486,6 +499,9 @@ class UNet2DConditionModel(nn.Module):
         self.conv_in = Conv2d(_f16(sd["conv_in.weight"].permute(2, 3, 1, 0), dev), _f32(sd["conv_in.bias"], dev), 3)  # [3,3,Cin,Cout]
         self.time_proj = Timesteps(ch[0])
         self.time_embedding = TimestepEmbedding(sd, dev)
+        if cfg.addition_embed:      # SDXL `addition_embed_type = "text_time"`
+            self.add_time_proj = Timesteps(cfg.addition_time_embed_dim)
+            self.add_embedding = TimestepEmbedding(sd, dev, "add_embedding")
         self._temb_width = 0
         self._resnets = []
 
@@ -505,7 +521,7 @@ class UNet2DConditionModel(nn.Module):
                 blk.resnets.append(resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout))
                 if cfg.down_has_attn[i]:
                     blk.attentions.append(Transformer2DModel(sd, f"down_blocks.{i}.attentions.{j}", cout, cfg.num_heads[i],
-                                                             cfg.cross_attention_dim, G, dev, f"down{i}.{j}"))
+                                                             cfg.cross_attention_dim, G, dev, f"down{i}.{j}", cfg.depth(i)))
             blk.downsamplers = nn.ModuleList([Downsample2D(sd, f"down_blocks.{i}.downsamplers.0", dev)]) if i < nlev - 1 else None
             self.down_blocks.append(blk)
         self.up_blocks = nn.ModuleList()
@@ -521,7 +537,7 @@ class UNet2DConditionModel(nn.Module):
         self.mid_block.has_cross_attention = True
         self.mid_block.resnets.append(resnet("mid_block.resnets.0", cm, cm))
         self.mid_block.attentions.append(Transformer2DModel(sd, "mid_block.attentions.0", cm, cfg.num_heads[-1],
-                                                            cfg.cross_attention_dim, G, dev, "mid"))
+                                                            cfg.cross_attention_dim, G, dev, "mid", cfg.depth(nlev - 1)))
         self.mid_block.resnets.append(resnet("mid_block.resnets.1", cm, cm))
         for i, prev, out_c, in_c in up_specs:
             blk = CrossAttnUpBlock2D() if rev_attn[i] else UpBlock2D()
@@ -534,7 +550,8 @@ class UNet2DConditionModel(nn.Module):
                 blk.resnets.append(resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, out_c))
                 if rev_attn[i]:
                     blk.attentions.append(Transformer2DModel(sd, f"up_blocks.{i}.attentions.{j}", out_c, rev_heads[i],
-                                                             cfg.cross_attention_dim, G, dev, f"up{i}.{j}"))
+                                                             cfg.cross_attention_dim, G, dev, f"up{i}.{j}",
+                                                             cfg.depth(nlev - 1 - i)))
             blk.upsamplers = nn.ModuleList([Upsample2D(sd, f"up_blocks.{i}.upsamplers.0", dev)]) if i < nlev - 1 else None
             self.up_blocks.append(blk)
         self.conv_norm_out = GroupNorm(_f32(sd["conv_norm_out.weight"], dev), _f32(sd["conv_norm_out.bias"], dev), G, eps)
@@ -578,9 +595,27 @@ class UNet2DConditionModel(nn.Module):
                     out.append(v)
         return out
 
-    def time_rows(self, timesteps_f32):
-        """fp32 [T, sum Cout]: time_emb_proj(silu(time_embedding(time_proj(t)))) for every resnet at once."""
+    def aug_embedding(self, added_cond_kwargs):
+        """SDXL: fp16 [B, time_embed_dim] = add_embedding(cat([text_embeds, sinusoids of the 6 time ids])) — constant over
+        the steps of one edit (`/root/reference/pix2pix-zero/model/sd_utils.py:408-421` builds the kwargs)"""
+        if not self.cfg.addition_embed:
+            return None
+        if added_cond_kwargs is None:
+            raise ValueError("this UNet has an additional text-time embedding: added_cond_kwargs is required")
+        te = added_cond_kwargs["text_embeds"].to(self._device).float().contiguous()
+        ids = added_cond_kwargs["time_ids"].to(self._device).float().contiguous()
+        B = te.shape[0]
+        tim = self.add_time_proj(ids.reshape(-1).contiguous()).reshape(B, -1)
+        return self.add_embedding(torch.cat([hip.to_f16(te), tim], dim=-1).contiguous())
+
+    def time_rows(self, timesteps_f32, aug=None):
+        """fp32 [T, sum Cout]: time_emb_proj(silu(time_embedding(time_proj(t)))) for every resnet at once.
+        aug (fp16 [B, time_embed_dim], `aug_embedding`): rows become [T * B, sum Cout], step-major."""
         emb = self.time_embedding(self.time_proj(timesteps_f32))
+        if aug is not None:
+            T, B = emb.shape[0], aug.shape[0]
+            emb = hip.add(emb[:, None, :].expand(T, B, -1).contiguous(), aug[None].expand(T, B, -1).contiguous())
+            emb = emb.reshape(T * B, -1)
         rows = hip.gemm(hip.silu(emb), self._temb_w, bias=self._temb_b)
         return hip.to_f32(rows)
 
@@ -607,7 +642,7 @@ class UNet2DConditionModel(nn.Module):
             ctx = self._ctx_f16(ctx)
         if temb_row is None:
             t = torch.as_tensor(timestep).to(device=self._device, dtype=torch.float32).reshape(-1)[:1].contiguous()
-            temb_row = self.time_rows(t)
+            temb_row = self.time_rows(t, self.aug_embedding(added_cond_kwargs))     # [1 or B, width]
         trow = lambda r: temb_row[:, r.temb_slot[0]:r.temb_slot[0] + r.temb_slot[1]].contiguous()
         if self._plan is not None:
             self._plan.begin_forward(B)

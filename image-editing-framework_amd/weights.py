@@ -30,25 +30,26 @@ def _resnet(shapes, p, cin, cout, temb):
         shapes[p + ".conv_shortcut.bias"] = (cout,)
 
 
-def _transformer(shapes, p, c, ctx, linear=False):
+def _transformer(shapes, p, c, ctx, linear=False, depth=1):
     shapes[p + ".norm.weight"] = (c,)
     shapes[p + ".norm.bias"] = (c,)
     shapes[p + ".proj_in.weight"] = (c, c) if linear else (c, c, 1, 1)
     shapes[p + ".proj_in.bias"] = (c,)
-    b = p + ".transformer_blocks.0"
-    for n in ("norm1", "norm2", "norm3"):
-        shapes[f"{b}.{n}.weight"] = (c,)
-        shapes[f"{b}.{n}.bias"] = (c,)
-    for a, kdim in (("attn1", c), ("attn2", ctx)):
-        shapes[f"{b}.{a}.to_q.weight"] = (c, c)
-        shapes[f"{b}.{a}.to_k.weight"] = (c, kdim)
-        shapes[f"{b}.{a}.to_v.weight"] = (c, kdim)
-        shapes[f"{b}.{a}.to_out.0.weight"] = (c, c)
-        shapes[f"{b}.{a}.to_out.0.bias"] = (c,)
-    shapes[f"{b}.ff.net.0.proj.weight"] = (8 * c, c)
-    shapes[f"{b}.ff.net.0.proj.bias"] = (8 * c,)
-    shapes[f"{b}.ff.net.2.weight"] = (c, 4 * c)
-    shapes[f"{b}.ff.net.2.bias"] = (c,)
+    for k in range(depth):
+        b = f"{p}.transformer_blocks.{k}"
+        for n in ("norm1", "norm2", "norm3"):
+            shapes[f"{b}.{n}.weight"] = (c,)
+            shapes[f"{b}.{n}.bias"] = (c,)
+        for a, kdim in (("attn1", c), ("attn2", ctx)):
+            shapes[f"{b}.{a}.to_q.weight"] = (c, c)
+            shapes[f"{b}.{a}.to_k.weight"] = (c, kdim)
+            shapes[f"{b}.{a}.to_v.weight"] = (c, kdim)
+            shapes[f"{b}.{a}.to_out.0.weight"] = (c, c)
+            shapes[f"{b}.{a}.to_out.0.bias"] = (c,)
+        shapes[f"{b}.ff.net.0.proj.weight"] = (8 * c, c)
+        shapes[f"{b}.ff.net.0.proj.bias"] = (8 * c,)
+        shapes[f"{b}.ff.net.2.weight"] = (c, 4 * c)
+        shapes[f"{b}.ff.net.2.bias"] = (c,)
     shapes[p + ".proj_out.weight"] = (c, c) if linear else (c, c, 1, 1)
     shapes[p + ".proj_out.bias"] = (c,)
 
@@ -65,19 +66,25 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
     s["time_embedding.linear_1.bias"] = (temb,)
     s["time_embedding.linear_2.weight"] = (temb, temb)
     s["time_embedding.linear_2.bias"] = (temb,)
+    if cfg.addition_embed:
+        s["add_embedding.linear_1.weight"] = (temb, cfg.addition_input_dim)
+        s["add_embedding.linear_1.bias"] = (temb,)
+        s["add_embedding.linear_2.weight"] = (temb, temb)
+        s["add_embedding.linear_2.bias"] = (temb,)
     cout = ch[0]
     for i in range(nlev):
         cin, cout = cout, ch[i]
         for j in range(cfg.layers_per_block):
             _resnet(s, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, temb)
             if cfg.down_has_attn[i]:
-                _transformer(s, f"down_blocks.{i}.attentions.{j}", cout, cfg.cross_attention_dim, cfg.use_linear_projection)
+                _transformer(s, f"down_blocks.{i}.attentions.{j}", cout, cfg.cross_attention_dim, cfg.use_linear_projection,
+                             cfg.depth(i))
         if i < nlev - 1:
             s[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
             s[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (cout,)
     cm = ch[-1]
     _resnet(s, "mid_block.resnets.0", cm, cm, temb)
-    _transformer(s, "mid_block.attentions.0", cm, cfg.cross_attention_dim, cfg.use_linear_projection)
+    _transformer(s, "mid_block.attentions.0", cm, cfg.cross_attention_dim, cfg.use_linear_projection, cfg.depth(nlev - 1))
     _resnet(s, "mid_block.resnets.1", cm, cm, temb)
     rev = tuple(reversed(ch))
     rev_attn = tuple(reversed(cfg.down_has_attn))
@@ -90,7 +97,8 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
             rin = prev if j == 0 else out_c
             _resnet(s, f"up_blocks.{i}.resnets.{j}", rin + skip, out_c, temb)
             if rev_attn[i]:
-                _transformer(s, f"up_blocks.{i}.attentions.{j}", out_c, cfg.cross_attention_dim, cfg.use_linear_projection)
+                _transformer(s, f"up_blocks.{i}.attentions.{j}", out_c, cfg.cross_attention_dim, cfg.use_linear_projection,
+                             cfg.depth(nlev - 1 - i))
         if i < nlev - 1:
             s[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
             s[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)

@@ -90,16 +90,19 @@ def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, q
     else:
         h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
-    b = p + ".transformer_blocks.0"
-    n = F.layer_norm(h, (C,), sd[b + ".norm1.weight"], sd[b + ".norm1.bias"], 1e-5)
-    h = h + attention(sd, b + ".attn1", n, None, heads, hook, place, qkv_hook, qkv_path_hook)
-    n = F.layer_norm(h, (C,), sd[b + ".norm2.weight"], sd[b + ".norm2.bias"], 1e-5)
-    h = h + attention(sd, b + ".attn2", n, ctx, heads, hook, place, qkv_hook, qkv_path_hook)
-    n = F.layer_norm(h, (C,), sd[b + ".norm3.weight"], sd[b + ".norm3.bias"], 1e-5)
-    g = F.linear(n, sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"])
-    hid, gate = g.chunk(2, dim=-1)
-    g = hid * F.gelu(gate)
-    h = h + F.linear(g, sd[b + ".ff.net.2.weight"], sd[b + ".ff.net.2.bias"])
+    k = 0
+    while f"{p}.transformer_blocks.{k}.norm1.weight" in sd:       # SDXL: several BasicTransformerBlocks per Transformer2DModel
+        b = f"{p}.transformer_blocks.{k}"
+        n = F.layer_norm(h, (C,), sd[b + ".norm1.weight"], sd[b + ".norm1.bias"], 1e-5)
+        h = h + attention(sd, b + ".attn1", n, None, heads, hook, place, qkv_hook, qkv_path_hook)
+        n = F.layer_norm(h, (C,), sd[b + ".norm2.weight"], sd[b + ".norm2.bias"], 1e-5)
+        h = h + attention(sd, b + ".attn2", n, ctx, heads, hook, place, qkv_hook, qkv_path_hook)
+        n = F.layer_norm(h, (C,), sd[b + ".norm3.weight"], sd[b + ".norm3.bias"], 1e-5)
+        g = F.linear(n, sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"])
+        hid, gate = g.chunk(2, dim=-1)
+        g = hid * F.gelu(gate)
+        h = h + F.linear(g, sd[b + ".ff.net.2.weight"], sd[b + ".ff.net.2.bias"])
+        k += 1
     if sd[p + ".proj_out.weight"].dim() == 2:
         h = F.linear(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]).reshape(B, H, W, C).permute(0, 3, 1, 2)
     else:
@@ -109,7 +112,8 @@ def transformer(sd, p: str, x, ctx, heads: int, groups: int, hook, place: str, q
 
 
 # --------------------------------------------------------------------------- whole net
-def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=None, qkv_path_hook=None, res_inject=None):
+def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=None, qkv_path_hook=None, res_inject=None,
+                 added_cond_kwargs=None):
     """sample [B,4,H,W] fp32, timestep scalar/int tensor, ctx [B,77,Cc] -> eps [B,4,H,W].
 
     `hook(probs, is_cross, place)` is called once per Attention module in module-tree
@@ -129,6 +133,18 @@ def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=
     temb = timestep_embedding(t, ch[0])
     temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
     temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    if "add_embedding.linear_1.weight" in sd:
+        # SDXL `addition_embed_type == "text_time"` (diffusers UNet2DConditionModel.get_aug_embed [ext]): the 6 time ids are
+        # embedded like timesteps (dim 256 each), flattened, appended to the pooled text embedding, and run through a
+        # TimestepEmbedding MLP; the result is added to the time embedding
+        # (`/root/reference/pix2pix-zero/model/sd_utils.py:408-421` builds the kwargs)
+        text_embeds, time_ids = added_cond_kwargs["text_embeds"].float(), added_cond_kwargs["time_ids"].float()
+        dim = (sd["add_embedding.linear_1.weight"].shape[1] - text_embeds.shape[-1]) // time_ids.shape[-1]
+        time_embeds = timestep_embedding(time_ids.flatten(), dim).reshape(B, -1)
+        aug = torch.cat([text_embeds, time_embeds], dim=-1)
+        aug = F.linear(aug, sd["add_embedding.linear_1.weight"], sd["add_embedding.linear_1.bias"])
+        aug = F.linear(F.silu(aug), sd["add_embedding.linear_2.weight"], sd["add_embedding.linear_2.bias"])
+        temb = temb + aug
 
     def tap(name, v):
         if taps is not None:
@@ -173,6 +189,7 @@ def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=
 
 
 def count_attention_layers(cfg) -> int:
-    n_tr = sum(cfg.layers_per_block for a in cfg.down_has_attn if a) + 1
-    n_tr += sum(cfg.layers_per_block + 1 for a in cfg.down_has_attn if a)
+    nlev = len(cfg.block_out_channels)
+    n_tr = sum(cfg.layers_per_block * cfg.depth(i) for i, a in enumerate(cfg.down_has_attn) if a) + cfg.depth(nlev - 1)
+    n_tr += sum((cfg.layers_per_block + 1) * cfg.depth(i) for i, a in enumerate(cfg.down_has_attn) if a)
     return 2 * n_tr

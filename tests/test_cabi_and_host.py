@@ -57,6 +57,7 @@ def test_tile_plans():
 def test_param_inventory_matches_sd15():
     assert weights.num_params(config.SD15) == 859_520_964      # the published SD1.5 UNet parameter count
     assert weights.num_params(config.SD21) == 865_910_724      # the published SD2.1 UNet parameter count
+    assert weights.num_params(config.SDXL) == 2_567_463_684    # the published SDXL base UNet parameter count
     sd = weights.synthetic_state_dict(config.TINY, 0)
     sd2 = weights.synthetic_state_dict(config.TINY, 0)
     assert all(torch.equal(sd[k], sd2[k]) for k in sd)          # deterministic
@@ -283,3 +284,32 @@ def test_oracle_p2pzero_invariants():
             eu, ec = eps.chunk(2)
             lat = sched.step(eu + 7.5 * (ec - eu), int(t), lat)
     assert torch.allclose(e0, lat, atol=1e-6)
+
+
+def test_oracle_sdxl_family_invariants():
+    """oracle self-checks for the SDXL geometry: the additional text-time embedding reaches the output, depth > 1
+    transformers run every block (zeroing the LAST block's output projections changes the result), and the module tree of
+    the product holds depth(level) blocks per Transformer2DModel"""
+    from oracle import unet_ref
+    from ief_amd.unet import UNet2DConditionModel
+    cfg = config.SMALLXL
+    sd = weights.synthetic_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    added = {"text_embeds": torch.randn(2, cfg.pooled_text_dim, generator=g), "time_ids": torch.tensor([[64.0, 64, 0, 0, 64, 64]] * 2)}
+    with torch.no_grad():
+        y = unet_ref.unet_forward(sd, cfg, x, 501, ctx, added_cond_kwargs=added)
+        y2 = unet_ref.unet_forward(sd, cfg, x, 501, ctx, added_cond_kwargs=dict(added, time_ids=added["time_ids"] * 2))
+        assert (y - y2).abs().max() > 1e-4
+        last = f"mid_block.attentions.0.transformer_blocks.{cfg.depth(2) - 1}"
+        sd2 = dict(sd)
+        for k in sd:
+            if k.startswith(last) and ("to_out.0" in k or "ff.net.2" in k):
+                sd2[k] = torch.zeros_like(sd[k])
+        y3 = unet_ref.unet_forward(sd2, cfg, x, 501, ctx, added_cond_kwargs=added)
+        assert (y - y3).abs().max() > 1e-4
+    u = UNet2DConditionModel(cfg, sd, device="cpu")
+    assert [len(t.transformer_blocks) for t in u.mid_block.attentions] == [cfg.depth(2)]
+    assert not u.down_blocks[0].has_cross_attention and len(u.down_blocks[1].attentions[0].transformer_blocks) == cfg.depth(1)
+    assert len(u.attention_modules()) == unet_ref.count_attention_layers(cfg)
