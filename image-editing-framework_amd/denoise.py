@@ -32,8 +32,11 @@ _POOL_CAP = 8
 
 class FusedDenoiser:
     def __init__(self, model, context: torch.Tensor, num_latents: int, latent_hw, guidance_scale: Optional[float],
-                 mode: str = "denoise", uncond_list: Optional[List[torch.Tensor]] = None, use_graph: bool = True):
-        """context: [2*Bp,77,C] (uncond, cond) for mode 'denoise' with CFG, [Bp,77,C] for 'invert' / no-CFG."""
+                 mode: str = "denoise", uncond_list: Optional[List[torch.Tensor]] = None, use_graph: bool = True,
+                 added_cond_kwargs=None):
+        """context: [2*Bp,77,C] (uncond, cond) for mode 'denoise' with CFG, [Bp,77,C] for 'invert' / no-CFG.
+        added_cond_kwargs: SDXL's {"text_embeds" [B, 1280], "time_ids" [B, 6]} (one row per UNet batch row); they are
+        constant over the steps, so they fold into the per-step time-embedding rows (then one row PER BATCH ROW)."""
         self.model, self.unet, self.sched = model, model.unet, model.scheduler
         dev = self.unet.device
         self.mode = mode
@@ -49,13 +52,13 @@ class FusedDenoiser:
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.coef_cur = torch.zeros(4, dtype=torch.float32, device=dev)
         self.coef_table = self.temb_table = self.temb_cur = self.ctx = self.ctx_table = None
-        self._fill(context, guidance_scale, uncond_list)
+        self._fill(context, guidance_scale, uncond_list, added_cond_kwargs)
         self.use_graph = use_graph
         self.graph = None
         self.plan = self.unet._plan
         self._keep, self._pooled_started, self._pool_key = None, False, None
 
-    def _fill(self, context, guidance_scale, uncond_list):
+    def _fill(self, context, guidance_scale, uncond_list, added_cond_kwargs=None):
         """(re)compute every table the step graph reads, IN PLACE once the buffers exist (re-use of a captured loop)"""
         dev = self.unet.device
         ts = self.sched.timesteps.tolist()
@@ -75,9 +78,14 @@ class FusedDenoiser:
                 cur.copy_(value)
 
         put("coef_table", torch.tensor([[a, b, g, 0.0] for a, b in coef], dtype=torch.float32, device=dev))
-        put("temb_table", self.unet.time_rows(torch.tensor(ts, dtype=torch.float32, device=dev)).contiguous())
+        aug = self.unet.aug_embedding(added_cond_kwargs)          # None unless the UNet has SDXL's additional embedding
+        if aug is not None and aug.shape[0] != self.B:
+            raise ValueError(f"added_cond_kwargs batch {aug.shape[0]} != UNet batch {self.B}")
+        rows = self.unet.time_rows(torch.tensor(ts, dtype=torch.float32, device=dev), aug)
+        nb = 1 if aug is None else self.B
+        put("temb_table", rows.reshape(len(ts), nb, -1).contiguous())
         if self.temb_cur is None:
-            self.temb_cur = torch.zeros(1, self.temb_table.shape[1], dtype=torch.float32, device=dev)
+            self.temb_cur = torch.zeros(nb, self.temb_table.shape[2], dtype=torch.float32, device=dev)
         ctx16 = hip.to_f16(context.to(dev).float().contiguous())
         if uncond_list is not None:  # null-text embeddings: the uncond half changes every step
             rows = []
@@ -96,9 +104,9 @@ class FusedDenoiser:
                 None if uncond_list is None else len(uncond_list), len(self.sched.timesteps),
                 None if plan is None else plan.signature(self.unet))
 
-    def rebind(self, context, guidance_scale, uncond_list):
+    def rebind(self, context, guidance_scale, uncond_list, added_cond_kwargs=None):
         """point a captured loop at the next image: new tables, new cross-attention K/V, the new controller's plan"""
-        self._fill(context, guidance_scale, uncond_list)
+        self._fill(context, guidance_scale, uncond_list, added_cond_kwargs)
         if self.ctx_table is None:          # K/V of the fixed context live in tensors the graph reads: refresh in place
             for m, kv in self._keep:
                 hip.gemm(self.ctx, m.w_kv, out=kv)
@@ -212,7 +220,7 @@ class FusedDenoiser:
 
 
 def acquire(model, context, num_latents, latent_hw, guidance_scale, mode="denoise", uncond_list=None,
-            use_graph=True) -> FusedDenoiser:
+            use_graph=True, added_cond_kwargs=None) -> FusedDenoiser:
     """a FusedDenoiser for this job: a pooled one with a captured graph of the same shape / plan signature, re-pointed
     at the new context, tables and controller — or a new one"""
     if REUSE_GRAPHS and use_graph:
@@ -224,12 +232,14 @@ def acquire(model, context, num_latents, latent_hw, guidance_scale, mode="denois
         free = _POOL.get(key)
         if free:
             loop = free.pop()
-            loop.rebind(context, guidance_scale, uncond_list)
+            loop.rebind(context, guidance_scale, uncond_list, added_cond_kwargs)
             return loop
-        loop = FusedDenoiser(model, context, num_latents, latent_hw, guidance_scale, mode, uncond_list, use_graph)
+        loop = FusedDenoiser(model, context, num_latents, latent_hw, guidance_scale, mode, uncond_list, use_graph,
+                             added_cond_kwargs)
         loop._pool_key = key
         return loop
-    return FusedDenoiser(model, context, num_latents, latent_hw, guidance_scale, mode, uncond_list, use_graph)
+    return FusedDenoiser(model, context, num_latents, latent_hw, guidance_scale, mode, uncond_list, use_graph,
+                         added_cond_kwargs)
 
 
 def drop_pool():

@@ -32,6 +32,7 @@ def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32):
     scheduler = DDIMScheduler.from_config(SCHEDULER_CONFIG)
     if sd_version in ("1.5", "1.4", "2.1", "tiny", "small", "small21"):
         return StableDiffusionPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device)
-    if sd_version in ("xl-base",):
-        raise ValueError(f"sd_version {sd_version}: the SDXL shape family is not built yet (DESIGN.md, next rows)")
+    if sd_version in ("xl-base", "smallxl"):       # `StableDiffusionXLPipeline` branch of edit_syn.py:63-65
+        from ief_amd.pipeline import StableDiffusionXLPipeline
+        return StableDiffusionXLPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device)
     raise ValueError("please use the right sd_version")

@@ -13,7 +13,7 @@ from _bootstrap import load_pipe, seed_everything
 
 from ief_amd.p2p.model.attention_base import EmptyControl
 from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace
-from ief_amd.p2p.model.sd_utils import P2P
+from ief_amd.p2p.model.sd_utils import P2P, P2P_XL
 from ief_amd.p2p.utils.save_image import save_img
 
 parser = argparse.ArgumentParser("General config")
@@ -35,9 +35,12 @@ def main(argv=None):
     edit_type = "refine"  # ["refine", "replace"]
 
     pipe = load_pipe(args.sd_version, device)
-    if pipe.__class__.__name__ != "StableDiffusionPipeline":
+    if pipe.__class__.__name__ == "StableDiffusionPipeline":            # dispatch of edit_syn.py:90-93
+        editor = P2P(model=pipe, num_inference_steps=num_inference_steps)
+    elif pipe.__class__.__name__ == "StableDiffusionXLPipeline":
+        editor = P2P_XL(model=pipe, num_inference_steps=num_inference_steps)
+    else:
         raise ValueError("please use the right sd_version")
-    editor = P2P(model=pipe, num_inference_steps=num_inference_steps)
 
     os.makedirs(out_path, exist_ok=True)
     controller = EmptyControl(LOW_RESOURCE=LOW_RESOURCE)

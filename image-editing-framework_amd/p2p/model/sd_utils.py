@@ -72,13 +72,13 @@ class P2P:
         if height is None:
             height = width = model.unet.config.sample_size * model.vae_scale_factor
         batch_size = len(prompt)
-        uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+        uncond_embeddings, text_embeddings, added_cond_kwargs = self._encode(model, prompt, height, width)
         latent, latents = self.init_latent(latent, model, height, width, generator, batch_size)
         model.scheduler.set_timesteps(num_inference_steps)
         context = torch.cat([uncond_embeddings, text_embeddings])
         if _fusable(model, controller, low_resource):
             loop = acquire(model, context, batch_size, (height // 8, width // 8), guidance_scale,
-                                 uncond_list=uncond_embeddings_list)
+                                 uncond_list=uncond_embeddings_list, added_cond_kwargs=added_cond_kwargs)
             try:
                 latents = loop.run(latents)
             finally:
@@ -87,11 +87,17 @@ class P2P:
             for i, t in enumerate(tqdm(model.scheduler.timesteps, desc="Now doing P2P editing")):
                 if uncond_embeddings_list is not None:
                     context = torch.cat([uncond_embeddings_list[i].expand(*text_embeddings.shape), text_embeddings])
-                latents = self.diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource)
+                latents = self.diffusion_step(model, controller, latents, context, t, guidance_scale, low_resource,
+                                              added_cond_kwargs=added_cond_kwargs)
         if return_latents:
             return latents, latent
         image = self.latent2image(model.vae, latents)
         return image, latent
+
+    def _encode(self, model, prompt, height, width):
+        """-> (uncond [B,77,C], cond [B,77,C], added_cond_kwargs or None)"""
+        uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+        return uncond_embeddings, text_embeddings, None
 
     @torch.no_grad()
     def edit_many(self, model, jobs, num_inference_steps: int = 50, guidance_scale: float = 7.5,
@@ -128,15 +134,18 @@ class P2P:
             for loop in loops:
                 loop.release()
 
-    def diffusion_step(self, model, controller, latents, context, t, guidance_scale, low_resource=False):
-        """one eager step (`sd_utils.py:67-79`); CFG + DDIM update fused in one kernel."""
+    def diffusion_step(self, model, controller, latents, context, t, guidance_scale, low_resource=False,
+                       added_cond_kwargs=None):
+        """one eager step (`sd_utils.py:67-79`, XL: :175-186); CFG + DDIM update fused in one kernel."""
         latents = latents.float().contiguous()
         if low_resource:
             bp = latents.shape[0]
-            eps_u = model.unet(latents, t, encoder_hidden_states=context[:bp])["sample"]
-            eps_c = model.unet(latents, t, encoder_hidden_states=context[bp:])["sample"]
+            half = lambda i: None if added_cond_kwargs is None else {k: v[i * bp:(i + 1) * bp] for k, v in added_cond_kwargs.items()}
+            eps_u = model.unet(latents, t, encoder_hidden_states=context[:bp], added_cond_kwargs=half(0))["sample"]
+            eps_c = model.unet(latents, t, encoder_hidden_states=context[bp:], added_cond_kwargs=half(1))["sample"]
         else:
-            eps = model.unet(torch.cat([latents] * 2), t, encoder_hidden_states=context)["sample"]
+            eps = model.unet(torch.cat([latents] * 2), t, encoder_hidden_states=context,
+                             added_cond_kwargs=added_cond_kwargs)["sample"]
             eps_u, eps_c = eps.chunk(2)
         a_t, a_p = model.scheduler.step_coeffs(int(t))
         coef = torch.tensor([a_t, a_p, float(guidance_scale)], dtype=torch.float32, device=latents.device)
@@ -152,6 +161,36 @@ class P2P:
         image = (image / 2 + 0.5).clamp(0, 1)
         image = image.cpu().permute(0, 2, 3, 1).numpy()
         return (image * 255).astype(np.uint8)
+
+
+class P2P_XL(P2P):
+    """`P2P_XL` (`/root/reference/p2p/model/sd_utils.py:142-224`): the same sampler on an SDXL-family pipeline.  What
+    differs is the text side — two encoders, pooled embeddings and the six time ids handed to the UNet as
+    `added_cond_kwargs` — and the latent size (the reference hard-codes 1024x1024, :160; here the pipeline's own sample
+    size, which is 1024 for `xl-base`).  The additional embedding is constant over the steps, so the captured step graph
+    reads it folded into its per-step time-embedding rows (`denoise.FusedDenoiser`)."""
+
+    def _encode(self, model, prompt, height, width):
+        return self.encode_prompt_xl(model, prompt, model._execution_device, True, height, width, len(prompt), split=True)
+
+    def encode_prompt_xl(self, model, prompt, device, do_classifier_free_guidance, height, width, batch_size, split=False):
+        """(:186-224) -> (prompt_embeds [2B,77,C], added_cond_kwargs); split=True -> (uncond, cond, added_cond_kwargs)"""
+        prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = model.encode_prompt(
+            prompt=prompt, prompt_2=None, device=device, num_images_per_prompt=1,
+            do_classifier_free_guidance=do_classifier_free_guidance, negative_prompt=None, negative_prompt_2=None)
+        original_size = target_size = (height, width)
+        add_time_ids = model._get_add_time_ids(original_size, (0, 0), target_size, dtype=prompt_embeds.dtype)
+        add_text_embeds = pooled
+        if do_classifier_free_guidance:
+            add_text_embeds = torch.cat([negative_pooled, pooled], dim=0)
+            add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
+        add_time_ids = add_time_ids.to(device).repeat(batch_size, 1)
+        added_cond_kwargs = {"text_embeds": add_text_embeds.to(device), "time_ids": add_time_ids}
+        if split:
+            return negative_prompt_embeds.to(device), prompt_embeds.to(device), added_cond_kwargs
+        if do_classifier_free_guidance:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        return prompt_embeds.to(device), added_cond_kwargs
 
 
 class P2P_NTI(P2P):

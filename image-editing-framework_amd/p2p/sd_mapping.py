@@ -10,9 +10,10 @@ import os
 sd_maps = {
     "1.4": os.environ.get("IEF_SD14_DIR", "synthetic:sd15"),   # same architecture as 1.5
     "1.5": os.environ.get("IEF_SD15_DIR", "synthetic:sd15"),
-    "xl-base": os.environ.get("IEF_SDXL_DIR", "stabilityai/stable-diffusion-xl-base-1.0"),  # next-tier shape family
+    "xl-base": os.environ.get("IEF_SDXL_DIR", "synthetic:sdxl"),
     "2.1": os.environ.get("IEF_SD21_DIR", "synthetic:sd21"),
     "tiny": "synthetic:tiny",
     "small": "synthetic:small",
     "small21": "synthetic:small21",
+    "smallxl": "synthetic:smallxl",
 }

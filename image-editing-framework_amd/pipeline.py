@@ -98,6 +98,67 @@ class StableDiffusionPipeline:
         return self.unet.device
 
 
+class StableDiffusionXLPipeline(StableDiffusionPipeline):
+    """The surface the reference's `*_XL` samplers use (`/root/reference/p2p/model/sd_utils.py:186-224`): two text
+    encoders whose hidden states are concatenated into the 2048-wide context, the second one's pooled output, and
+    `_get_add_time_ids`.  With synthetic weights both encoders are seeded stand-ins (off the per-step path)."""
+
+    def __init__(self, unet, tokenizer, text_encoder, vae, scheduler, cfg, state_dict=None, text_encoder_2=None):
+        super().__init__(unet, tokenizer, text_encoder, vae, scheduler, cfg, state_dict)
+        self.tokenizer_2, self.text_encoder_2 = tokenizer, text_encoder_2
+
+    @classmethod
+    def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
+                        keep_state_dict: bool = False, **unused):
+        from .unet import UNet2DConditionModel
+        if not model_key.startswith("synthetic:"):
+            raise FileNotFoundError(
+                f"'{model_key}': no SDXL checkpoint exists offline and the local-directory loader for the two CLIP text "
+                "encoders is not written; use 'synthetic:sdxl' (seeded weights of the public architecture)")
+        parts = model_key.split(":")
+        cfg = CONFIGS[parts[1]]
+        if not cfg.addition_embed:
+            raise ValueError(f"{parts[1]} is not an SDXL-family configuration")
+        seed = int(parts[2]) if len(parts) > 2 else 0
+        sd = _weights.synthetic_state_dict(cfg, seed)
+        d2 = cfg.pooled_text_dim
+        tokenizer = WordPieceTokenizer(cfg.text_max_length)
+        enc1 = SyntheticTextEncoder(cfg.cross_attention_dim - d2, seed=1).to(device)
+        enc2 = SyntheticTextEncoder(d2, seed=2).to(device)
+        import dataclasses
+        vcfg = SD_VAE if parts[1] == "sdxl" else TINY_VAE
+        vae = AutoencoderKL(dataclasses.replace(vcfg, scaling_factor=0.13025), device=device)   # the SDXL VAE's factor
+        unet = UNet2DConditionModel(cfg, sd, device=device)
+        sched = scheduler if scheduler is not None else DDIMScheduler()
+        return cls(unet, tokenizer, enc1, vae, sched, cfg, sd if keep_state_dict else None, text_encoder_2=enc2)
+
+    @torch.no_grad()
+    def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt=1, do_classifier_free_guidance=True,
+                      negative_prompt=None, negative_prompt_2=None, prompt_embeds=None, negative_prompt_embeds=None,
+                      pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None, lora_scale=None, **unused):
+        """-> (prompt_embeds [B,77,C1+C2], negative_prompt_embeds, pooled [B,C2], negative_pooled).  As SDXL base does
+        (`force_zeros_for_empty_prompt`), a missing negative prompt gives ZERO embeddings, not the encoding of ""."""
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        tok = self.tokenizer
+        ids = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+        h1 = self.text_encoder(ids.to(self.device))[0]
+        h2 = self.text_encoder_2(ids.to(self.device))[0]
+        embeds = torch.cat([h1, h2], dim=-1)
+        pooled = h2.mean(dim=1)
+        if negative_prompt is None:
+            neg, neg_pooled = torch.zeros_like(embeds), torch.zeros_like(pooled)
+        else:
+            nids = tok([negative_prompt] * len(prompt) if isinstance(negative_prompt, str) else list(negative_prompt),
+                       padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+            n1, n2 = self.text_encoder(nids.to(self.device))[0], self.text_encoder_2(nids.to(self.device))[0]
+            neg, neg_pooled = torch.cat([n1, n2], dim=-1), n2.mean(dim=1)
+        return embeds, neg, pooled, neg_pooled
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype=torch.float32,
+                          text_encoder_projection_dim=None):
+        return torch.tensor([list(original_size + crops_coords_top_left + target_size)], dtype=dtype)
+
+
 def _load_local_unet(path):
     import json
     from safetensors.torch import load_file
@@ -112,7 +173,13 @@ def _load_local_unet(path):
         down_has_attn=tuple("CrossAttn" in t for t in c["down_block_types"]),
         layers_per_block=c["layers_per_block"], cross_attention_dim=c["cross_attention_dim"], num_heads=heads,
         norm_num_groups=c["norm_num_groups"], norm_eps=c.get("norm_eps", 1e-5),
-        use_linear_projection=bool(c.get("use_linear_projection", False)))
+        use_linear_projection=bool(c.get("use_linear_projection", False)),
+        transformer_layers=(tuple(c["transformer_layers_per_block"])
+                            if isinstance(c.get("transformer_layers_per_block"), (list, tuple)) else ()),
+        addition_embed=c.get("addition_embed_type") == "text_time",
+        addition_time_embed_dim=c.get("addition_time_embed_dim") or 256,
+        pooled_text_dim=(c["projection_class_embeddings_input_dim"] - 6 * (c.get("addition_time_embed_dim") or 256))
+        if c.get("addition_embed_type") == "text_time" else 1280)
     sd = load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
     missing = [k for k in _weights.unet_param_shapes(cfg) if k not in sd]
     if missing:

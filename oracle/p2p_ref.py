@@ -122,9 +122,10 @@ class P2PControlRef:
 @torch.no_grad()
 def edit_loop(sd, cfg, context, x_T, controller, sched: DDIMRef, guidance_scale: float = 7.5,
               num_steps: Optional[int] = None, uncond_list: Optional[List[torch.Tensor]] = None,
-              trace: Optional[list] = None):
+              trace: Optional[list] = None, added_cond_kwargs=None):
     """`P2P.text2image_ldm_stable` hot loop + `diffusion_step`
-    (`/root/reference/p2p/model/sd_utils.py:58-79`; NTI context swap :133-138).
+    (`/root/reference/p2p/model/sd_utils.py:58-79`; NTI context swap :133-138; `P2P_XL`, :168-186, passes
+    `added_cond_kwargs` to every UNet call).
 
     context [2*Bp,77,C] = cat(uncond, cond); x_T [1,4,h,w] shared by all prompts (:13-21).
     Returns final latents [Bp,4,h,w].
@@ -139,7 +140,7 @@ def edit_loop(sd, cfg, context, x_T, controller, sched: DDIMRef, guidance_scale:
         ctx = context
         if uncond_list is not None:
             ctx = torch.cat([uncond_list[i].expand(bp, *context.shape[1:]), context[bp:]])
-        eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), t, ctx, hook=hook)
+        eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), t, ctx, hook=hook, added_cond_kwargs=added_cond_kwargs)
         e_u, e_c = eps.chunk(2)
         eps = e_u + guidance_scale * (e_c - e_u)
         lat = sched.step(eps, int(t), lat)

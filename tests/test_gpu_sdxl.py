@@ -71,3 +71,68 @@ def test_module_counts():
     from oracle.unet_ref import count_attention_layers
     assert weights.num_params(config.SDXL) == 2_567_463_684          # the published size of the SDXL base UNet
     assert count_attention_layers(config.SDXL) == 140                # 70 BasicTransformerBlocks
+
+
+# ------------------------------------------------------------------------------------------------ P2P on the XL family
+import os  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+
+import numpy as np  # noqa: E402
+from PIL import Image  # noqa: E402
+
+from ief_amd.pipeline import StableDiffusionXLPipeline  # noqa: E402
+from ief_amd.p2p.model.sd_utils import P2P_XL  # noqa: E402
+from ief_amd.p2p.model.attention_base import EmptyControl  # noqa: E402
+from ief_amd.p2p.model.attention_control import AttentionRefine  # noqa: E402
+from oracle import p2p_ref  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROMPTS = ["a green apple on a wooden table", "a red apple on a wooden table"]
+
+
+@pytest.fixture(scope="module")
+def xlpipe():
+    return StableDiffusionXLPipeline.from_pretrained("synthetic:smallxl", keep_state_dict=True)
+
+
+def test_p2p_xl_loop_vs_oracle(xlpipe):
+    """the captured-graph sampler with the additional embedding folded into its per-step time rows, against the oracle's
+    eager loop (Python controller on materialised maps) — plain CFG sampling and an AttentionRefine edit"""
+    cfg = xlpipe.cfg
+    steps = 4
+    size = cfg.sample_size * 8
+    editor = P2P_XL(xlpipe, steps)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(3))
+    unc, cond, added = editor._encode(xlpipe, PROMPTS, size, size)
+    assert unc.abs().max() == 0 and added["time_ids"].shape == (4, 6) and added["text_embeds"].shape == (4, cfg.pooled_text_dim)
+    ctx = torch.cat([unc, cond]).float().cpu()
+    added_cpu = {k: v.float().cpu() for k, v in added.items()}
+    sched = p2p_ref.DDIMRef(num_inference_steps=steps)
+    sd = xlpipe._state_dict
+    with torch.no_grad():
+        plain_ref = p2p_ref.edit_loop(sd, cfg, ctx, x_T, None, sched, 7.5, added_cond_kwargs=added_cpu)
+    got, _ = editor.text2image_ldm_stable(xlpipe, PROMPTS, EmptyControl(LOW_RESOURCE=False), num_inference_steps=steps, guidance_scale=7.5,
+                                          latent=x_T, return_latents=True)
+    e0 = rel_err(got, plain_ref)
+    ctrl = AttentionRefine(prompts=PROMPTS, tokenizer=xlpipe.tokenizer, num_steps=steps, cross_replace_steps=0.8,
+                           self_replace_steps=0.4, device=DEV)
+    edit, _ = editor.text2image_ldm_stable(xlpipe, PROMPTS, ctrl, num_inference_steps=steps, guidance_scale=7.5,
+                                           latent=x_T, return_latents=True)
+    ref_ctrl = p2p_ref.P2PControlRef(mode="refine", num_prompts=2, cross_alpha=ctrl.cross_replace_alpha.float().cpu(),
+                                     num_self_replace=ctrl.num_self_replace, mapper=ctrl.mapper.cpu(),
+                                     alphas=ctrl.alphas.float().cpu())
+    with torch.no_grad():
+        edit_ref = p2p_ref.edit_loop(sd, cfg, ctx, x_T, ref_ctrl, sched, 7.5, added_cond_kwargs=added_cpu)
+    e1, moved = rel_err(edit, edit_ref), rel_err(plain_ref, edit_ref)
+    print(f"P2P_XL {steps} steps: plain {e0:.2e}, AttentionRefine edit {e1:.2e}; the edit moves the latents by {moved:.2e}")
+    assert e0 < 5e-2 and e1 < 5e-2
+
+
+def test_p2p_xl_cli(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "image-editing-framework_amd", "p2p", "edit_syn.py"),
+                        "--sd_version", "smallxl"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    src = np.array(Image.open(tmp_path / "exp" / "source.png")).astype(int)
+    edit = np.array(Image.open(tmp_path / "exp" / "edit.png")).astype(int)
+    assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
