@@ -122,7 +122,16 @@ def main():
     if args.uncond == "per-step":
         g = torch.Generator().manual_seed(1234 + rank)
         uncond_list = [(u[:1].cpu() + 0.01 * torch.randn(1, *u.shape[1:], generator=g)).to(dev) for _ in range(MAX_STEPS)]
-    loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list)
+    # SDXL family: pooled text embedding + six time ids per UNet batch row (P2P_XL.encode_prompt_xl); constant over the
+    # steps, folded by the loop into its per-step time-embedding rows
+    global ADDED
+    ADDED = None
+    if cfg.addition_embed:
+        g = torch.Generator().manual_seed(4321 + rank)
+        size = float(hw * 8)
+        ADDED = {"text_embeds": (torch.randn(4, cfg.pooled_text_dim, generator=g) * 0.5).to(dev),
+                 "time_ids": torch.tensor([[size, size, 0.0, 0.0, size, size]] * 4, device=dev)}
+    loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=ADDED)
 
     def run_steps(n):
         """n steps, restarting the edit (controller + step counters) whenever 50 are used up"""
@@ -192,7 +201,9 @@ def main():
         dist.destroy_process_group()
 
 
-MODEL_NAMES = {"sd15": "SD1.5", "sd21": "SD2.1", "tiny": "tiny", "small": "small", "small21": "small21"}
+MODEL_NAMES = {"sd15": "SD1.5", "sd21": "SD2.1", "sdxl": "SDXL", "tiny": "tiny", "small": "small", "small21": "small21",
+               "smallxl": "smallxl"}
+ADDED = None
 
 
 def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_list=None, steps=40):
@@ -204,7 +215,7 @@ def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_lis
     for _ in range(E):
         c = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
         register_attention_control(pipe, c)
-        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list)
+        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=ADDED)
         lp.start(x_T)
         unregister_attention_control(pipe, None)
         loops.append(lp); ctrls.append(c)
@@ -300,7 +311,8 @@ def cpu_baseline(pipe, cfg, ctx, x_T, ctrl, budget_s):
     def step(i, lat):
         t = sched.timesteps[i]
         with torch.no_grad():
-            eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), t, c, hook=ref_ctrl)
+            eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), t, c, hook=ref_ctrl,
+                                        added_cond_kwargs=None if ADDED is None else {k: v.cpu() for k, v in ADDED.items()})
         e_u, e_c = eps.chunk(2)
         return sched.step(e_u + 7.5 * (e_c - e_u), int(t), lat)
 

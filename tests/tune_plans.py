@@ -25,10 +25,18 @@ hw = cfg.sample_size
 for B in (4, 2, 1):
     x = torch.randn(B, 4, hw, hw, device=dev)
     ctx = (torch.randn(B, 77, cfg.cross_attention_dim, device=dev) * 0.1)
+    added = None
+    if cfg.addition_embed:
+        added = {"text_embeds": torch.randn(B, cfg.pooled_text_dim, device=dev),
+                 "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0.0, 0.0, hw * 8.0, hw * 8.0]] * B, device=dev)}
     with torch.no_grad():
-        pipe.unet(x, 501, encoder_hidden_states=ctx)
+        pipe.unet(x, 501, encoder_hidden_states=ctx, added_cond_kwargs=added)
     torch.cuda.synchronize()
     print(f"B={B}: {len(hip._plan_table())} shapes tuned", flush=True)
+if cfg.addition_embed:          # the reverse pass is not built for the SDXL family yet: forward shapes only
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    hip.save_plans(out)
+    sys.exit(0)
 # null-text optimisation: the data-gradient GEMMs / convs of the reverse pass at batch 1 (grad.UNetAdjoint)
 from ief_amd.grad import UNetAdjoint
 adj = UNetAdjoint(pipe.unet)
