@@ -105,10 +105,11 @@ class UNetAdjoint:
                 self.wt_conv(s.conv.weight)
         for blk in list(u.down_blocks) + [u.mid_block] + list(u.up_blocks):
             for t in blk.attentions:
-                b = t.transformer_blocks[0]
-                for w in (t.proj_in.weight, t.proj_out.weight, b.attn1.w_qkv, b.attn1.to_out[0].weight, b.attn2.to_q.weight,
-                          b.attn2.to_out[0].weight, b.ff.net[0].proj.weight, b.ff.net[2].weight):
-                    self.wt_lin(w)
+                self.wt_lin(t.proj_in.weight), self.wt_lin(t.proj_out.weight)
+                for b in t.transformer_blocks:
+                    for w in (b.attn1.w_qkv, b.attn1.to_out[0].weight, b.attn2.to_q.weight, b.attn2.to_out[0].weight,
+                              b.ff.net[0].proj.weight, b.ff.net[2].weight):
+                        self.wt_lin(w)
         if self.mode == "input":
             self.wt_conv_in(u.conv_in.weight)
 
@@ -131,23 +132,26 @@ class UNetAdjoint:
     def _tr_fwd(self, t, x, kv_all):
         B, H, W, C = x.shape
         N = H * W
-        blk = t.transformer_blocks[0]
-        a1, a2, ff = blk.attn1, blk.attn2, blk.ff
         hn, st0 = t.norm(x, return_stats=True)
-        h0 = t.proj_in(hn).reshape(B, N, C)
-        qkv = hip.gemm(blk.norm1(h0), a1.w_qkv)
-        lse1 = torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device)
-        o1 = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], a1.heads, a1.scale, lse=lse1)
-        h1 = a1.to_out[0](o1, residual=h0)
-        q2 = hip.gemm(blk.norm2(h1), a2.to_q.weight)
-        off = a2._kv_off
-        lse2 = torch.empty(B, a2.heads, N, dtype=torch.float32, device=x.device)
-        o2 = hip.attn_flash(q2, kv_all[..., off:off + C], kv_all[..., off + C:off + 2 * C], a2.heads, a2.scale, lse=lse2)
-        h2 = a2.to_out[0](o2, residual=h1)
-        pre = hip.gemm(blk.norm3(h2), ff.net[0].proj.weight, bias=ff.net[0].proj.bias)
-        h3 = ff.net[2](hip.geglu_il(pre), residual=h2)
-        out = t.proj_out(h3.reshape(B, H, W, C), residual=x)
-        self.rec[id(t)] = (x, h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre, st0)
+        h = t.proj_in(hn).reshape(B, N, C)
+        recs = []
+        for blk in t.transformer_blocks:            # SDXL stacks several blocks between proj_in and proj_out
+            a1, a2, ff = blk.attn1, blk.attn2, blk.ff
+            h0 = h
+            qkv = hip.gemm(blk.norm1(h0), a1.w_qkv)
+            lse1 = torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device)
+            o1 = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], a1.heads, a1.scale, lse=lse1)
+            h1 = a1.to_out[0](o1, residual=h0)
+            q2 = hip.gemm(blk.norm2(h1), a2.to_q.weight)
+            off = a2._kv_off
+            lse2 = torch.empty(B, a2.heads, N, dtype=torch.float32, device=x.device)
+            o2 = hip.attn_flash(q2, kv_all[..., off:off + C], kv_all[..., off + C:off + 2 * C], a2.heads, a2.scale, lse=lse2)
+            h2 = a2.to_out[0](o2, residual=h1)
+            pre = hip.gemm(blk.norm3(h2), ff.net[0].proj.weight, bias=ff.net[0].proj.bias)
+            h = ff.net[2](hip.geglu_il(pre), residual=h2)
+            recs.append((h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre))
+        out = t.proj_out(h.reshape(B, H, W, C), residual=x)
+        self.rec[id(t)] = (x, st0, recs)
         return out
 
     def forward(self, sample, temb_row, ctx16):
@@ -196,13 +200,10 @@ class UNetAdjoint:
         res = hip.groupnorm_bwd(x, d_g1, n1.weight, n1.bias, n1.num_groups, n1.eps, silu=True, x2=skip, add=add, stats=st1)
         return res if skip is not None else (res, None)
 
-    def _tr_bwd(self, t, d_out, stop=False):
-        x, h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre, st0 = self.rec[id(t)]
-        B, H, W, C = x.shape
-        N = H * W
-        blk = t.transformer_blocks[0]
+    def _blk_bwd(self, blk, rec, d_h3, B, N, C, stop=False):
+        """one BasicTransformerBlock: gradient w.r.t. its output -> gradient w.r.t. its input (None when `stop`)"""
+        h0, qkv, o1, lse1, h1, q2, o2, lse2, h2, pre = rec
         a1, a2, ff = blk.attn1, blk.attn2, blk.ff
-        d_h3 = hip.gemm(d_out.reshape(B, N, C), self.wt_lin(t.proj_out.weight))
         d_gg = hip.gemm(d_h3, self.wt_lin(ff.net[2].weight))
         d_n3 = hip.gemm(hip.geglu_il_bwd(pre, d_gg), self.wt_lin(ff.net[0].proj.weight))
         d_h2 = hip.layernorm_bwd(h2, d_n3, blk.norm3.weight, blk.norm3.eps, add=d_h3)
@@ -228,8 +229,20 @@ class UNetAdjoint:
         dqkv = torch.empty_like(qkv)
         hip.attn_bwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], o1, d_o1, lse1, a1.heads, a1.scale,
                      dq=dqkv[..., :C], dk=dqkv[..., C:2 * C], dv=dqkv[..., 2 * C:])
-        d_h0 = hip.layernorm_bwd(h0, hip.gemm(dqkv, self.wt_lin(a1.w_qkv)), blk.norm1.weight, blk.norm1.eps, add=d_h1)
-        d_hn = hip.gemm(d_h0, self.wt_lin(t.proj_in.weight)).reshape(B, H, W, C)
+        return hip.layernorm_bwd(h0, hip.gemm(dqkv, self.wt_lin(a1.w_qkv)), blk.norm1.weight, blk.norm1.eps, add=d_h1)
+
+    def _tr_bwd(self, t, d_out, stop=False):
+        """stop (mode "context"): t is the first transformer of the forward; nothing upstream of its FIRST block's
+        cross-attention depends on the context, so the chain ends there"""
+        x, st0, recs = self.rec[id(t)]
+        B, H, W, C = x.shape
+        N = H * W
+        d_h = hip.gemm(d_out.reshape(B, N, C), self.wt_lin(t.proj_out.weight))
+        for k in reversed(range(len(t.transformer_blocks))):
+            d_h = self._blk_bwd(t.transformer_blocks[k], recs[k], d_h, B, N, C, stop=stop and k == 0)
+        if d_h is None:
+            return None
+        d_hn = hip.gemm(d_h, self.wt_lin(t.proj_in.weight)).reshape(B, H, W, C)
         n = t.norm
         return hip.groupnorm_bwd(x, d_hn, n.weight, n.bias, n.num_groups, n.eps, silu=False, add=d_out, stats=st0)
 

@@ -58,3 +58,35 @@ class ddim_inversion:
     def get_context(self, model, prompt):
         uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
         return torch.cat([uncond_embeddings, text_embeddings])
+
+
+class ddim_inversion_xl(ddim_inversion):
+    """`ddim_inversion_xl` (`/root/reference/pix2pix-zero/inversion/ddim.py:60-109`, same class in every method folder):
+    the inversion on an SDXL-family pipeline.  `get_context` returns the encoder's 4-tuple; the loop conditions on the
+    prompt embeddings and the prompt's `added_cond_kwargs` (pooled embedding + time ids of the image size; the reference
+    defaults to 1024x1024, here the latent's own size)."""
+
+    @torch.no_grad()
+    def ddim_inversion_loop(self, model, latent, prompt, cross_attention_kwargs=None, height=None, width=None):
+        context = self.get_context(model, prompt)
+        prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = context
+        height = height or latent.shape[-2] * model.vae_scale_factor
+        width = width or latent.shape[-1] * model.vae_scale_factor
+        device = model._execution_device
+        add_time_ids = model._get_add_time_ids((height, width), (0, 0), (height, width), dtype=prompt_embeds.dtype)
+        B = latent.shape[0]
+        added_cond_kwargs = {"text_embeds": pooled_prompt_embeds.to(device), "time_ids": add_time_ids.to(device).repeat(B, 1)}
+        unet = model.unet
+        if not (all(m.is_native() for m in unet.attention_modules()) and getattr(unet, "_plan", None) is None):
+            raise RuntimeError("ddim_inversion_xl: an attention hook is installed; invert before registering controllers")
+        loop = acquire(model, prompt_embeds.to(device), B, tuple(latent.shape[-2:]), None, mode="invert",
+                       added_cond_kwargs=added_cond_kwargs)
+        try:
+            _, all_latent = loop.run(latent, keep_all=True)
+        finally:
+            loop.release()
+        return all_latent, context
+
+    def get_context(self, model, prompt):
+        return model.encode_prompt(prompt=prompt, prompt_2=None, device=model.unet.device, num_images_per_prompt=1,
+                                   do_classifier_free_guidance=True, negative_prompt=None, negative_prompt_2=None)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero  # noqa: E402
+from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_XL  # noqa: E402
 
 parser = argparse.ArgumentParser("General config")
 parser.add_argument("--sd_version", type=str, default="1.5")
@@ -28,7 +28,8 @@ def main(argv=None):
     only_sample = False
     out_path = "./exp"
     pipe = load_pipe(args.sd_version, device)
-    editor = P2P_Zero(pipe, num_inference_steps)
+    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of edit_syn.py:80-87
+    editor = (P2P_Zero_XL if xl else P2P_Zero)(pipe, num_inference_steps)
     os.makedirs(out_path, exist_ok=True)
     image_source, image_edit = editor(prompt=[args.source_prompt] + [args.target_prompt],
                                       num_inference_steps=num_inference_steps, guidance_scale=GUIDANCE_SCALE,

@@ -1,5 +1,5 @@
 """`P2P_Zero` / `P2P_Zero_NTI` samplers — call signature of `/root/reference/pix2pix-zero/model/sd_utils.py:6-197,426-617`
-(SD1.x / 2.x family; the SDXL classes `P2P_Zero_XL*` belong to a shape family that is not built yet).
+(SD1.x / 2.x family) and `P2P_Zero_XL` (:212-423, SDXL family; `P2P_Zero_XL_NTI` needs the XL null-text optimiser, not built).
 
     editor = P2P_Zero(pipe, num_inference_steps)
     image_rec, image_edit = editor(prompt=source_prompt + target_prompt, num_inference_steps=50, guidance_scale=7.5,
@@ -34,14 +34,14 @@ class _Engine:
     """static buffers + the two captured loop bodies for one (latent size, step count, guidance_amount): built on first
     use and kept across images, since everything an image changes is a buffer the graphs READ"""
 
-    def __init__(self, model, h, w, nsteps, guidance_amount, use_graph):
+    def __init__(self, model, h, w, nsteps, guidance_amount, use_graph, temb_rows=1):
         unet = model.unet
         dev = unet.device
         C = unet.config.in_channels
         f32 = dict(dtype=torch.float32, device=dev)
         self.unet, self.use_graph, self.guidance_amount = unet, use_graph, float(guidance_amount)
         self.coef = torch.zeros(4, **f32)
-        self.temb = torch.zeros(1, unet.time_rows(torch.zeros(1, **f32)).shape[1], **f32)
+        self.temb = torch.zeros(temb_rows, unet._temb_width, **f32)    # one row, or one per batch row (SDXL's embedding)
         self.lat = torch.zeros(1, C, h, w, **f32)
         self.x_in = torch.zeros(2, C, h, w, **f32)
         self.zero_eps = torch.zeros(2, C, h, w, **f32)
@@ -135,35 +135,39 @@ class P2P_Zero:
             ts = ts[:num_steps]
         f32 = dict(dtype=torch.float32, device=dev)
         coef_table = torch.tensor([[*sched.step_coeffs(t), float(guidance_scale), 0.0] for t in ts], **f32)
-        temb_table = unet.time_rows(torch.tensor(ts, **f32)).contiguous()
+        ts_dev = torch.tensor(ts, **f32)
         null_rows = None
         if uncond_embeddings_list is not None:       # P2P_Zero_NTI: `prompt_embeds[0] = uncond_embeddings_list[i]` (:518,582)
             null_rows = [hip.to_f16(u.to(dev).float().contiguous())[0] for u in uncond_embeddings_list]
 
         def context_of(p):
-            with torch.no_grad():
-                u, c = _encode_prompts(model, [p])
-            return torch.cat([u, c]).to(dev).float()
+            """-> ([2,77,C] = (negative, prompt) embeddings, per-step time-embedding rows [steps, 1 or 2, width])"""
+            emb, added = self._encode(model, p, height, width)
+            aug = unet.aug_embedding(added)
+            rows = unet.time_rows(ts_dev, aug)
+            return emb.to(dev).float(), rows.reshape(len(ts), 1 if aug is None else 2, -1).contiguous()
 
         unet, self.original_processors = prep_unet(unet)
         saved_cache = [(m, m.cache_kv) for m in unet.attention_modules()]
         for m in unet.attention_modules():
             m.cache_kv = False          # the context buffer is rewritten in place (prompt switch, null-text rows)
             m._kv_key, m._kv = None, None
+        nb = 2 if unet.cfg.addition_embed else 1
         key = (h, w, len(ts), float(guidance_amount), bool(use_graph))
         try:
             E = self._engines.get(key)
             if E is None:
                 self._engines.clear()                       # one shape at a time: the map buffers are large
-                E = self._engines[key] = _Engine(model, h, w, len(ts), guidance_amount, use_graph)
+                E = self._engines[key] = _Engine(model, h, w, len(ts), guidance_amount, use_graph, temb_rows=nb)
 
             def set_step(i):
-                E.temb.copy_(temb_table[i:i + 1]), E.coef.copy_(coef_table[i])
+                E.temb.copy_(temb_table[i]), E.coef.copy_(coef_table[i])
                 if null_rows is not None:
                     E.ctx16[0].copy_(null_rows[i])
 
             # ---------------- reference pass: record the maps
-            hip.to_f16(context_of(prompt[0]).contiguous(), out=E.ctx16)
+            emb, temb_table = context_of(prompt[0])
+            hip.to_f16(emb.contiguous(), out=E.ctx16)
             for m, st in zip(E.cross, E.stage):
                 m.map_out = st
             with torch.no_grad():
@@ -180,7 +184,7 @@ class P2P_Zero:
                 return rec_latents if return_latents else self.latent2image(rec_latents)
 
             # ---------------- edit pass
-            emb = context_of(prompt[1])
+            emb, temb_table = context_of(prompt[1])
             if edit_dir is not None:            # `prompt_embeds_edit += edit_dir` (:145-146)
                 emb = emb + edit_dir.to(dev).float()
             hip.to_f16(emb.contiguous(), out=E.ctx16)
@@ -206,6 +210,12 @@ class P2P_Zero:
             return rec_latents, edit_latents
         return self.latent2image(rec_latents), self.latent2image(edit_latents)
 
+    def _encode(self, model, p, height, width):
+        """-> ([2,77,C] = (negative, prompt) embeddings, added_cond_kwargs or None)"""
+        with torch.no_grad():
+            u, c = _encode_prompts(model, [p])
+        return torch.cat([u, c]), None
+
     @torch.no_grad()
     def latent2image(self, latents, return_type="np"):
         latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
@@ -224,3 +234,29 @@ class P2P_Zero_NTI(P2P_Zero):
         if uncond_embeddings_list is None:
             raise ValueError("P2P_Zero_NTI: uncond_embeddings_list is required")
         return super().__call__(*args, uncond_embeddings_list=uncond_embeddings_list, **kw)
+
+
+class P2P_Zero_XL(P2P_Zero):
+    """`P2P_Zero_XL` (`/root/reference/pix2pix-zero/model/sd_utils.py:212-423`): the same two passes on an SDXL-family
+    pipeline.  Each prompt comes with its `added_cond_kwargs` (pooled embedding + six time ids, :388-423); they are
+    constant over the steps, so each pass reads them folded into its per-step time-embedding rows (one row per batch
+    row).  The transformers are several blocks deep there: the reverse pass walks every block (`grad.UNetAdjoint`) and
+    the objective has one term per cross-attention module, 70 of them on SDXL."""
+
+    def _encode(self, model, p, height, width):
+        return self.encode_prompt_xl(p, model._execution_device, True, height, width, 1)
+
+    def encode_prompt_xl(self, prompt, device, do_classifier_free_guidance, height, width, batch_size):
+        model = self.model
+        prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = model.encode_prompt(
+            prompt=prompt, prompt_2=None, device=device, num_images_per_prompt=1,
+            do_classifier_free_guidance=do_classifier_free_guidance, negative_prompt=None, negative_prompt_2=None)
+        original_size = target_size = (height, width)
+        add_time_ids = model._get_add_time_ids(original_size, (0, 0), target_size, dtype=prompt_embeds.dtype)
+        add_text_embeds = pooled
+        if do_classifier_free_guidance:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+            add_text_embeds = torch.cat([negative_pooled, pooled], dim=0)
+            add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
+        add_time_ids = add_time_ids.to(device).repeat(batch_size, 1)
+        return prompt_embeds.to(device), {"text_embeds": add_text_embeds.to(device).detach(), "time_ids": add_time_ids.detach()}

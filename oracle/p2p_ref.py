@@ -150,14 +150,15 @@ def edit_loop(sd, cfg, context, x_T, controller, sched: DDIMRef, guidance_scale:
 
 
 @torch.no_grad()
-def ddim_inversion_loop(sd, cfg, cond_emb, latent, sched: DDIMRef, num_steps: Optional[int] = None):
-    """`/root/reference/p2p/inversion/ddim.py:21-32`: cond-only UNet, ascending timesteps."""
+def ddim_inversion_loop(sd, cfg, cond_emb, latent, sched: DDIMRef, num_steps: Optional[int] = None, added_cond_kwargs=None):
+    """`/root/reference/p2p/inversion/ddim.py:21-32`: cond-only UNet, ascending timesteps (`ddim_inversion_xl`, :60-86:
+    the same with the prompt's `added_cond_kwargs`)."""
     all_lat = [latent]
     lat = latent.clone()
     n = sched.num_inference_steps if num_steps is None else num_steps
     for i in range(n):
         t = sched.timesteps[len(sched.timesteps) - i - 1]
-        eps = unet_ref.unet_forward(sd, cfg, lat, t, cond_emb)
+        eps = unet_ref.unet_forward(sd, cfg, lat, t, cond_emb, added_cond_kwargs=added_cond_kwargs)
         lat = sched.reverse(eps, int(t), lat)
         all_lat.append(lat)
     return all_lat

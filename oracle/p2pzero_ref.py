@@ -9,6 +9,7 @@ Restates `/root/reference/pix2pix-zero/model/sd_utils.py:6-197` (`P2P_Zero`, SD1
     `latents = x_in.chunk(2)[0]` (:180); CFG; DDIM step (:183-188).
   - `P2P_Zero_NTI` (:426-617): the same with row 0 of the context replaced by the null-text embedding of step i in
     both passes (:518,582).
+  - `P2P_Zero_XL` (:212-423): the same on the SDXL family; every UNet call takes the prompt's `added_cond_kwargs`.
 Parity unpinned: the reference module imports diffusers (not installed here), so no fixture could be generated from
 it; the rules above are read off its source.
 """
@@ -20,7 +21,7 @@ from . import unet_ref
 from .p2p_ref import DDIMRef
 
 
-def forward_with_maps(sd, cfg, x, t, ctx):
+def forward_with_maps(sd, cfg, x, t, ctx, added=None):
     """-> (eps, [cross-attention maps [B*heads, N, 77] in execution order]); differentiable"""
     maps: List[torch.Tensor] = []
 
@@ -29,7 +30,7 @@ def forward_with_maps(sd, cfg, x, t, ctx):
             maps.append(probs)
         return probs
 
-    eps = unet_ref.unet_forward(sd, cfg, x, t, ctx, hook=hook)
+    eps = unet_ref.unet_forward(sd, cfg, x, t, ctx, hook=hook, added_cond_kwargs=added)
     return eps, maps
 
 
@@ -40,17 +41,17 @@ def map_loss(maps, ref_maps):
     return loss
 
 
-def input_gradient(sd, cfg, x, t, ctx, ref_maps):
+def input_gradient(sd, cfg, x, t, ctx, ref_maps, added=None):
     """-> (loss, d loss / d x) of the cross-attention-map objective"""
     x_in = x.detach().clone().requires_grad_(True)
-    _, maps = forward_with_maps(sd, cfg, x_in, t, ctx)
+    _, maps = forward_with_maps(sd, cfg, x_in, t, ctx, added)
     loss = map_loss(maps, ref_maps)
     grad, = torch.autograd.grad(loss, x_in)
     return float(loss.detach()), grad
 
 
 def reference_pass(sd, cfg, ctx, x_T, sched: DDIMRef, guidance_scale: float, uncond_list: Optional[list] = None,
-                   num_steps: Optional[int] = None):
+                   num_steps: Optional[int] = None, added=None):
     """ctx [2,77,C] = (uncond, cond of the source prompt).  -> (x_0, maps[step][layer])"""
     lat = x_T.clone()
     ctx = ctx.clone()
@@ -60,7 +61,7 @@ def reference_pass(sd, cfg, ctx, x_T, sched: DDIMRef, guidance_scale: float, unc
         for i, t in enumerate(ts):
             if uncond_list is not None:
                 ctx[0] = uncond_list[i][0]
-            eps, maps = forward_with_maps(sd, cfg, torch.cat([lat] * 2), int(t), ctx)
+            eps, maps = forward_with_maps(sd, cfg, torch.cat([lat] * 2), int(t), ctx, added)
             all_maps.append([m.clone() for m in maps])
             eu, ec = eps.chunk(2)
             lat = sched.step(eu + guidance_scale * (ec - eu), int(t), lat)
@@ -68,7 +69,7 @@ def reference_pass(sd, cfg, ctx, x_T, sched: DDIMRef, guidance_scale: float, unc
 
 
 def edit_pass(sd, cfg, ctx_edit, x_T, all_maps, sched: DDIMRef, guidance_scale: float, guidance_amount: float = 0.1,
-              uncond_list: Optional[list] = None, num_steps: Optional[int] = None):
+              uncond_list: Optional[list] = None, num_steps: Optional[int] = None, added=None):
     lat = x_T.clone()
     ctx = ctx_edit.clone()
     losses = []
@@ -77,11 +78,11 @@ def edit_pass(sd, cfg, ctx_edit, x_T, all_maps, sched: DDIMRef, guidance_scale: 
         if uncond_list is not None:
             ctx[0] = uncond_list[i][0]
         x_in = torch.cat([lat] * 2)
-        loss, grad = input_gradient(sd, cfg, x_in, int(t), ctx, all_maps[i])
+        loss, grad = input_gradient(sd, cfg, x_in, int(t), ctx, all_maps[i], added)
         losses.append(loss)
         x_new = x_in - guidance_amount * grad
         with torch.no_grad():
-            eps = unet_ref.unet_forward(sd, cfg, x_new, int(t), ctx)
+            eps = unet_ref.unet_forward(sd, cfg, x_new, int(t), ctx, added_cond_kwargs=added)
             lat = x_new.chunk(2)[0]
             eu, ec = eps.chunk(2)
             lat = sched.step(eu + guidance_scale * (ec - eu), int(t), lat)
@@ -89,8 +90,10 @@ def edit_pass(sd, cfg, ctx_edit, x_T, all_maps, sched: DDIMRef, guidance_scale: 
 
 
 def p2pzero(sd, cfg, ctx_src, ctx_tgt, x_T, sched: DDIMRef, guidance_scale: float = 7.5, guidance_amount: float = 0.1,
-            uncond_list: Optional[list] = None, num_steps: Optional[int] = None):
-    """-> (reconstruction latent, edited latent, per-step losses)"""
-    rec, maps = reference_pass(sd, cfg, ctx_src, x_T, sched, guidance_scale, uncond_list, num_steps)
-    edit, losses = edit_pass(sd, cfg, ctx_tgt, x_T, maps, sched, guidance_scale, guidance_amount, uncond_list, num_steps)
+            uncond_list: Optional[list] = None, num_steps: Optional[int] = None, added_src=None, added_tgt=None):
+    """-> (reconstruction latent, edited latent, per-step losses).  added_src / added_tgt: `P2P_Zero_XL` — the
+    `added_cond_kwargs` of the source / target prompt (`sd_utils.py:256,317`)"""
+    rec, maps = reference_pass(sd, cfg, ctx_src, x_T, sched, guidance_scale, uncond_list, num_steps, added_src)
+    edit, losses = edit_pass(sd, cfg, ctx_tgt, x_T, maps, sched, guidance_scale, guidance_amount, uncond_list, num_steps,
+                             added_tgt)
     return rec, edit, losses

@@ -126,6 +126,8 @@ def test_p2p_xl_loop_vs_oracle(xlpipe):
         edit_ref = p2p_ref.edit_loop(sd, cfg, ctx, x_T, ref_ctrl, sched, 7.5, added_cond_kwargs=added_cpu)
     e1, moved = rel_err(edit, edit_ref), rel_err(plain_ref, edit_ref)
     print(f"P2P_XL {steps} steps: plain {e0:.2e}, AttentionRefine edit {e1:.2e}; the edit moves the latents by {moved:.2e}")
+    from ief_amd.p2p.model.register import unregister_attention_control
+    unregister_attention_control(xlpipe, None)       # the sampler leaves its controller registered, as the reference does
     assert e0 < 5e-2 and e1 < 5e-2
 
 
@@ -136,3 +138,116 @@ def test_p2p_xl_cli(tmp_path):
     src = np.array(Image.open(tmp_path / "exp" / "source.png")).astype(int)
     edit = np.array(Image.open(tmp_path / "exp" / "edit.png")).astype(int)
     assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
+
+
+# ------------------------------------------------------------------------------------------------ Pix2Pix-zero on the XL family
+from ief_amd.grad import UNetAdjoint  # noqa: E402
+from ief_amd.p2p.inversion.ddim import ddim_inversion_xl  # noqa: E402
+from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero_XL  # noqa: E402
+from oracle import p2pzero_ref  # noqa: E402
+
+
+def _exec_order(modules):
+    rank = lambda m: (0 if m.layer_name.startswith("down") else 1 if m.layer_name.startswith("mid") else 2)
+    return sorted(range(len(modules)), key=lambda i: (rank(modules[i]), i))
+
+
+def test_unet_input_gradient_smallxl(smallxl):
+    """the reverse pass through transformers several blocks deep, with per-batch-row time-embedding rows"""
+    cfg, unet = smallxl.cfg, smallxl.unet
+    B = 2
+    x, ctx, added = _inputs(cfg, B, seed=4)
+    ctx = ctx.half().float()
+    added_dev = {k: v.to(DEV) for k, v in added.items()}
+    unet(x.to(DEV), 401, encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=added_dev)
+    cross = [m for m in unet.attention_modules() if m.is_cross]
+    g = torch.Generator().manual_seed(5)
+    refs = [torch.softmax(torch.randn(B * m.heads, m.last_tokens, 77, generator=g) * 1.5, -1).half() for m in cross]
+    loss_ref, grad_ref = p2pzero_ref.input_gradient(smallxl._state_dict, cfg, x, 401, ctx,
+                                                    [refs[i].float() for i in _exec_order(cross)], added)
+    gs = 1024.0
+    adj = UNetAdjoint(unet, gs, mode="input")
+    adj.set_reference_maps([r.to(DEV) for r in refs])
+    temb = unet.time_rows(torch.tensor([401.0], device=DEV), unet.aug_embedding(added_dev))
+    assert temb.shape[0] == B
+    adj.forward(x.to(DEV), temb, ctx.half().to(DEV))
+    d_x = adj.backward(torch.zeros_like(x, device=DEV)) / gs
+    e, el = rel_err(d_x, grad_ref), abs(adj.loss_parts.sum().item() - loss_ref) / loss_ref
+    print(f"smallxl B={B}: d objective / d latent {e:.2e} (max |grad| {grad_ref.abs().max():.3e}); objective {el:.2e}; "
+          f"{len(cross)} cross-attention modules")
+    assert e < 5e-2 and el < 1e-2
+
+
+def test_context_gradient_smallxl(smallxl):
+    """mode "context" (null-text inversion's gradient) through the deeper transformers: the chain must stop at the first
+    block of the first transformer and still collect every module's dK / dV"""
+    cfg, unet = smallxl.cfg, smallxl.unet
+    x, ctx, added = _inputs(cfg, 1, seed=6)
+    ctx16 = ctx.half()
+    added_dev = {k: v.to(DEV) for k, v in added.items()}
+    g = torch.Generator().manual_seed(7)
+    d_eps = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=g)
+    cf = ctx16.float().requires_grad_(True)
+    ref = unet_ref.unet_forward(smallxl._state_dict, cfg, x, 401, cf, added_cond_kwargs=added)
+    (ref * d_eps).sum().backward()
+    adj = UNetAdjoint(unet, 1.0)
+    temb = unet.time_rows(torch.tensor([401.0], device=DEV), unet.aug_embedding(added_dev))
+    eps = adj.forward(x.to(DEV), temb, ctx16.to(DEV))
+    got = adj.backward(d_eps.to(DEV))
+    e_f, e_g = rel_err(eps, ref.detach()), rel_err(got, cf.grad)
+    print(f"smallxl: forward(tape) {e_f:.2e}; d/d ctx {e_g:.2e}")
+    assert e_f < 2e-2 and e_g < 5e-2
+
+
+def test_ddim_inversion_xl_vs_oracle(xlpipe):
+    cfg = xlpipe.cfg
+    steps = 4
+    xlpipe.scheduler.set_timesteps(steps)
+    x0 = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(8))
+    inv = ddim_inversion_xl()
+    lats, context = inv.ddim_inversion_loop(xlpipe, x0.to(DEV), PROMPTS[:1])
+    emb, _, pooled, _ = context
+    size = float(cfg.sample_size * 8)
+    added = {"text_embeds": pooled.float().cpu(), "time_ids": torch.tensor([[size, size, 0.0, 0.0, size, size]])}
+    with torch.no_grad():
+        ref = p2p_ref.ddim_inversion_loop(xlpipe._state_dict, cfg, emb.float().cpu(), x0, p2p_ref.DDIMRef(steps),
+                                          added_cond_kwargs=added)
+    e = max(rel_err(a, b) for a, b in zip(lats, ref))
+    print(f"ddim_inversion_xl {steps} steps: worst latent {e:.2e}")
+    assert len(lats) == steps + 1 and e < 2e-2
+
+
+def test_p2pzero_xl_two_pass_vs_oracle(xlpipe):
+    cfg = xlpipe.cfg
+    steps, run_steps, gscale, amount = 10, 3, 7.5, 0.1
+    size = cfg.sample_size * 8
+    sched = p2p_ref.DDIMRef(num_inference_steps=steps)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(9))
+    editor = P2P_Zero_XL(xlpipe, steps)
+    (e_s, a_s), (e_t, a_t) = (editor._encode(xlpipe, p, size, size) for p in PROMPTS)
+    cpu = lambda d: {k: v.float().cpu() for k, v in d.items()}
+    rec_ref, edit_ref, losses_ref = p2pzero_ref.p2pzero(xlpipe._state_dict, cfg, e_s.float().cpu(), e_t.float().cpu(), x_T, sched,
+                                                        gscale, amount, num_steps=run_steps, added_src=cpu(a_s),
+                                                        added_tgt=cpu(a_t))
+    rec, edit = editor(prompt=PROMPTS, num_inference_steps=steps, guidance_scale=gscale, guidance_amount=amount, latents=x_T,
+                       return_latents=True, num_steps=run_steps)
+    e_rec, e_edit = rel_err(rec, rec_ref), rel_err(edit, edit_ref)
+    e_loss = max(abs(a - b) / b for a, b in zip(editor.last_losses, losses_ref))
+    print(f"P2P_Zero_XL {run_steps} steps: reconstruction {e_rec:.2e}, edit {e_edit:.2e}, objective {e_loss:.2e} ({losses_ref})")
+    assert e_rec < 5e-2 and e_edit < 5e-2 and e_loss < 2e-2
+
+
+def test_p2pzero_xl_clis(tmp_path):
+    folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
+    r = subprocess.run([sys.executable, os.path.join(folder, "edit_syn.py"), "--sd_version", "smallxl"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rng = np.random.RandomState(0)
+    img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "test.jpg")
+    r = subprocess.run([sys.executable, os.path.join(folder, "edit_real.py"), "--sd_version", "smallxl", "--inversion_type",
+                        "ddim", "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for name in ("source.png", "inversion.png", "edit.png"):
+        assert (tmp_path / "exp" / name).exists()
