@@ -31,7 +31,11 @@ def main(argv=None):
     out_path = "./exp"
     pipe = load_pipe(args.sd_version, device)
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor
-    editor = MasaCtrl(pipe, num_inference_steps)
+    if pipe.__class__.__name__ == "StableDiffusionXLPipeline":          # dispatch of edit_syn.py:87-98
+        from ief_amd.masactrl.model.sd_utils import MasaCtrl_XL
+        model_type, LAYPER, editor = "SDXL", 54, MasaCtrl_XL(pipe, num_inference_steps)
+    else:
+        model_type, editor = "SD", MasaCtrl(pipe, num_inference_steps)
     os.makedirs(out_path, exist_ok=True)
     controller = AttentionBase()
     regiter_attention_editor_diffusers(editor.model, controller)
@@ -39,7 +43,7 @@ def main(argv=None):
                                 num_inference_steps=num_inference_steps, height=size, width=size)
     save_img(image, os.path.join(out_path, "source.png"))
     init_latent = torch.cat([init_latent, init_latent])
-    controller = MutualSelfAttentionControl(STEP, LAYPER, model_type="SD")
+    controller = MutualSelfAttentionControl(STEP, LAYPER, model_type=model_type)
     regiter_attention_editor_diffusers(editor.model, controller)
     image_masactrl, _ = editor(prompt=[args.source_prompt, args.target_prompt], latents=init_latent,
                                guidance_scale=GUIDANCE_SCALE, num_inference_steps=num_inference_steps, height=size,

@@ -4,9 +4,12 @@ import numpy as np
 import torch
 
 from ...denoise import acquire
+from ...p2p.model.sd_utils import encode_prompt_xl
 
 
 class MasaCtrl:
+    xl = False
+
     def __init__(self, pipeline, num_inference_steps) -> None:
         self.model = pipeline
         self.model.scheduler.set_timesteps(num_inference_steps)
@@ -55,8 +58,12 @@ class MasaCtrl:
             g = guidance_scale
         else:
             context, g = text_embeddings, None
+        added_cond_kwargs = None
+        if self.xl:       # `MasaCtrl_XL.__call__` (:148-149): both text encoders + the pooled / time-id conditioning
+            context, added_cond_kwargs = encode_prompt_xl(model, prompt, dev, guidance_scale > 1.0, height, width, batch_size)
         model.scheduler.set_timesteps(num_inference_steps)
-        loop = acquire(model, context, batch_size, (height // 8, width // 8), g, uncond_list=uncond_list)
+        loop = acquire(model, context, batch_size, (height // 8, width // 8), g, uncond_list=uncond_list,
+                       added_cond_kwargs=added_cond_kwargs)
         try:
             latents = loop.run(latents)
         finally:
@@ -64,6 +71,19 @@ class MasaCtrl:
         if return_latents:
             return latents, init_latent
         return self.latent2image(latents, return_type="np"), init_latent
+
+
+class MasaCtrl_XL(MasaCtrl):
+    """`MasaCtrl_XL` (`/root/reference/masactrl/model/sd_utils.py:127-226`): the same sampler on an SDXL-family pipeline
+    (the reference defaults height = width = 1024; pass the pipeline's own size for the small test family)."""
+    xl = True
+
+    def __call__(self, prompt, batch_size=1, height=None, width=None, **kw):
+        size = self.model.unet.config.sample_size * self.model.vae_scale_factor
+        return super().__call__(prompt, batch_size=batch_size, height=height or size, width=width or size, **kw)
+
+    def encode_prompt_xl(self, prompt, device, do_classifier_free_guidance, height, width, batch_size):
+        return encode_prompt_xl(self.model, prompt, device, do_classifier_free_guidance, height, width, batch_size)
 
 
 class MasaCtrl_NTI(MasaCtrl):

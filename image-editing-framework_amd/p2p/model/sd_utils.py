@@ -39,6 +39,24 @@ def _encode_prompts(model, prompt: List[str]):
     return uncond_embeddings, text_embeddings
 
 
+def encode_prompt_xl(model, prompt, device, do_classifier_free_guidance, height, width, batch_size):
+    """The `encode_prompt_xl` every `*_XL` sampler of the reference carries (`p2p/model/sd_utils.py:186-224`,
+    `masactrl/model/sd_utils.py:191-226`, `pix2pix-zero/model/sd_utils.py:388-423`): -> (prompt_embeds [2B,77,C] =
+    (negative, prompt), added_cond_kwargs = {"text_embeds" [2B, pooled], "time_ids" [2B, 6]})."""
+    prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = model.encode_prompt(
+        prompt=prompt, prompt_2=None, device=device, num_images_per_prompt=1,
+        do_classifier_free_guidance=do_classifier_free_guidance, negative_prompt=None, negative_prompt_2=None)
+    original_size = target_size = (height, width)
+    add_time_ids = model._get_add_time_ids(original_size, (0, 0), target_size, dtype=prompt_embeds.dtype)
+    add_text_embeds = pooled
+    if do_classifier_free_guidance:
+        prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        add_text_embeds = torch.cat([negative_pooled, pooled], dim=0)
+        add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
+    add_time_ids = add_time_ids.to(device).repeat(batch_size, 1)
+    return prompt_embeds.to(device), {"text_embeds": add_text_embeds.to(device), "time_ids": add_time_ids}
+
+
 def _fusable(model, controller, low_resource) -> bool:
     if low_resource:
         return False
@@ -171,26 +189,11 @@ class P2P_XL(P2P):
     reads it folded into its per-step time-embedding rows (`denoise.FusedDenoiser`)."""
 
     def _encode(self, model, prompt, height, width):
-        return self.encode_prompt_xl(model, prompt, model._execution_device, True, height, width, len(prompt), split=True)
+        emb, added = self.encode_prompt_xl(model, prompt, model._execution_device, True, height, width, len(prompt))
+        return emb[:len(prompt)], emb[len(prompt):], added
 
-    def encode_prompt_xl(self, model, prompt, device, do_classifier_free_guidance, height, width, batch_size, split=False):
-        """(:186-224) -> (prompt_embeds [2B,77,C], added_cond_kwargs); split=True -> (uncond, cond, added_cond_kwargs)"""
-        prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = model.encode_prompt(
-            prompt=prompt, prompt_2=None, device=device, num_images_per_prompt=1,
-            do_classifier_free_guidance=do_classifier_free_guidance, negative_prompt=None, negative_prompt_2=None)
-        original_size = target_size = (height, width)
-        add_time_ids = model._get_add_time_ids(original_size, (0, 0), target_size, dtype=prompt_embeds.dtype)
-        add_text_embeds = pooled
-        if do_classifier_free_guidance:
-            add_text_embeds = torch.cat([negative_pooled, pooled], dim=0)
-            add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
-        add_time_ids = add_time_ids.to(device).repeat(batch_size, 1)
-        added_cond_kwargs = {"text_embeds": add_text_embeds.to(device), "time_ids": add_time_ids}
-        if split:
-            return negative_prompt_embeds.to(device), prompt_embeds.to(device), added_cond_kwargs
-        if do_classifier_free_guidance:
-            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
-        return prompt_embeds.to(device), added_cond_kwargs
+    def encode_prompt_xl(self, model, prompt, device, do_classifier_free_guidance, height, width, batch_size):
+        return encode_prompt_xl(model, prompt, device, do_classifier_free_guidance, height, width, batch_size)
 
 
 class P2P_NTI(P2P):

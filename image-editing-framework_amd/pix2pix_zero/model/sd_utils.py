@@ -24,7 +24,7 @@ import torch
 
 from ... import hip
 from ...grad import UNetAdjoint
-from ...p2p.model.sd_utils import _encode_prompts
+from ...p2p.model.sd_utils import _encode_prompts, encode_prompt_xl
 from .attention_control import prep_unet, restore_original_processors
 
 GRAD_SCALE = 1024.0     # the fp16 gradients of the map objective are carried times this (undone in the SGD step)
@@ -247,16 +247,4 @@ class P2P_Zero_XL(P2P_Zero):
         return self.encode_prompt_xl(p, model._execution_device, True, height, width, 1)
 
     def encode_prompt_xl(self, prompt, device, do_classifier_free_guidance, height, width, batch_size):
-        model = self.model
-        prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = model.encode_prompt(
-            prompt=prompt, prompt_2=None, device=device, num_images_per_prompt=1,
-            do_classifier_free_guidance=do_classifier_free_guidance, negative_prompt=None, negative_prompt_2=None)
-        original_size = target_size = (height, width)
-        add_time_ids = model._get_add_time_ids(original_size, (0, 0), target_size, dtype=prompt_embeds.dtype)
-        add_text_embeds = pooled
-        if do_classifier_free_guidance:
-            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
-            add_text_embeds = torch.cat([negative_pooled, pooled], dim=0)
-            add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
-        add_time_ids = add_time_ids.to(device).repeat(batch_size, 1)
-        return prompt_embeds.to(device), {"text_embeds": add_text_embeds.to(device).detach(), "time_ids": add_time_ids.detach()}
+        return encode_prompt_xl(self.model, prompt, device, do_classifier_free_guidance, height, width, batch_size)
