@@ -89,3 +89,8 @@ class MasaCtrl_XL(MasaCtrl):
 class MasaCtrl_NTI(MasaCtrl):
     """`MasaCtrl_NTI` of the reference (`masactrl/model/sd_utils.py:229-`): the sampler with per-step unconditional
     embeddings from null-text inversion; `MasaCtrl.__call__` already takes `uncond_embeddings_list`."""
+
+
+class MasaCtrl_XL_NTI(MasaCtrl_XL):
+    """`MasaCtrl_XL_NTI` (`/root/reference/masactrl/model/sd_utils.py:316-`): `MasaCtrl_XL` with per-step unconditional
+    embeddings from `NTI_XL`; `MasaCtrl.__call__` already takes `uncond_embeddings_list`."""

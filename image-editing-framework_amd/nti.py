@@ -22,7 +22,10 @@ from .grad import UNetAdjoint
 
 class NullTextOptimizer:
     def __init__(self, model, cond: torch.Tensor, guidance_scale: float, latent_hw, grad_scale: float = 1.0,
-                 use_graph: bool = True):
+                 use_graph: bool = True, added_cond=None, added_uncond=None, lr: float = 1e-2, restart: bool = False):
+        """added_cond / added_uncond, lr, restart: `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`) — the
+        conditional and unconditional UNet calls take their own SDXL `added_cond_kwargs` (folded into two tables of
+        per-step time-embedding rows), lr = 5e-2, and the embedding restarts from its initial value every timestep."""
         self.model, self.unet, self.sched = model, model.unet, model.scheduler
         dev = self.unet.device
         self.dev = dev
@@ -43,8 +46,15 @@ class NullTextOptimizer:
         g = float(guidance_scale)
         self.coef_table = torch.tensor([[*self.sched.step_coeffs(t), g, 0.0] for t in ts], **f32)
         self.coef = torch.zeros(4, **f32)
-        self.temb_table = self.unet.time_rows(torch.tensor(ts, **f32)).contiguous()
+        tsd = torch.tensor(ts, **f32)
+        self.temb_table = self.unet.time_rows(tsd, self.unet.aug_embedding(added_uncond)).contiguous()     # uncond calls
         self.temb = torch.zeros(1, self.temb_table.shape[1], **f32)
+        if added_cond is not None:
+            self.temb_table_c = self.unet.time_rows(tsd, self.unet.aug_embedding(added_cond)).contiguous()
+            self.temb_c = torch.zeros_like(self.temb)
+        else:
+            self.temb_table_c, self.temb_c = self.temb_table, self.temb
+        self.lr, self.restart = float(lr), bool(restart)
         self.cond16 = hip.to_f16(cond.to(dev).float().contiguous())
         L, Cc = self.cond16.shape[1:]
         self.param = torch.zeros(1, L, Cc, **f32)
@@ -58,7 +68,7 @@ class NullTextOptimizer:
 
     # ------------------------------------------------------------------ the three stream-ordered bodies
     def _body_cond(self):
-        eps = self.unet(self.lat, encoder_hidden_states=self.cond16, temb_row=self.temb)["sample"]
+        eps = self.unet(self.lat, encoder_hidden_states=self.cond16, temb_row=self.temb_c)["sample"]
         self.eps_c.copy_(eps)
 
     def _body_inner(self):
@@ -104,6 +114,7 @@ class NullTextOptimizer:
         self._latents = latents
         self.lat.copy_(latents[-1].to(dev).float())
         self.param.copy_(uncond.to(dev).float()[:1])
+        self._param0 = self.param.clone()
         hip.to_f16(self.param, out=self.p16)
         if self.use_graph and self._graphs is None:
             self._capture()
@@ -116,10 +127,15 @@ class NullTextOptimizer:
     def outer_begin(self, i: int):
         latents = self._latents
         self.temb.copy_(self.temb_table[i:i + 1])
+        if self.temb_c is not self.temb:
+            self.temb_c.copy_(self.temb_table_c[i:i + 1])
+        if self.restart:
+            self.param.copy_(self._param0)
+            hip.to_f16(self.param, out=self.p16)
         self.coef.copy_(self.coef_table[i])
         self.target.copy_(latents[len(latents) - i - 2].to(self.dev).float())
         self.m.zero_(), self.v.zero_(), self.adam_step.zero_()          # `Adam([uncond], lr=...)` anew (nti.py:17)
-        self.hyper[0:1].fill_(1e-2 * (1.0 - i / 100.0))
+        self.hyper[0:1].fill_(self.lr * (1.0 - i / 100.0))
         self._run(0)
         self._done, self._loss = 0, float("nan")
 

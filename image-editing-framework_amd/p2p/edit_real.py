@@ -11,11 +11,11 @@ from PIL import Image
 
 from _bootstrap import load_pipe, seed_everything
 
-from ief_amd.p2p.inversion.ddim import ddim_inversion
-from ief_amd.p2p.inversion.nti import NTI
+from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL
 from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace
 from ief_amd.p2p.model.register import unregister_attention_control
-from ief_amd.p2p.model.sd_utils import P2P, P2P_NTI
+from ief_amd.p2p.model.sd_utils import P2P, P2P_NTI, P2P_XL, P2P_XL_NTI
 from ief_amd.p2p.utils.save_image import save_img
 
 parser = argparse.ArgumentParser("General config")
@@ -70,10 +70,13 @@ def main(argv=None):
     out_path = "./exp"
     edit_type = "refine"  # ["refine", "replace"]
     pipe = load_pipe(args.sd_version, device)
+    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of edit_real.py:97-115
     if args.inversion_type == "ddim":
-        editor, invertor = P2P(model=pipe, num_inference_steps=50), ddim_inversion()
+        editor = (P2P_XL if xl else P2P)(model=pipe, num_inference_steps=50)
+        invertor = ddim_inversion_xl() if xl else ddim_inversion()
     elif args.inversion_type == "null-text":
-        editor, invertor = P2P_NTI(model=pipe, num_inference_steps=50), NTI()
+        editor = (P2P_XL_NTI if xl else P2P_NTI)(model=pipe, num_inference_steps=50)
+        invertor = NTI_XL() if xl else NTI()
     else:
         raise ValueError("Please choose right inversion type")
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor

@@ -199,3 +199,8 @@ class P2P_XL(P2P):
 class P2P_NTI(P2P):
     """`text2image_ldm_stable(..., uncond_embeddings_list=[50 x [1,77,C]])` (:92-140): the base class
     already takes the per-step null-text embeddings, selected per step on the device."""
+
+
+class P2P_XL_NTI(P2P_XL):
+    """`P2P_XL_NTI` (`/root/reference/p2p/model/sd_utils.py:226-`): `P2P_XL` with the per-step null-text embeddings of
+    `NTI_XL` on the unconditional rows; the base sampler already takes `uncond_embeddings_list`."""

@@ -13,9 +13,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI, P2P_Zero_XL  # noqa: E402
+from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI, P2P_Zero_XL, P2P_Zero_XL_NTI  # noqa: E402
 
 parser = argparse.ArgumentParser("General config")
 parser.add_argument("--sd_version", type=str, default="1.5")
@@ -40,10 +40,10 @@ def main(argv=None):
     pipe = load_pipe(args.sd_version, device)
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor
     xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of edit_real.py:95-112
-    if xl and args.inversion_type != "ddim":
-        raise NotImplementedError("pix2pix-zero on the SDXL family: only --inversion_type ddim (NTI_XL is not built)")
-    if xl:
+    if xl and args.inversion_type == "ddim":
         invertor, editor = ddim_inversion_xl(), P2P_Zero_XL(pipe, num_inference_steps)
+    elif xl:
+        invertor, editor = NTI_XL(), P2P_Zero_XL_NTI(pipe, num_inference_steps)
     elif args.inversion_type == "ddim":
         invertor, editor = ddim_inversion(), P2P_Zero(pipe, num_inference_steps)
     else:

@@ -1,5 +1,5 @@
 """`P2P_Zero` / `P2P_Zero_NTI` samplers — call signature of `/root/reference/pix2pix-zero/model/sd_utils.py:6-197,426-617`
-(SD1.x / 2.x family) and `P2P_Zero_XL` (:212-423, SDXL family; `P2P_Zero_XL_NTI` needs the XL null-text optimiser, not built).
+(SD1.x / 2.x family), `P2P_Zero_XL` (:212-423) and `P2P_Zero_XL_NTI` (:619-784) on the SDXL family.
 
     editor = P2P_Zero(pipe, num_inference_steps)
     image_rec, image_edit = editor(prompt=source_prompt + target_prompt, num_inference_steps=50, guidance_scale=7.5,
@@ -248,3 +248,13 @@ class P2P_Zero_XL(P2P_Zero):
 
     def encode_prompt_xl(self, prompt, device, do_classifier_free_guidance, height, width, batch_size):
         return encode_prompt_xl(self.model, prompt, device, do_classifier_free_guidance, height, width, batch_size)
+
+
+class P2P_Zero_XL_NTI(P2P_Zero_XL):
+    """`P2P_Zero_XL_NTI` (`/root/reference/pix2pix-zero/model/sd_utils.py:619-784`): `P2P_Zero_XL` with row 0 of the context
+    replaced per step by the null-text embedding of `NTI_XL` (:696,749)."""
+
+    def __call__(self, *args, uncond_embeddings_list=None, **kw):
+        if uncond_embeddings_list is None:
+            raise ValueError("P2P_Zero_XL_NTI: uncond_embeddings_list is required")
+        return super().__call__(*args, uncond_embeddings_list=uncond_embeddings_list, **kw)

@@ -21,9 +21,9 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI, P2P_Zero_XL  # noqa: E402
+from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI, P2P_Zero_XL, P2P_Zero_XL_NTI  # noqa: E402
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
 
@@ -53,10 +53,9 @@ def main(argv=None):
     num_inner_steps, early_stop_epsilon = 10, 1e-5
     nti = args.inversion_type == "null-text"
     xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of test.py:84-103
-    if xl and nti:
-        raise NotImplementedError("pix2pix-zero on the SDXL family: only --inversion_type ddim (NTI_XL is not built)")
     if xl:          # BASELINE.json config 5: SDXL, 1024x1024
-        invertor, editor = ddim_inversion_xl(), P2P_Zero_XL(pipe, num_inference_steps)
+        invertor = NTI_XL() if nti else ddim_inversion_xl()
+        editor = (P2P_Zero_XL_NTI if nti else P2P_Zero_XL)(pipe, num_inference_steps)
     else:
         invertor = NTI() if nti else ddim_inversion()
         editor = (P2P_Zero_NTI if nti else P2P_Zero)(pipe, num_inference_steps)
@@ -81,7 +80,10 @@ def main(argv=None):
             extra = {}
             if nti:
                 lat_j = [l[j:j + 1].clone() for l in latents]
-                ctx_j = torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]])
+                if xl:      # the encoder's 4-tuple, one row per image
+                    ctx_j = tuple(c[j:j + 1] for c in context)
+                else:
+                    ctx_j = torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]])
                 extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, lat_j, ctx_j, num_inner_steps,
                                                                              early_stop_epsilon, guidance_scale)
             image_source, image_edit = editor(prompt=[source_prompt] + [target_prompt],

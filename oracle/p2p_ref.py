@@ -166,25 +166,33 @@ def ddim_inversion_loop(sd, cfg, cond_emb, latent, sched: DDIMRef, num_steps: Op
 
 def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps: int = 10,
                       epsilon: float = 1e-5, guidance_scale: float = 7.5,
-                      num_outer: Optional[int] = None):
-    """`/root/reference/p2p/inversion/nti.py:9-45` with the oracle UNet as `model.unet`."""
+                      num_outer: Optional[int] = None, added_cond=None, added_uncond=None, lr: float = 1e-2,
+                      restart: bool = False):
+    """`/root/reference/p2p/inversion/nti.py:9-45` with the oracle UNet as `model.unet`.
+    `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`) is the same loop with lr = 5e-2 (:69), the embedding
+    RESTARTED from the negative prompt embedding at every timestep (:67, `restart`), and the conditional / unconditional
+    UNet calls taking their own `added_cond_kwargs` (:58-61,74,76,90-92)."""
     from torch.optim.adam import Adam
     import torch.nn.functional as F
 
     uncond, cond = context.chunk(2)
+    uncond0 = uncond.clone()
+    both = None
+    if added_cond is not None:
+        both = {k: torch.cat([added_uncond[k], added_cond[k]]) for k in added_cond}
     out = []
     cur = latents[-1]
     n = sched.num_inference_steps if num_outer is None else num_outer
     for i in range(n):
-        uncond = uncond.clone().detach()
+        uncond = (uncond0 if restart else uncond).clone().detach()
         uncond.requires_grad = True
-        opt = Adam([uncond], lr=1e-2 * (1.0 - i / 100.0))
+        opt = Adam([uncond], lr=lr * (1.0 - i / 100.0))
         prev = latents[len(latents) - i - 2]
         t = sched.timesteps[i]
         with torch.no_grad():
-            e_c = unet_ref.unet_forward(sd, cfg, cur, t, cond)
+            e_c = unet_ref.unet_forward(sd, cfg, cur, t, cond, added_cond_kwargs=added_cond)
         for j in range(num_inner_steps):
-            e_u = unet_ref.unet_forward(sd, cfg, cur, t, uncond)
+            e_u = unet_ref.unet_forward(sd, cfg, cur, t, uncond, added_cond_kwargs=added_uncond)
             eps = e_u + guidance_scale * (e_c - e_u)
             rec = sched.step(eps, int(t), cur)
             loss = F.mse_loss(rec, prev)
@@ -195,7 +203,7 @@ def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps
                 break
         out.append(uncond[:1].detach())
         with torch.no_grad():
-            eps = unet_ref.unet_forward(sd, cfg, torch.cat([cur] * 2), t, torch.cat([uncond, cond]))
+            eps = unet_ref.unet_forward(sd, cfg, torch.cat([cur] * 2), t, torch.cat([uncond, cond]), added_cond_kwargs=both)
             e_u, e_c2 = eps.chunk(2)
             cur = sched.step(e_u + guidance_scale * (e_c2 - e_u), int(t), cur)
     return out
