@@ -103,18 +103,33 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
     encoders whose hidden states are concatenated into the 2048-wide context, the second one's pooled output, and
     `_get_add_time_ids`.  With synthetic weights both encoders are seeded stand-ins (off the per-step path)."""
 
-    def __init__(self, unet, tokenizer, text_encoder, vae, scheduler, cfg, state_dict=None, text_encoder_2=None):
+    def __init__(self, unet, tokenizer, text_encoder, vae, scheduler, cfg, state_dict=None, text_encoder_2=None,
+                 tokenizer_2=None):
         super().__init__(unet, tokenizer, text_encoder, vae, scheduler, cfg, state_dict)
-        self.tokenizer_2, self.text_encoder_2 = tokenizer, text_encoder_2
+        self.tokenizer_2, self.text_encoder_2 = tokenizer_2 or tokenizer, text_encoder_2
 
     @classmethod
     def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
                         keep_state_dict: bool = False, **unused):
         from .unet import UNet2DConditionModel
+        import dataclasses
+        sched = scheduler if scheduler is not None else DDIMScheduler()
+        if os.path.isdir(model_key):
+            # a local diffusers-layout SDXL directory: unet/ and vae/ are required; text_encoder/ and text_encoder_2/ (CLIP
+            # weights for `transformers`) and tokenizer/ are used when present, seeded stand-ins otherwise
+            cfg, sd = _load_local_unet(model_key)
+            if not cfg.addition_embed:
+                raise ValueError(f"{model_key}: unet/config.json is not an SDXL-family configuration")
+            vae = _load_local_vae(model_key, device)
+            tokenizer, tokenizer_2, enc1, enc2 = _load_local_text_xl(model_key, cfg)
+            unet = UNet2DConditionModel(cfg, sd, device=device)
+            return cls(unet, tokenizer, enc1.to(device), vae, sched, cfg, sd if keep_state_dict else None,
+                       text_encoder_2=enc2.to(device), tokenizer_2=tokenizer_2)
         if not model_key.startswith("synthetic:"):
             raise FileNotFoundError(
-                f"'{model_key}': no SDXL checkpoint exists offline and the local-directory loader for the two CLIP text "
-                "encoders is not written; use 'synthetic:sdxl' (seeded weights of the public architecture)")
+                f"'{model_key}' is neither 'synthetic:<cfg>' nor a local directory.  Hub names cannot be fetched offline: "
+                "point sd_mapping.sd_maps['xl-base'] (or IEF_SDXL_DIR) at a local diffusers-layout directory, or use "
+                "'synthetic:sdxl' (seeded weights of the public architecture)")
         parts = model_key.split(":")
         cfg = CONFIGS[parts[1]]
         if not cfg.addition_embed:
@@ -125,12 +140,29 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         tokenizer = WordPieceTokenizer(cfg.text_max_length)
         enc1 = SyntheticTextEncoder(cfg.cross_attention_dim - d2, seed=1).to(device)
         enc2 = SyntheticTextEncoder(d2, seed=2).to(device)
-        import dataclasses
         vcfg = SD_VAE if parts[1] == "sdxl" else TINY_VAE
         vae = AutoencoderKL(dataclasses.replace(vcfg, scaling_factor=0.13025), device=device)   # the SDXL VAE's factor
         unet = UNet2DConditionModel(cfg, sd, device=device)
-        sched = scheduler if scheduler is not None else DDIMScheduler()
         return cls(unet, tokenizer, enc1, vae, sched, cfg, sd if keep_state_dict else None, text_encoder_2=enc2)
+
+    def _hidden_and_pooled(self, texts):
+        """-> (penultimate hidden states of both encoders concatenated [B,77,C1+C2], pooled output of the second [B,C2]),
+        as diffusers' SDXL `encode_prompt` does with CLIP (`hidden_states[-2]`, `text_embeds`); the seeded stand-ins have
+        one layer and no projection head: their output and its token mean"""
+        outs = []
+        pooled = None
+        for k, (tok, enc) in enumerate(((self.tokenizer, self.text_encoder), (self.tokenizer_2, self.text_encoder_2))):
+            ids = tok(texts, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+            if isinstance(enc, SyntheticTextEncoder):
+                h = enc(ids.to(self.device))[0]
+                p = h.mean(dim=1)
+            else:
+                o = enc(ids.to(self.device), output_hidden_states=True)
+                h, p = o.hidden_states[-2].float(), o[0].float()
+            outs.append(h)
+            if k == 1:
+                pooled = p
+        return torch.cat(outs, dim=-1), pooled
 
     @torch.no_grad()
     def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt=1, do_classifier_free_guidance=True,
@@ -139,19 +171,12 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         """-> (prompt_embeds [B,77,C1+C2], negative_prompt_embeds, pooled [B,C2], negative_pooled).  As SDXL base does
         (`force_zeros_for_empty_prompt`), a missing negative prompt gives ZERO embeddings, not the encoding of ""."""
         prompt = [prompt] if isinstance(prompt, str) else list(prompt)
-        tok = self.tokenizer
-        ids = tok(prompt, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
-        h1 = self.text_encoder(ids.to(self.device))[0]
-        h2 = self.text_encoder_2(ids.to(self.device))[0]
-        embeds = torch.cat([h1, h2], dim=-1)
-        pooled = h2.mean(dim=1)
+        embeds, pooled = self._hidden_and_pooled(prompt)
         if negative_prompt is None:
             neg, neg_pooled = torch.zeros_like(embeds), torch.zeros_like(pooled)
         else:
-            nids = tok([negative_prompt] * len(prompt) if isinstance(negative_prompt, str) else list(negative_prompt),
-                       padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
-            n1, n2 = self.text_encoder(nids.to(self.device))[0], self.text_encoder_2(nids.to(self.device))[0]
-            neg, neg_pooled = torch.cat([n1, n2], dim=-1), n2.mean(dim=1)
+            negs = [negative_prompt] * len(prompt) if isinstance(negative_prompt, str) else list(negative_prompt)
+            neg, neg_pooled = self._hidden_and_pooled(negs)
         return embeds, neg, pooled, neg_pooled
 
     def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype=torch.float32,
@@ -198,6 +223,29 @@ def _load_local_vae(path, device):
                     norm_num_groups=c["norm_num_groups"], scaling_factor=c.get("scaling_factor", 0.18215))
     sd = {k: v.float() for k, v in load_file(os.path.join(vdir, "diffusion_pytorch_model.safetensors")).items()}
     return AutoencoderKL(cfg, sd, device=device)
+
+
+def _load_local_text_xl(path, cfg):
+    """-> (tokenizer, tokenizer_2, text_encoder, text_encoder_2) of a local SDXL directory"""
+    d2 = cfg.pooled_text_dim
+    toks = []
+    for name in ("tokenizer", "tokenizer_2"):
+        tok_dir = os.path.join(path, name)
+        if os.path.isdir(tok_dir):
+            from transformers import CLIPTokenizer
+            toks.append(CLIPTokenizer.from_pretrained(tok_dir))
+        else:
+            toks.append(toks[0] if toks else WordPieceTokenizer(cfg.text_max_length))
+    tokenizer, tokenizer_2 = toks
+    e1, e2 = os.path.join(path, "text_encoder"), os.path.join(path, "text_encoder_2")
+    if os.path.isdir(e1) and os.path.isdir(e2):
+        from transformers import CLIPTextModel, CLIPTextModelWithProjection
+        enc1, enc2 = CLIPTextModel.from_pretrained(e1).eval(), CLIPTextModelWithProjection.from_pretrained(e2).eval()
+        if enc1.config.hidden_size + enc2.config.hidden_size != cfg.cross_attention_dim or enc2.config.projection_dim != d2:
+            raise ValueError("text encoders do not match the UNet: hidden sizes must add up to cross_attention_dim and the "
+                             "second encoder's projection must be the pooled width")
+        return tokenizer, tokenizer_2, enc1, enc2
+    return tokenizer, tokenizer_2, SyntheticTextEncoder(cfg.cross_attention_dim - d2, seed=1), SyntheticTextEncoder(d2, seed=2)
 
 
 def _load_local_text(path, cfg):

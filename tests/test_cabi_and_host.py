@@ -313,3 +313,58 @@ def test_oracle_sdxl_family_invariants():
     assert [len(t.transformer_blocks) for t in u.mid_block.attentions] == [cfg.depth(2)]
     assert not u.down_blocks[0].has_cross_attention and len(u.down_blocks[1].attentions[0].transformer_blocks) == cfg.depth(1)
     assert len(u.attention_modules()) == unet_ref.count_attention_layers(cfg)
+
+
+def _write_diffusers_dir(root, cfg, sd, xl=False):
+    """a local diffusers-layout directory as README.md:30-32 of the reference tells users to point sd_mapping at"""
+    import json
+    from safetensors.torch import save_file
+    from ief_amd.vae import TINY_VAE, synthetic_vae_state_dict
+    os.makedirs(os.path.join(root, "unet"))
+    os.makedirs(os.path.join(root, "vae"))
+    nlev = len(cfg.block_out_channels)
+    c = {"sample_size": cfg.sample_size, "in_channels": 4, "out_channels": 4,
+         "block_out_channels": list(cfg.block_out_channels),
+         "down_block_types": ["CrossAttnDownBlock2D" if a else "DownBlock2D" for a in cfg.down_has_attn],
+         "layers_per_block": cfg.layers_per_block, "cross_attention_dim": cfg.cross_attention_dim,
+         "attention_head_dim": list(cfg.num_heads), "norm_num_groups": cfg.norm_num_groups, "norm_eps": cfg.norm_eps,
+         "use_linear_projection": cfg.use_linear_projection}
+    if xl:
+        c.update({"transformer_layers_per_block": [cfg.depth(i) for i in range(nlev)], "addition_embed_type": "text_time",
+                  "addition_time_embed_dim": cfg.addition_time_embed_dim,
+                  "projection_class_embeddings_input_dim": cfg.addition_input_dim})
+    with open(os.path.join(root, "unet", "config.json"), "w") as f:
+        json.dump(c, f)
+    save_file({k: v.half().contiguous() for k, v in sd.items()}, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    v = TINY_VAE
+    with open(os.path.join(root, "vae", "config.json"), "w") as f:
+        json.dump({"block_out_channels": list(v.block_out_channels), "layers_per_block": v.layers_per_block,
+                   "latent_channels": v.latent_channels, "in_channels": v.in_channels, "norm_num_groups": v.norm_num_groups,
+                   "scaling_factor": v.scaling_factor}, f)
+    save_file({k: t.contiguous() for k, t in synthetic_vae_state_dict(v).items()},
+              os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small21", "smallxl"])
+def test_local_diffusers_directory_loads(tmp_path, name):
+    """`sd_maps[...] = <local dir>`: unet/config.json is mapped onto the UNetConfig of that family and the checkpoint's
+    tensors reach the packer unchanged (fp16 on disk, as the published checkpoints' `variant="fp16"` files are)"""
+    from ief_amd.pipeline import _load_local_unet, _load_local_vae
+    cfg = config.CONFIGS[name]
+    sd = weights.synthetic_state_dict(cfg, 0)
+    root = str(tmp_path / name)
+    _write_diffusers_dir(root, cfg, sd, xl=cfg.addition_embed)
+    got_cfg, got_sd = _load_local_unet(root)
+    for field in ("sample_size", "block_out_channels", "down_has_attn", "cross_attention_dim", "num_heads",
+                  "use_linear_projection", "addition_embed", "addition_time_embed_dim", "pooled_text_dim"):
+        assert getattr(got_cfg, field) == getattr(cfg, field), field
+    assert [got_cfg.depth(i) for i in range(len(cfg.block_out_channels))] == [cfg.depth(i) for i in range(len(cfg.block_out_channels))]
+    assert set(got_sd) == set(sd) and all(torch.equal(got_sd[k], sd[k].half().float()) for k in sd)
+    vae = _load_local_vae(root, "cpu")
+    assert vae.config.scaling_factor == 0.18215
+    # a checkpoint that lacks tensors is refused with the missing names
+    from safetensors.torch import save_file
+    part = {k: v.half().contiguous() for k, v in list(sd.items())[:-3]}
+    save_file(part, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(KeyError):
+        _load_local_unet(root)

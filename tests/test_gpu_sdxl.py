@@ -378,3 +378,39 @@ def test_xl_null_text_clis(tmp_path):
         for name in ("source.png", "inversion.png", "edit.png"):
             assert (tmp_path / "exp" / name).exists()
             os.remove(tmp_path / "exp" / name)
+
+
+# ------------------------------------------------------------------------------------------------ local SDXL-layout directory
+def test_local_sdxl_directory_with_clip_text_encoders(tmp_path):
+    """`sd_maps["xl-base"] -> local dir` (README.md:30-32 of the reference): unet/ + vae/ safetensors in diffusers' layout and
+    two CLIP text encoders loaded by `transformers` (random weights of a tiny CLIP configuration here: there are no
+    checkpoints offline; the tokenizer falls back to the seeded one, a CLIP vocabulary cannot be made up).  The pipeline
+    must produce the same UNet outputs as the synthetic one built from the same tensors, and run P2P_XL end to end."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from test_cabi_and_host import _write_diffusers_dir
+    cfg = config.SMALLXL
+    sd = weights.synthetic_state_dict(cfg, 0)
+    root = str(tmp_path / "sdxl_dir")
+    _write_diffusers_dir(root, cfg, sd, xl=True)
+    d2 = cfg.pooled_text_dim
+    d1 = cfg.cross_attention_dim - d2
+    torch.manual_seed(0)
+    kw = dict(vocab_size=49408, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=77)
+    CLIPTextModel(CLIPTextConfig(hidden_size=d1, intermediate_size=2 * d1, **kw)).save_pretrained(os.path.join(root, "text_encoder"))
+    CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=d2, intermediate_size=2 * d2, projection_dim=d2, **kw)).save_pretrained(
+        os.path.join(root, "text_encoder_2"))
+    pipe = StableDiffusionXLPipeline.from_pretrained(root)
+    assert type(pipe.text_encoder).__name__ == "CLIPTextModel" and pipe.cfg.depth(2) == cfg.depth(2)
+    emb, neg, pooled, neg_pooled = pipe.encode_prompt(PROMPTS)
+    assert emb.shape == (2, 77, cfg.cross_attention_dim) and pooled.shape == (2, d2) and neg.abs().max() == 0
+    # same tensors, rounded to fp16 on disk (biases, norm affines and the folded LayerNorm weights included, which the
+    # synthetic pipeline packs from fp32): the same UNet up to that rounding
+    x, ctx, added = _inputs(cfg, 2, seed=21)
+    kwargs = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs={k: v.to(DEV) for k, v in added.items()})
+    ref_pipe = StableDiffusionXLPipeline.from_pretrained("synthetic:smallxl")
+    e = rel_err(pipe.unet(x.to(DEV), 301, **kwargs)["sample"], ref_pipe.unet(x.to(DEV), 301, **kwargs)["sample"])
+    print(f"local directory vs synthetic pipeline of the same tensors: {e:.2e}")
+    assert e < 1e-2
+    editor = P2P_XL(pipe, 3)
+    images, _ = editor.text2image_ldm_stable(pipe, PROMPTS, EmptyControl(LOW_RESOURCE=False), num_inference_steps=3)
+    assert images.shape == (2, cfg.sample_size * 8, cfg.sample_size * 8, 3) and images.dtype == np.uint8
