@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     float* row_mu = rpart + 64 * CH * 2;             // folded LayerNorm: mean and rstd of the 64 rows of a pass
     float* row_rs = row_mu + 64;
     half_t* __restrict__ Out = p.Out + z * p.strideO;
+    float ccs = 0.f, ccq = 0.f;                      // cstat_out: thread tid < BN owns output column n0 + tid
     for (int pass = 0; pass < NPASS; ++pass) {
         if (p.rstat_in && tid < 64) {
             const int m = m0 + pass * 64 + tid;
@@ -392,6 +393,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
                 *(half8*)(Out + (long long)m * p.ldo + n) = o;
+                if (p.cstat_out) {   // what the consumer will read goes back into the stage for the column sums below
+                    float* sp = stage + row * LDS_N + nc * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sp[e] = (float)o[e];
+                }
                 if (p.rstat_out) {   // moments of what the consumer will read (the fp16-rounded values)
                     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -399,12 +405,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                     rpart[(row * CH + nc) * 2] = a1;
                     rpart[(row * CH + nc) * 2 + 1] = a2;
                 }
-            } else if (p.rstat_out) {
-                rpart[(row * CH + nc) * 2] = 0.f;
-                rpart[(row * CH + nc) * 2 + 1] = 0.f;
+            } else {
+                if (p.rstat_out) {
+                    rpart[(row * CH + nc) * 2] = 0.f;
+                    rpart[(row * CH + nc) * 2 + 1] = 0.f;
+                }
+                if (p.cstat_out) {
+                    float* sp = stage + row * LDS_N + nc * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sp[e] = 0.f;
+                }
             }
         }
         __syncthreads();
+        if (p.cstat_out) {           // column sums over this pass's rows, fixed order: deterministic
+            if (tid < BN) {
+                for (int r = 0; r < PROWS; ++r) {
+                    const float v = stage[r * LDS_N + tid];
+                    ccs += v;
+                    ccq += v * v;
+                }
+            }
+            __syncthreads();         // the next pass overwrites the stage
+        }
         if (p.rstat_out && tid < PROWS) {   // fixed summation order: deterministic
             const int m = m0 + pass * 64 + tid;
             if (m < p.M) {
@@ -414,6 +437,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                 ro[0] = a1; ro[1] = a2;
             }
         }
+    }
+    if (p.cstat_out && tid < BN && n0 + tid < p.N) {
+        float* co = p.cstat_out + ((long long)(m0 / BM) * p.N + n0 + tid) * 2;
+        co[0] = ccs; co[1] = ccq;
     }
 }
 
@@ -512,6 +539,15 @@ static int dispatch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     return launch_igemm<64, 64, 2, 2, CONV>(p, batch, st);
 }
 
+extern "C" int ief_gemm_tile_bm(int tile_hint) {
+    switch (tile_hint) {
+        case 1: case 4: case 6: case 7: case 9: return 128;
+        case 2: case 3: case 5: return 64;
+        case 8: return 256;
+        default: return 0;
+    }
+}
+
 extern "C" int ief_gemm_tile_bn(int tile_hint) {
     switch (tile_hint) {
         case 1: case 2: case 8: case 9: return 128;
@@ -535,6 +571,7 @@ static int check_common(const IefGemmParams& p) {
     }
     if (p.rstat_in && (!p.colsum || p.rstat_slots <= 0 || p.splits > 1 || !(p.ln_eps > 0.f))) return IEF_EINVAL;
     if (p.rstat_out && p.splits > 1) return IEF_EINVAL;
+    if (p.cstat_out && (p.splits > 1 || (p.flags & 2) || ief_gemm_tile_bm(p.tile_hint) == 0)) return IEF_EINVAL;
     // 32-bit byte offsets inside each operand
     if ((long long)p.N * p.ldw * 2 >= (1ll << 32)) return IEF_ESHAPE;
     return IEF_OK;
@@ -547,6 +584,7 @@ extern "C" int ief_gemm_f16(const IefGemmParams* pp, int batch, void* stream) {
     if (rc) return rc;
     if (p.lda & 7) return IEF_EALIGN;
     if (batch <= 0) return IEF_ESHAPE;
+    if (p.cstat_out && batch != 1) return IEF_EINVAL;
     if (p.splits > 1 && batch != 1) return IEF_ESHAPE;
     if ((long long)p.M * p.lda * 2 >= (1ll << 32)) return IEF_ESHAPE;
     p.ups = 0; p.H = p.Wd = 1;

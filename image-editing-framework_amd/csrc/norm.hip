@@ -239,6 +239,65 @@ extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int
     return IEF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm from the producer's per-tile column statistics (IefGemmParams.cstat_out): one wave per (batch, group) folds
+// (tiles of the image) x (channels of the group) partial pairs in a fixed order; a group of a channel-concat input may
+// take channels from both sources, each with its own tile height.
+__global__ __launch_bounds__(64) void gn_finalize_cstat_kernel(const float* __restrict__ cs1, int bm1, int C1,
+                                                               const float* __restrict__ cs2, int bm2, int C2,
+                                                               float* __restrict__ stats, int HW, int groups, float eps) {
+    const int C = C1 + C2, cpg = C / groups;
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    const int t1 = HW / bm1, t2 = C2 > 0 ? HW / bm2 : 0;
+    float s = 0.f, q = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const bool first = c < C1;
+        const float* cs = first ? cs1 : cs2;
+        const int Cs = first ? C1 : C2, cc = first ? c : c - C1, nt = first ? t1 : t2;
+        for (int t = threadIdx.x; t < nt; t += 64) {
+            const float* o = cs + ((long long)(b * nt + t) * Cs + cc) * 2;
+            s += o[0]; q += o[1];
+        }
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        const float inv = 1.0f / ((float)cpg * (float)HW);
+        const float m = s * inv;
+        stats[((long long)b * groups + g) * 2] = m;
+        stats[((long long)b * groups + g) * 2 + 1] = rsqrtf(fmaxf(q * inv - m * m, 0.f) + eps);
+    }
+}
+
+extern "C" int ief_groupnorm_cstat_f16(const ief_half* x, const ief_half* x2, int C1, int C2, ief_half* out,
+                                       const float* gamma, const float* beta, const float* cstat1, int bm1,
+                                       const float* cstat2, int bm2, float* stats, int B, int HW, int groups, float eps,
+                                       int apply_silu, void* stream) {
+    if (!x || !out || !gamma || !beta || !cstat1 || !stats) return IEF_EINVAL;
+    if (C2 > 0 && (!x2 || !cstat2)) return IEF_EINVAL;
+    const int C = C1 + C2;
+    if (B <= 0 || HW <= 0 || groups <= 0 || groups > GN_MAX_GROUPS) return IEF_ESHAPE;
+    if ((C1 & 7) || (C2 & 7) || (C % groups) || C > 8 * 1024) return IEF_ESHAPE;
+    if (bm1 <= 0 || (HW % bm1) || (C2 > 0 && (bm2 <= 0 || (HW % bm2)))) return IEF_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_finalize_cstat_kernel, dim3(B * groups), dim3(64), 0, st, cstat1, bm1, C1, cstat2, bm2, C2, stats,
+                       HW, groups, eps);
+    IEF_LAUNCH_CHECK();
+    const int C8 = C / 8;
+    int PYa = 256 / C8;
+    if (PYa < 1) PYa = 1;
+    if (PYa > HW) PYa = HW;
+    int ppb = PYa * 4;
+    if (ppb > HW) ppb = HW;
+    int ta = C8 * PYa;
+    if (ta < 64) ta = 64;
+    const int gx = (HW + ppb - 1) / ppb;
+    // splits = 0: the apply kernel then reads the finalized statistics at the start of the buffer it is handed
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, B), dim3(ta), 0, st, x, x2, C1, C2, out, gamma, beta, stats, HW, groups, 0,
+                       eps, apply_silu, ppb, PYa);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 // one wave per row; row kept in registers (C <= 8 * 64 * LN_MAXCH)
 #define LN_MAXCH 4
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ out,

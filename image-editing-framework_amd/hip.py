@@ -34,6 +34,7 @@ class IefGemmParams(Structure):
         ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p), ("stages", c_int),
         ("pad_hi_only", c_int),
         ("rstat_out", c_void_p), ("rstat_in", c_void_p), ("rstat_slots", c_int), ("colsum", c_void_p), ("ln_eps", c_float),
+        ("cstat_out", c_void_p),
     ]
 
 
@@ -86,7 +87,7 @@ EXPORTS = [
     "ief_attn_bwd_delta_f32", "ief_attn_bwd_f16", "ief_groupnorm_bwd_f16", "ief_layernorm_bwd_f16", "ief_geglu_il_f16",
     "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
     "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn", "ief_gather_rows_f16",
-    "ief_attn_map_loss_bwd_f16", "ief_axpy_f32", "ief_map_loss_blocks",
+    "ief_attn_map_loss_bwd_f16", "ief_axpy_f32", "ief_map_loss_blocks", "ief_groupnorm_cstat_f16", "ief_gemm_tile_bm",
 ]
 
 
@@ -140,6 +141,10 @@ def load():
     lib.ief_axpy_f32.argtypes = [c_void_p, c_void_p, c_float, c_longlong, c_void_p]
     lib.ief_map_loss_blocks.restype = c_int
     lib.ief_map_loss_blocks.argtypes = [c_int, c_int]
+    lib.ief_groupnorm_cstat_f16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                            c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]
+    lib.ief_gemm_tile_bm.restype = c_int
+    lib.ief_gemm_tile_bm.argtypes = [c_int]
     lib.ief_groupnorm_bwd_f16.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8 + [c_int, c_int, c_int, c_float,
                                                                                               c_int, c_void_p]
     lib.ief_layernorm_bwd_f16.argtypes = [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]
@@ -222,6 +227,27 @@ class _Timed:
         if _prof is not None:
             self.e1.record(torch.cuda.current_stream())
             _prof.append((self.name, self.flops, self.e0, self.e1))
+
+
+# GroupNorm statistics from the producer: a conv / 1x1-projection launch whose output is an NHWC activation of a level with
+# at least this many pixels per image leaves per-tile column sums next to it (`out._cstat`); `groupnorm` uses them when the
+# input would otherwise take the three-launch path.  The attribute lives on the tensor OBJECT the producer returns: a
+# view / reshape drops it and the consumer falls back to computing the statistics itself, it can never read stale ones.
+GN_CSTAT = os.environ.get("IEF_GN_CSTAT", "1") == "1"
+_CSTAT_MIN_HW = 1024
+
+
+def _attach_cstat(lib, p, out, M, N, hw):
+    """decide whether this launch emits column statistics; returns the scratch tensor to keep alive (or None)"""
+    if not GN_CSTAT or hw is None or hw < _CSTAT_MIN_HW or p.splits > 1 or (p.flags & 2) or AUTOTUNE:
+        return None
+    bm = lib.ief_gemm_tile_bm(p.tile_hint)
+    if bm <= 0 or hw % bm or M % hw:
+        return None
+    cs = torch.empty(M // bm, N, 2, dtype=torch.float32, device=out.device)
+    p.cstat_out = cs.data_ptr()
+    out._cstat = (cs, bm, hw)
+    return cs
 
 
 def pick_tile(M: int, N: int, batch: int = 1) -> int:
@@ -476,6 +502,8 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
             raise ValueError("gemm: colsum must have N entries")
         p.rstat_in, p.rstat_slots, p.colsum, p.ln_eps = st_in.data_ptr(), st_in.shape[1], colsum.data_ptr(), eps
     p.flags, p.zeros = (3 if geglu else 1), _zeros(a.device)
+    if a.dim() == 4 and out.dim() == 4 and out.is_contiguous():       # a 1x1 projection over an NHWC activation
+        _attach_cstat(lib, p, out, M, N, a.shape[1] * a.shape[2])
     with _Timed(_kname(p.tile_hint, False, p.stages) + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     return (out, stats) if row_stats else out
@@ -552,6 +580,8 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
         p.ws = ws.data_ptr()
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
+    if out.is_contiguous():
+        _attach_cstat(lib, p, out, M, Cout, Ho * Wo)
     with _Timed(_kname(p.tile_hint, True, p.stages) + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
     return out
@@ -666,6 +696,20 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
     HW = x.numel() // (B * C1)
     if out is None:
         out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float16, device=x.device)
+    cs1, cs2 = getattr(x, "_cstat", None), None if x2 is None else getattr(x2, "_cstat", None)
+    cpg = (C1 + C2) // groups
+    single_launch = not (cpg & 1) and HW * cpg * 2 <= 48 * 1024           # the C side's one-workgroup-per-group condition
+    if (GN_CSTAT and not return_stats and not single_launch and cs1 is not None and cs1[2] == HW
+            and (x2 is None or (cs2 is not None and cs2[2] == HW))):
+        # statistics were left by the producers' epilogues: fold them (one small launch) and apply
+        stats = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+        with _Timed("groupnorm(stats+apply)", 0.0):
+            _check(lib.ief_groupnorm_cstat_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                               _dev32(beta, "beta").data_ptr(), cs1[0].data_ptr(), cs1[1],
+                                               None if cs2 is None else cs2[0].data_ptr(), 0 if cs2 is None else cs2[1],
+                                               stats.data_ptr(), B, HW, groups, eps, 1 if silu else 0, _stream()),
+                   "ief_groupnorm_cstat_f16")
+        return out
     splits = lib.ief_gn_splits(HW)
     partial = torch.empty(B * (splits + 1) * groups * 2, dtype=torch.float32, device=x.device)
     with _Timed("groupnorm(stats+apply)", 0.0):

@@ -90,6 +90,11 @@ typedef struct IefGemmParams {
     int rstat_slots;
     const float* colsum;
     float ln_eps;
+    /* GroupNorm statistics from the PRODUCER of its input: cstat_out [ceil(M / BM)][N][2] fp32 = per output channel the
+     * (sum, sum of squares) of the fp16-rounded outputs over the BM rows of each M tile, summed in a fixed order
+     * (ief_gemm_tile_bm(tile_hint) gives BM; the consumer is ief_groupnorm_cstat_f16).  No split-K, no GEGLU epilogue,
+     * dense batch 1. */
+    float* cstat_out;
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);
@@ -251,6 +256,15 @@ int ief_attn_map_loss_bwd_f16(const IefMapLossParams* p, void* stream);
 int ief_map_loss_blocks(int N, int d);
 /* y[i] += a * x[i] (fp32): the plain SGD step on the UNet input (sd_utils.py:160,174) */
 int ief_axpy_f32(float* y, const float* x, float a, long long n, void* stream);
+/* GroupNorm(+SiLU) whose statistics were left by the kernels that produced x (and x2): cstat1 / cstat2 are those launches'
+ * IefGemmParams.cstat_out, bm1 / bm2 their M-tile heights (HW % bm == 0: no tile straddles two images).  One small
+ * launch folds the per-tile partials into (mean, rstd) per (batch, group) in `stats` (B * groups * 2 floats), one applies:
+ * the statistics pass over x is gone.  replaces the same reference lines as ief_groupnorm_silu_f16. */
+int ief_groupnorm_cstat_f16(const ief_half* x, const ief_half* x2, int C1, int C2, ief_half* out, const float* gamma,
+                            const float* beta, const float* cstat1, int bm1, const float* cstat2, int bm2, float* stats,
+                            int B, int HW, int groups, float eps, int apply_silu, void* stream);
+/* BM of a tile id (see ief_gemm_tile_bn) */
+int ief_gemm_tile_bm(int tile_hint);
 /* GroupNorm(+SiLU) backward w.r.t. the input: x (+x2 channel concat) is the forward INPUT, dy [B][HW][C1+C2] the gradient
  * of the output, `add` (optional, same shape as dy) is added to the result; dx [B][HW][C1], dx2 [B][HW][C2].
  * stats: (mean, rstd) [B][groups][2] saved by the forward, or NULL (recomputed); partial: scratch of
