@@ -1,4 +1,4 @@
-"""Launch ONE kernel shape a few times (for rocprofv3 --pmc runs).  usage: one_kernel.py attn40|conv64|gemmff"""
+"""Launch ONE kernel shape a few times (for rocprofv3 --pmc runs).  usage: one_kernel.py attn40|conv64|conv32|gemmff|gemmsq"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,6 +20,9 @@ elif what == "conv32":
 elif what == "gemmff":
     a, w = h(4096, 640), h(5120, 640, scale=0.04)
     fn = lambda: hip.gemm(a, w)
+elif what == "gemmsq":      # the most frequent linear of the step: a square projection with bias + residual (to_out / proj_out)
+    a, w, b, r = h(4, 4096, 320), h(320, 320, scale=0.05), torch.randn(320, device=DEV), h(4, 4096, 320)
+    fn = lambda: hip.gemm(a, w, bias=b, residual=r)
 for _ in range(4):
     fn()
 torch.cuda.synchronize()
