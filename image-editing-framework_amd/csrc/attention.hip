@@ -892,7 +892,10 @@ __device__ __forceinline__ void cross_scores(f32x16 (&s)[3], const half_t* Ks, c
 template <int D>
 __global__ __launch_bounds__(256) void attn_cross_p2p_kernel(const IefCrossParams p) {
     using C = AttnCfg<D>;
+    // everything the workgroup reads is staged in ONE phase (own K, the edit source's K, V^T, the mapper, the gate rows)
+    // and both query fragments are fetched meanwhile: one global-memory latency on the critical path instead of four
     __shared__ __attribute__((aligned(16))) half_t Ks[XL * C::KS];
+    __shared__ __attribute__((aligned(16))) half_t Ks2[XL * C::KS];     // K of the edit source row
     __shared__ __attribute__((aligned(16))) half_t Vt[C::DT * 32 * XS];
     __shared__ __attribute__((aligned(16))) half_t Ms[XL * XS];
     __shared__ float coef_s[2 * XL];
@@ -907,22 +910,36 @@ __global__ __launch_bounds__(256) void attn_cross_p2p_kernel(const IefCrossParam
     const float sc = p.scale * LOG2E;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    for (int i = tid; i < XL * C::KS / 8; i += 256) ((half8*)Ks)[i] = zero8;
+    // query fragments straight from global memory (no dependence on the staging below)
+    half8 qf[C::D16], qs[C::D16];
+    load_q_frags<D>(qf, p.Q, ((long long)b * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    if (es >= 0) load_q_frags<D>(qs, p.Q, ((long long)es * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+
+    for (int i = tid; i < XL * C::KS / 8; i += 256) { ((half8*)Ks)[i] = zero8; ((half8*)Ks2)[i] = zero8; }
     for (int i = tid; i < C::DT * 32 * XS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
     __syncthreads();
 
-    auto stage_k = [&](int bsrc) {
+    auto stage_k = [&](half_t* dst, int bsrc) {
         const half_t* Kb = p.K + (long long)bsrc * p.L * p.ldk + head * D;
         for (int c = tid; c < XL * C::CPR; c += 256) {
             const int row = c / C::CPR, ch = c - row * C::CPR;
-            *(half8*)(Ks + row * C::KS + ch * 8) = row < p.L ? *(const half8*)(Kb + (long long)row * p.ldk + ch * 8) : zero8;
+            if (row < p.L) *(half8*)(dst + row * C::KS + ch * 8) = *(const half8*)(Kb + (long long)row * p.ldk + ch * 8);
         }
     };
-
-    half8 qf[C::D16];
-    f32x16 pm[3];
+    stage_k(Ks, b);
+    {
+        const half_t* Vb = p.V + (long long)b * p.L * p.ldv + head * D;
+        for (int c = tid; c < XL * C::CPR; c += 256) {
+            const int row = c / C::CPR, ch = c - row * C::CPR;
+            if (row < p.L) {
+                const half8 v = *(const half8*)(Vb + (long long)row * p.ldv + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * XS + row] = v[e];
+            }
+        }
+    }
     if (es >= 0) {  // block-uniform
-        stage_k(es);
+        stage_k(Ks2, es);
         const half_t* Mg = p.MT + (long long)slot * XL * XL;
         for (int c = tid; c < XL * XL / 8; c += 256) {
             const int row = c / (XL / 8), ch = c - row * (XL / 8);
@@ -931,10 +948,13 @@ __global__ __launch_bounds__(256) void attn_cross_p2p_kernel(const IefCrossParam
             *(half4*)(Ms + row * XS + ch * 8 + 4) = (half4){v[4], v[5], v[6], v[7]};
         }
         for (int i = tid; i < 2 * XL; i += 256) coef_s[i] = p.coef[(long long)slot * 2 * XL + i];
-        __syncthreads();
-        load_q_frags<D>(qf, p.Q, ((long long)es * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
+    }
+    __syncthreads();
+
+    f32x16 pm[3];
+    if (es >= 0) {
         f32x16 ps[3];
-        cross_scores<D>(ps, Ks, qf, r, h, sc, p.L);
+        cross_scores<D>(ps, Ks2, qs, r, h, sc, p.L);
         // PM^T[n][q] = sum_w M^T[n][w] P_src^T[w][q]
 #pragma unroll
         for (int u = 0; u < 3; ++u)
@@ -950,23 +970,7 @@ __global__ __launch_bounds__(256) void attn_cross_p2p_kernel(const IefCrossParam
                 pm[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(read_perm_frag(mrow, 32 * u2 + 16, h), pb1, pm[u], 0, 0, 0);
             }
         }
-        __syncthreads();  // everyone is done with the source K image
     }
-
-    stage_k(b);
-    {
-        const half_t* Vb = p.V + (long long)b * p.L * p.ldv + head * D;
-        for (int c = tid; c < XL * C::CPR; c += 256) {
-            const int row = c / C::CPR, ch = c - row * C::CPR;
-            if (row < p.L) {
-                const half8 v = *(const half8*)(Vb + (long long)row * p.ldv + ch * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * XS + row] = v[e];
-            }
-        }
-    }
-    __syncthreads();
-    load_q_frags<D>(qf, p.Q, ((long long)b * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
     f32x16 ps[3];
     cross_scores<D>(ps, Ks, qf, r, h, sc, p.L);
     if (es >= 0) {
