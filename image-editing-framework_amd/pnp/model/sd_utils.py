@@ -13,7 +13,7 @@ from typing import List, Optional, Union
 import numpy as np
 import torch
 
-from ...denoise import acquire
+from ...denoise import acquire, run_interleaved
 from ...p2p.model.sd_utils import _encode_prompts
 from .register import (register_attention_control_efficient, register_conv_control_efficient, register_time,
                        unregister_attention_control_efficient, unregister_conv_control_efficient)
@@ -76,6 +76,48 @@ class PnP:
         if return_latents:
             return latents
         return self.latent2image(latents)
+
+    @torch.no_grad()
+    def edit_many(self, jobs, num_inference_steps: int = 50, guidance_scale: float = 7.5, pnp_attn_t: float = 0.5,
+                  pnp_f_t: float = 0.8, height: Optional[int] = None, width: Optional[int] = None):
+        """Several independent Plug-and-Play edits IN FLIGHT on one GPU (a throughput schedule the reference does not have:
+        its drivers call the sampler once per image).  jobs: [(prompts [source, target], latents [2,4,h,w] or [1,4,h,w])]
+        or [(prompts, latents, uncond_embeddings_list)] (`PnP_NTI`).  Each job's loop is captured while the injection
+        schedules are registered, then all loops are stepped in turn on their own streams (`denoise.run_interleaved`).
+        Returns one uint8 [2,H,W,3] per job — the values `__call__` gives job by job."""
+        model = self.model
+        dev = model.unet.device
+        if not guidance_scale > 1.0:
+            raise NotImplementedError("PnP.edit_many: classifier-free guidance is what the reference's drivers run")
+        model.scheduler.set_timesteps(num_inference_steps)
+        height = height or model.unet.config.sample_size * model.vae_scale_factor
+        width = width or model.unet.config.sample_size * model.vae_scale_factor
+        C = model.unet.config.in_channels
+        loops = []
+        try:
+            for job in jobs:
+                prompt, latents = job[0], job[1]
+                uncond_list = job[2] if len(job) > 2 else None
+                uncond_embeddings, text_embeddings = _encode_prompts(model, list(prompt))
+                latents = latents.to(dev).float() * model.scheduler.init_noise_sigma
+                if latents.shape[0] == 1:
+                    latents = latents.expand(len(prompt), C, height // 8, width // 8)
+                self.init_pnp(conv_injection_t=int(num_inference_steps * pnp_f_t),
+                              qk_injection_t=int(num_inference_steps * pnp_attn_t))
+                try:
+                    loop = acquire(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
+                                   (height // 8, width // 8), guidance_scale, uncond_list=uncond_list)
+                    loops.append(loop)
+                    loop.start(latents)
+                finally:                                    # the captured graph carries the plan's tables
+                    unregister_attention_control_efficient(model)
+                    unregister_conv_control_efficient(model)
+            run_interleaved(loops)
+            torch.cuda.synchronize()
+            return [self.latent2image(loop.result()) for loop in loops]
+        finally:
+            for loop in loops:
+                loop.release()
 
     @torch.no_grad()
     def latent2image(self, latents, return_type="np"):

@@ -36,6 +36,7 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
     ap.add_argument("--no_save", action="store_true")
     ap.add_argument("--invert_batch", type=int, default=1)
+    ap.add_argument("--in_flight", type=int, default=1, help="edits stepped concurrently on one GPU (PnP.edit_many)")
     args = ap.parse_args(argv)
     if args.inversion_type not in ("ddim", "null-text"):
         raise ValueError("--inversion_type must be ddim or null-text")
@@ -63,6 +64,9 @@ def main(argv=None):
             items += PIE(args.dataset_path, None, category=category).items
     mine = list(range(rank, len(items), world))
     bs = max(1, args.invert_batch)
+    E = max(1, args.in_flight)
+    if E > 1:
+        bs = max(bs, E)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c0 in range(0, len(mine), bs):
@@ -70,6 +74,23 @@ def main(argv=None):
         originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
         latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32) for im in originals])
         latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
+        if E > 1 and not nti:       # the chunk's edits in flight, E at a time; same images as the per-image calls below
+            for e0 in range(0, len(chunk), E):
+                part = list(range(e0, min(e0 + E, len(chunk))))
+                jobs = []
+                for j in part:
+                    x_T = latents[-1][j:j + 1].clone()
+                    jobs.append(([chunk[j][1], chunk[j][2]], torch.cat([x_T, x_T])))
+                outs = editor.edit_many(jobs, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                        pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t)
+                for j, images in zip(part, outs):
+                    if not args.no_save:
+                        out_path = os.path.join(args.exp_path, os.path.relpath(chunk[j][0].split(".")[0], root))
+                        os.makedirs(out_path, exist_ok=True)
+                        originals[j].save(os.path.join(out_path, "source.png"))
+                        save_img(images[0], os.path.join(out_path, "inversion.png"))
+                        save_img(images[1], os.path.join(out_path, "edit.png"))
+            continue
         for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
             x_T = latents[-1][j:j + 1].clone()
             extra = {}
