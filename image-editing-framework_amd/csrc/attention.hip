@@ -915,39 +915,61 @@ __global__ __launch_bounds__(256) void attn_cross_p2p_kernel(const IefCrossParam
     load_q_frags<D>(qf, p.Q, ((long long)b * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
     if (es >= 0) load_q_frags<D>(qs, p.Q, ((long long)es * p.N + q0 + r) * p.ldq + head * D, q_ok, h);
 
+    // ALL global loads of the staging are issued before anything waits on one of them (a load -> LDS-store loop exposes
+    // one memory latency per iteration: ~27 of them at d = 160)
+    constexpr int NCH = (XL * C::CPR + 255) / 256;      // 16-byte chunks of a K / V image per thread
+    constexpr int NM = (XL * XL / 8 + 255) / 256;       // ... of the mapper
+    half8 kreg[NCH], vreg[NCH], k2reg[NCH], mreg[NM];
+    float creg = 0.f;
+    {
+        const half_t* Kb = p.K + (long long)b * p.L * p.ldk + head * D;
+        const half_t* Vb = p.V + (long long)b * p.L * p.ldv + head * D;
+        const half_t* K2b = p.K + (long long)(es >= 0 ? es : b) * p.L * p.ldk + head * D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i, row = c / C::CPR, ch = c - row * C::CPR;
+            const bool ok = c < XL * C::CPR && row < p.L;
+            kreg[i] = ok ? *(const half8*)(Kb + (long long)row * p.ldk + ch * 8) : zero8;
+            vreg[i] = ok ? *(const half8*)(Vb + (long long)row * p.ldv + ch * 8) : zero8;
+            k2reg[i] = (ok && es >= 0) ? *(const half8*)(K2b + (long long)row * p.ldk + ch * 8) : zero8;
+        }
+        if (es >= 0) {
+            const half_t* Mg = p.MT + (long long)slot * XL * XL;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int c = tid + 256 * i;
+                mreg[i] = c < XL * XL / 8 ? *(const half8*)(Mg + c * 8) : zero8;
+            }
+            if (tid < 2 * XL) creg = p.coef[(long long)slot * 2 * XL + tid];
+        }
+    }
+
     for (int i = tid; i < XL * C::KS / 8; i += 256) { ((half8*)Ks)[i] = zero8; ((half8*)Ks2)[i] = zero8; }
     for (int i = tid; i < C::DT * 32 * XS / 4; i += 256) ((half4*)Vt)[i] = (half4){0, 0, 0, 0};
     __syncthreads();
 
-    auto stage_k = [&](half_t* dst, int bsrc) {
-        const half_t* Kb = p.K + (long long)bsrc * p.L * p.ldk + head * D;
-        for (int c = tid; c < XL * C::CPR; c += 256) {
-            const int row = c / C::CPR, ch = c - row * C::CPR;
-            if (row < p.L) *(half8*)(dst + row * C::KS + ch * 8) = *(const half8*)(Kb + (long long)row * p.ldk + ch * 8);
-        }
-    };
-    stage_k(Ks, b);
-    {
-        const half_t* Vb = p.V + (long long)b * p.L * p.ldv + head * D;
-        for (int c = tid; c < XL * C::CPR; c += 256) {
-            const int row = c / C::CPR, ch = c - row * C::CPR;
-            if (row < p.L) {
-                const half8 v = *(const half8*)(Vb + (long long)row * p.ldv + ch * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * XS + row] = v[e];
-            }
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i, row = c / C::CPR, ch = c - row * C::CPR;
+        if (c < XL * C::CPR && row < p.L) {
+            *(half8*)(Ks + row * C::KS + ch * 8) = kreg[i];
+            if (es >= 0) *(half8*)(Ks2 + row * C::KS + ch * 8) = k2reg[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * XS + row] = vreg[i][e];
         }
     }
     if (es >= 0) {  // block-uniform
-        stage_k(Ks2, es);
-        const half_t* Mg = p.MT + (long long)slot * XL * XL;
-        for (int c = tid; c < XL * XL / 8; c += 256) {
-            const int row = c / (XL / 8), ch = c - row * (XL / 8);
-            const half8 v = *(const half8*)(Mg + row * XL + ch * 8);
-            *(half4*)(Ms + row * XS + ch * 8) = (half4){v[0], v[1], v[2], v[3]};
-            *(half4*)(Ms + row * XS + ch * 8 + 4) = (half4){v[4], v[5], v[6], v[7]};
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int c = tid + 256 * i;
+            if (c < XL * XL / 8) {
+                const int row = c / (XL / 8), ch = c - row * (XL / 8);
+                const half8 v = mreg[i];
+                *(half4*)(Ms + row * XS + ch * 8) = (half4){v[0], v[1], v[2], v[3]};
+                *(half4*)(Ms + row * XS + ch * 8 + 4) = (half4){v[4], v[5], v[6], v[7]};
+            }
         }
-        for (int i = tid; i < 2 * XL; i += 256) coef_s[i] = p.coef[(long long)slot * 2 * XL + i];
+        if (tid < 2 * XL) coef_s[tid] = creg;
     }
     __syncthreads();
 
