@@ -154,11 +154,20 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict_
     const int cs = c < C1 ? C1 : C2, cc = c < C1 ? c : c - C1;
     const half_t* base = src + (long long)b * HW * cs + cc;
     float s = 0.f, q = 0.f;
+    constexpr int GU = 8;        // pixels in flight per thread: loads first, arithmetic after (memory-level parallelism)
     if (live) {
-        for (int p = py; p < HW; p += PY) {
-            const half2_t v = *(const half2_t*)(base + (long long)p * cs);
-            const float a0 = (float)v[0], a1 = (float)v[1];
-            s += a0 + a1; q += a0 * a0 + a1 * a1;
+        for (int p0 = py; p0 < HW; p0 += PY * GU) {
+            half2_t v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int p = p0 + u * PY;
+                v[u] = p < HW ? *(const half2_t*)(base + (long long)p * cs) : (half2_t){0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {      // same order as a pixel-at-a-time loop: bit-identical sums
+                const float a0 = (float)v[u][0], a1 = (float)v[u][1];
+                s += a0 + a1; q += a0 * a0 + a1 * a1;
+            }
         }
     }
     __shared__ float red[2][8];
@@ -176,12 +185,23 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict_
     const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
     const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
     half_t* ob = out + (long long)b * HW * C + c;
-    for (int p = py; p < HW; p += PY) {
-        const half2_t v = *(const half2_t*)(base + (long long)p * cs);
-        float y0 = (float)v[0] * sc0 + sh0, y1 = (float)v[1] * sc1 + sh1;
-        if (apply_silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
-        half2_t o = {(half_t)y0, (half_t)y1};
-        *(half2_t*)(ob + (long long)p * C) = o;
+    for (int p0 = py; p0 < HW; p0 += PY * GU) {
+        half2_t v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int p = p0 + u * PY;
+            v[u] = p < HW ? *(const half2_t*)(base + (long long)p * cs) : (half2_t){0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int p = p0 + u * PY;
+            if (p < HW) {
+                float y0 = (float)v[u][0] * sc0 + sh0, y1 = (float)v[u][1] * sc1 + sh1;
+                if (apply_silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
+                half2_t o = {(half_t)y0, (half_t)y1};
+                *(half2_t*)(ob + (long long)p * C) = o;
+            }
+        }
     }
 }
 
