@@ -453,7 +453,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IefGemmParam
         const int m = (int)(i / N8), n = (int)(i - (long long)m * N8) * 8;
         const float* w = p.ws + (long long)m * p.N + n;
         f32x4 a0 = *(const f32x4*)w, a1 = *(const f32x4*)(w + 4);
-        for (int s = 1; s < p.splits; ++s) {
+        int s = 1;
+        for (; s + 3 < p.splits; s += 4) {      // four slabs' loads in flight, added in slab order (bit-identical sums)
+            f32x4 t0[4], t1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { t0[u] = *(const f32x4*)(w + (s + u) * slab); t1[u] = *(const f32x4*)(w + (s + u) * slab + 4); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += t0[u]; a1 += t1[u]; }
+        }
+        for (; s < p.splits; ++s) {
             a0 += *(const f32x4*)(w + s * slab);
             a1 += *(const f32x4*)(w + s * slab + 4);
         }
