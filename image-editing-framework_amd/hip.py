@@ -779,7 +779,8 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
             raise ValueError("attn_flash: lse must be fp32 [B, heads, N]")
         p.lse = lse.data_ptr()
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
-    with _Timed(f"attn_flash_kernel<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
+    kern = {1: "attn_flash_kernel", 2: "attn_flash_pp_kernel"}.get(p.variant, "attn_flash_sp_kernel")
+    with _Timed(f"{kern}<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
         _check(lib.ief_attn_flash_f16(byref(p), _stream()), "ief_attn_flash_f16")
     return out
 

@@ -19,7 +19,7 @@ _spec = importlib.util.spec_from_file_location("masactrl_edit_real",
                                                os.path.join(os.path.dirname(os.path.abspath(__file__)), "edit_real.py"))
 _mod = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_mod)          # THIS folder's edit_real.py (p2p/ has one of the same name on sys.path)
-edit_one = _mod.edit_one
+edit_one, pick = _mod.edit_one, _mod.pick
 from ief_amd.masactrl.model.sd_utils import MasaCtrl, MasaCtrl_NTI  # noqa: E402
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
@@ -47,12 +47,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=device)
     seed_everything(42)
     pipe = load_pipe(args.sd_version, device)
-    if args.inversion_type == "ddim":
-        invertor, editor = ddim_inversion(), MasaCtrl(pipe, 50)
-    elif args.inversion_type == "null-text":
-        invertor, editor = NTI(), MasaCtrl_NTI(pipe, 50)
-    else:
-        raise ValueError("Please choose right inversion type")
+    invertor, editor = pick(pipe, args.inversion_type, 50)
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor
     if args.synthetic > 0:
         root = os.path.join(args.exp_path, "_synthetic_inputs")

@@ -31,9 +31,9 @@ from _bootstrap import load_pipe, seed_everything
 from edit_real import edit_latent, edit_one
 from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE
-from ief_amd.p2p.inversion.ddim import ddim_inversion
-from ief_amd.p2p.inversion.nti import NTI
-from ief_amd.p2p.model.sd_utils import P2P, P2P_NTI
+from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL
+from ief_amd.p2p.model.sd_utils import P2P, P2P_NTI, P2P_XL, P2P_XL_NTI
 from ief_amd.p2p.utils.save_image import save_img
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
@@ -70,10 +70,15 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=device)
     seed_everything(42)
     pipe = load_pipe(args.sd_version, device)
+    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of test.py:86-104
+    if xl and (args.invert_batch > 1 or args.in_flight > 1):
+        raise NotImplementedError("--invert_batch / --in_flight on the SDXL family: run the reference's per-image order")
     if args.inversion_type == "ddim":
-        editor, invertor = P2P(model=pipe, num_inference_steps=50), ddim_inversion()
+        editor = (P2P_XL if xl else P2P)(model=pipe, num_inference_steps=50)
+        invertor = ddim_inversion_xl() if xl else ddim_inversion()
     elif args.inversion_type == "null-text":
-        editor, invertor = P2P_NTI(model=pipe, num_inference_steps=50), NTI()
+        editor = (P2P_XL_NTI if xl else P2P_NTI)(model=pipe, num_inference_steps=50)
+        invertor = NTI_XL() if xl else NTI()
     else:
         raise ValueError("Please choose right inversion type")
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor

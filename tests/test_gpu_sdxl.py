@@ -414,3 +414,24 @@ def test_local_sdxl_directory_with_clip_text_encoders(tmp_path):
     editor = P2P_XL(pipe, 3)
     images, _ = editor.text2image_ldm_stable(pipe, PROMPTS, EmptyControl(LOW_RESOURCE=False), num_inference_steps=3)
     assert images.shape == (2, cfg.sample_size * 8, cfg.sample_size * 8, 3) and images.dtype == np.uint8
+
+
+def test_xl_drivers_and_masactrl_clis(tmp_path):
+    """the `StableDiffusionXLPipeline` dispatch of the remaining scripts: masactrl/edit_real.py (MasaCtrl_XL after
+    ddim_inversion_xl) and the PIE drivers p2p/test.py, masactrl/test.py on the small XL family"""
+    import json
+    rng = np.random.RandomState(0)
+    img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / "test.jpg")
+    pkg = os.path.join(ROOT, "image-editing-framework_amd")
+    r = subprocess.run([sys.executable, os.path.join(pkg, "masactrl", "edit_real.py"), "--sd_version", "smallxl",
+                        "--inversion_type", "ddim", "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "exp" / "edit.png").exists()
+    for folder, inv in (("p2p", "null-text"), ("masactrl", "ddim")):
+        r = subprocess.run([sys.executable, os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "1",
+                            "--inversion_type", inv, "--exp_path", str(tmp_path / folder)], cwd=str(tmp_path),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (folder, r.stderr[-3000:])
+        assert json.loads(r.stdout.strip().splitlines()[-1])["images"] == 1
