@@ -368,3 +368,33 @@ def test_local_diffusers_directory_loads(tmp_path, name):
     save_file(part, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
     with pytest.raises(KeyError):
         _load_local_unet(root)
+
+
+def test_sdxl_pipeline_host_surface():
+    """`StableDiffusionXLPipeline` on the host: what the reference's `*_XL` samplers read from it
+    (`p2p/model/sd_utils.py:186-224`) — the encoder 4-tuple with ZERO negative embeddings, `_get_add_time_ids`, and the
+    `added_cond_kwargs` that `encode_prompt_xl` assembles for a CFG batch of two prompts"""
+    from ief_amd.pipeline import StableDiffusionXLPipeline
+    from ief_amd.p2p.model.sd_utils import encode_prompt_xl
+    pipe = StableDiffusionXLPipeline.from_pretrained("synthetic:smallxl", device="cpu")
+    cfg = pipe.cfg
+    assert pipe.__class__.__name__ == "StableDiffusionXLPipeline" and pipe.vae.config.scaling_factor == 0.13025
+    emb, neg, pooled, neg_pooled = pipe.encode_prompt(["a cat", "a dog on the grass"])
+    assert emb.shape == (2, 77, cfg.cross_attention_dim) and pooled.shape == (2, cfg.pooled_text_dim)
+    assert neg.abs().max() == 0 and neg_pooled.abs().max() == 0                 # force_zeros_for_empty_prompt
+    assert not torch.equal(emb[0], emb[1])
+    e2, n2, p2, np2 = pipe.encode_prompt("a cat", negative_prompt="blurry")
+    assert torch.equal(e2[0], emb[0]) and n2.abs().max() > 0 and np2.shape == (1, cfg.pooled_text_dim)
+    ids = pipe._get_add_time_ids((1024, 768), (0, 0), (1024, 768), dtype=torch.float32)
+    assert ids.tolist() == [[1024.0, 768.0, 0.0, 0.0, 1024.0, 768.0]]
+    ctx, added = encode_prompt_xl(pipe, ["a cat", "a dog on the grass"], "cpu", True, 128, 128, 2)
+    assert ctx.shape == (4, 77, cfg.cross_attention_dim) and ctx[:2].abs().max() == 0 and torch.equal(ctx[2:], emb)
+    assert added["text_embeds"].shape == (4, cfg.pooled_text_dim) and torch.equal(added["text_embeds"][2:], pooled)
+    assert added["time_ids"].shape == (4, 6) and added["time_ids"][0].tolist() == [128.0, 128.0, 0.0, 0.0, 128.0, 128.0]
+    with pytest.raises(ValueError):
+        pipe.unet.aug_embedding(None)                                            # the SDXL UNet needs its conditioning
+    sd15 = __import__("ief_amd.pipeline", fromlist=["StableDiffusionPipeline"]).StableDiffusionPipeline.from_pretrained(
+        "synthetic:tiny", device="cpu")
+    assert sd15.unet.aug_embedding(None) is None and sd15.unet.aug_embedding({"text_embeds": None}) is None
+    with pytest.raises(ValueError):
+        StableDiffusionXLPipeline.from_pretrained("synthetic:tiny", device="cpu")
