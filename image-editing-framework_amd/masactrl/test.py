@@ -20,10 +20,7 @@ _spec = importlib.util.spec_from_file_location("masactrl_edit_real",
 _mod = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_mod)          # THIS folder's edit_real.py (p2p/ has one of the same name on sys.path)
 edit_one, pick = _mod.edit_one, _mod.pick
-from ief_amd.masactrl.model.sd_utils import MasaCtrl, MasaCtrl_NTI  # noqa: E402
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
-from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]

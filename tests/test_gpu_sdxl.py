@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from ief_amd import config, hip, weights  # noqa: E402
+from ief_amd import config, weights  # noqa: E402
 from ief_amd.pipeline import StableDiffusionPipeline  # noqa: E402
 from oracle import unet_ref  # noqa: E402
 
