@@ -398,3 +398,28 @@ def test_sdxl_pipeline_host_surface():
     assert sd15.unet.aug_embedding(None) is None and sd15.unet.aug_embedding({"text_embeds": None}) is None
     with pytest.raises(ValueError):
         StableDiffusionXLPipeline.from_pretrained("synthetic:tiny", device="cpu")
+
+
+def test_producer_statistics_are_only_requested_where_they_are_valid():
+    """host rule for `IefGemmParams.cstat_out` (GroupNorm statistics from the producer): only NHWC outputs of a level with
+    >= 1024 pixels per image, never with split-K or the GEGLU epilogue, and only when no M tile straddles two images"""
+    lib = hip.load()
+    assert [lib.ief_gemm_tile_bm(t) for t in range(1, 10)] == [128, 64, 64, 128, 64, 128, 128, 256, 128]
+    assert lib.ief_gemm_tile_bm(0) == 0 and lib.ief_map_loss_blocks(4096, 40) == 16 and lib.ief_map_loss_blocks(256, 160) == 4
+
+    def ask(tile, splits, flags, M, N, hw):
+        p = hip.IefGemmParams()
+        p.tile_hint, p.splits, p.flags = tile, splits, flags
+        out = torch.empty(M, N, dtype=torch.float16)
+        cs = hip._attach_cstat(lib, p, out, M, N, hw)
+        return cs, getattr(out, "_cstat", None), p.cstat_out
+
+    cs, att, ptr = ask(7, 1, 1, 4 * 4096, 320, 4096)
+    assert cs.shape == (4 * 4096 // 128, 320, 2) and att[1:] == (128, 4096) and ptr == cs.data_ptr()
+    for bad in ((7, 2, 1, 16384, 320, 4096),        # split-K: the reducer writes the output
+                (7, 1, 3, 16384, 320, 4096),        # GEGLU epilogue
+                (7, 1, 1, 4 * 256, 1280, 256),      # a small level: the single-launch GroupNorm is already one launch
+                (8, 1, 1, 4 * 1600, 320, 1600),     # 40x40 latents: a 256-row tile would straddle two images
+                (7, 1, 1, 1000, 320, None)):        # not an NHWC activation
+        cs, att, ptr = ask(*bad)
+        assert cs is None and att is None and not ptr, bad
