@@ -269,3 +269,43 @@ def test_masactrl_mutual_rule_mirror_vs_einops_vs_oracle():
     plain = c2(q, k, v, sim, sim.softmax(-1), False, "up", heads, scale=scale)
     ref = torch.bmm(sim.softmax(-1), v).reshape(B, heads, n, d).permute(0, 2, 1, 3).reshape(B, n, heads * d)
     assert torch.allclose(plain, ref, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ G9 / G10: SDXL-family inversion loops
+def test_oracle_xl_inversion_and_nti_match_reference(golden_dir):
+    """`ddim_inversion_xl.ddim_inversion_loop` and `NTI_XL.null_optimization` of the reference
+    (`/root/reference/pix2pix-zero/inversion/{ddim,nti}.py:60-96`, imported by `tests/golden/make_golden_xl.py`) on a toy
+    UNet that reads `added_cond_kwargs`: the oracle's loops with `added_cond / added_uncond`, lr = 5e-2 and `restart`
+    must reproduce them — which kwargs go to which call, the restart from the (zero) negative embedding at every
+    timestep, the lr schedule and the early stop"""
+    z = np.load(os.path.join(golden_dir, "nti_xl.npz"))
+    w1, w2, w3 = (torch.from_numpy(z[k]) for k in ("w1", "w2", "w3"))
+
+    def toy(sd, cfg, x, t, ctx, added_cond_kwargs=None, **kw):
+        c = (ctx @ w2).mean(1) + added_cond_kwargs["text_embeds"] @ w3 + 1e-4 * added_cond_kwargs["time_ids"].sum(-1, keepdim=True)
+        return torch.tanh(torch.einsum("bchw,cd->bdhw", x, w1) + c[:, :, None, None] + float(t) * 1e-3)
+
+    sched = p2p_ref.DDIMRef(5)
+    assert np.array_equal(sched.timesteps.numpy(), z["timesteps"])
+    emb, pooled = torch.from_numpy(z["emb"]), torch.from_numpy(z["pooled"])
+    ids = torch.tensor([[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]])
+    a_c = {"text_embeds": pooled, "time_ids": ids}
+    a_u = {"text_embeds": torch.zeros_like(pooled), "time_ids": ids}
+    saved = p2p_ref.unet_ref.unet_forward
+    p2p_ref.unet_ref.unet_forward = toy
+    try:
+        lat = p2p_ref.ddim_inversion_loop(None, None, emb, torch.from_numpy(z["x0"]), sched, added_cond_kwargs=a_c)
+        got_lat = np.stack([l.numpy() for l in lat])
+        assert got_lat.shape == z["inv_latents"].shape and np.allclose(got_lat, z["inv_latents"], atol=1e-6)
+        ctx = torch.cat([torch.zeros_like(emb), emb])
+        out = p2p_ref.null_optimization(None, None, [torch.from_numpy(a) for a in z["inv_latents"]], ctx, sched, 10, 1e-5, 7.5,
+                                        added_cond=a_c, added_uncond=a_u, lr=5e-2, restart=True)
+        got = np.stack([u.numpy() for u in out])
+        assert got.shape == z["nti_uncond"].shape and np.allclose(got, z["nti_uncond"], atol=1e-6)
+        # the knobs matter: without the restart, or with the SD1.x learning rate, the trajectory is a different one
+        for kw in (dict(lr=5e-2, restart=False), dict(lr=1e-2, restart=True)):
+            other = p2p_ref.null_optimization(None, None, [torch.from_numpy(a) for a in z["inv_latents"]], ctx, sched, 10, 1e-5,
+                                              7.5, added_cond=a_c, added_uncond=a_u, **kw)
+            assert not np.allclose(np.stack([u.numpy() for u in other]), z["nti_uncond"], atol=1e-4)
+    finally:
+        p2p_ref.unet_ref.unet_forward = saved
