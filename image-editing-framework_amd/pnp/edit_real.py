@@ -12,10 +12,10 @@ from PIL import Image
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "p2p"))
 from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
-from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
+from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI  # noqa: E402
-from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL  # noqa: E402
+from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI, PnP_XL, PnP_XL_NTI  # noqa: E402
 
 parser = argparse.ArgumentParser("General config")
 parser.add_argument("--sd_version", type=str, default="1.5")
@@ -40,8 +40,13 @@ def main(argv=None):
     out_path = "./exp"
     pipe = load_pipe(args.sd_version, device)
     size = pipe.unet.config.sample_size * pipe.vae_scale_factor
-    invertor = NTI() if nti else ddim_inversion()
-    editor = (PnP_NTI if nti else PnP)(pipe, num_inference_steps)
+    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # the XL branch of the reference's dispatch
+    if xl:
+        invertor = NTI_XL() if nti else ddim_inversion_xl()
+        editor = (PnP_XL_NTI if nti else PnP_XL)(pipe, num_inference_steps)
+    else:
+        invertor = NTI() if nti else ddim_inversion()
+        editor = (PnP_NTI if nti else PnP)(pipe, num_inference_steps)
     os.makedirs(out_path, exist_ok=True)
     original_image = Image.open(args.source_image).convert("RGB").resize((size, size))
     original_image.save(os.path.join(out_path, "source.png"))

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.pnp.model.sd_utils import PnP  # noqa: E402
+from ief_amd.pnp.model.sd_utils import PnP, PnP_XL  # noqa: E402
 
 parser = argparse.ArgumentParser("General config")
 parser.add_argument("--sd_version", type=str, default="1.5")
@@ -30,7 +30,8 @@ def main(argv=None):
     pnp_attn_t, pnp_f_t = 1.0, 1.0
     out_path = "./exp"
     pipe = load_pipe(args.sd_version, device)
-    editor = PnP(pipe, num_inference_steps)
+    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of edit_syn.py:88-91
+    editor = (PnP_XL if xl else PnP)(pipe, num_inference_steps)
     os.makedirs(out_path, exist_ok=True)
     images = editor(prompt=[args.source_prompt] + [args.target_prompt], num_inference_steps=num_inference_steps,
                     guidance_scale=GUIDANCE_SCALE, pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t)

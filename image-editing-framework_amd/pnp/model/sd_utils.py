@@ -14,12 +14,15 @@ import numpy as np
 import torch
 
 from ...denoise import acquire, run_interleaved
-from ...p2p.model.sd_utils import _encode_prompts
-from .register import (register_attention_control_efficient, register_conv_control_efficient, register_time,
+from ...p2p.model.sd_utils import _encode_prompts, encode_prompt_xl
+from .register import (register_attention_control_efficient, register_attention_control_efficient_xl,
+                       register_conv_control_efficient, register_conv_control_efficient_xl, register_time,
                        unregister_attention_control_efficient, unregister_conv_control_efficient)
 
 
 class PnP:
+    xl = False
+
     def __init__(self, pipeline, num_inference_steps) -> None:
         self.model = pipeline
         self.model.scheduler.set_timesteps(num_inference_steps)
@@ -28,8 +31,12 @@ class PnP:
         ts = self.model.scheduler.timesteps
         self.qk_injection_timesteps = ts[:qk_injection_t] if qk_injection_t >= 0 else []
         self.conv_injection_timesteps = ts[:conv_injection_t] if conv_injection_t >= 0 else []
-        register_attention_control_efficient(self.model, self.qk_injection_timesteps)
-        register_conv_control_efficient(self.model, self.conv_injection_timesteps)
+        if self.xl:       # `PnP_XL.init_pnp` (:131-136)
+            register_attention_control_efficient_xl(self.model, self.qk_injection_timesteps)
+            register_conv_control_efficient_xl(self.model, self.conv_injection_timesteps)
+        else:
+            register_attention_control_efficient(self.model, self.qk_injection_timesteps)
+            register_conv_control_efficient(self.model, self.conv_injection_timesteps)
 
     @torch.no_grad()
     def __call__(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
@@ -43,7 +50,12 @@ class PnP:
         width = width or model.unet.config.sample_size * model.vae_scale_factor
         prompt = [prompt] if isinstance(prompt, str) else list(prompt)
         batch_size = len(prompt)
-        uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+        added_cond_kwargs = None
+        if self.xl:       # `PnP_XL.__call__` (:175): both text encoders, pooled embedding and time ids
+            emb, added_cond_kwargs = encode_prompt_xl(model, prompt, dev, True, height, width, batch_size)
+            uncond_embeddings, text_embeddings = emb[:batch_size], emb[batch_size:]
+        else:
+            uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
         C = model.unet.config.in_channels
         if latents is None:
             latents = torch.randn((1, C, height // 8, width // 8), dtype=torch.float32)     # CPU generator, see p2p
@@ -58,7 +70,8 @@ class PnP:
                 context = text_embeddings
             # `PnP_NTI`: `prompt_embeds[0:2] = uncond_embeddings_list[i]` every step (:340) = per-step unconditional rows
             loop = acquire(model, context, batch_size, (height // 8, width // 8), g, use_graph=use_graph,
-                           uncond_list=uncond_embeddings_list)
+                           uncond_list=uncond_embeddings_list,
+                           added_cond_kwargs=added_cond_kwargs if g is not None else None)
             try:
                 if use_graph:
                     latents = loop.run(latents)
@@ -89,6 +102,8 @@ class PnP:
         dev = model.unet.device
         if not guidance_scale > 1.0:
             raise NotImplementedError("PnP.edit_many: classifier-free guidance is what the reference's drivers run")
+        if self.xl:
+            raise NotImplementedError("PnP.edit_many on the SDXL family: run the sampler once per image")
         model.scheduler.set_timesteps(num_inference_steps)
         height = height or model.unet.config.sample_size * model.vae_scale_factor
         width = width or model.unet.config.sample_size * model.vae_scale_factor
@@ -128,6 +143,19 @@ class PnP:
             image = image.cpu().permute(0, 2, 3, 1).numpy()
             image = (image * 255).astype(np.uint8)
         return image
+
+
+class PnP_XL(PnP):
+    """`PnP_XL` (`/root/reference/pnp/model/sd_utils.py:130-258`): the sampler on an SDXL-family pipeline — the `_xl`
+    injection sites of `model/register.py` and the `added_cond_kwargs` of `encode_prompt_xl`."""
+    xl = True
+
+    def encode_prompt_xl(self, prompt, device, do_classifier_free_guidance, height, width, batch_size):
+        return encode_prompt_xl(self.model, prompt, device, do_classifier_free_guidance, height, width, batch_size)
+
+
+class PnP_XL_NTI(PnP_XL):
+    """`PnP_XL_NTI` (:360-): `PnP_XL` with the per-step unconditional embeddings of `NTI_XL` on both unconditional rows."""
 
 
 class PnP_NTI(PnP):
