@@ -15,7 +15,7 @@ from ief_amd.masactrl.model.attention_control import MutualSelfAttentionControl 
 from ief_amd.masactrl.model.register import regiter_attention_editor_diffusers, unregister_attention_control  # noqa: E402
 from ief_amd.masactrl.model.sd_utils import MasaCtrl, MasaCtrl_NTI, MasaCtrl_XL, MasaCtrl_XL_NTI  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI, NTI_XL  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL_5e2 as NTI_XL  # noqa: E402  (this folder's copy: lr 5e-2)
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
 
 parser = argparse.ArgumentParser("General config")

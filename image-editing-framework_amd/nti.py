@@ -22,7 +22,8 @@ from .grad import UNetAdjoint
 
 class NullTextOptimizer:
     def __init__(self, model, cond: torch.Tensor, guidance_scale: float, latent_hw, grad_scale: float = 1.0,
-                 use_graph: bool = True, added_cond=None, added_uncond=None, lr: float = 1e-2, restart: bool = False):
+                 use_graph: bool = True, added_cond=None, added_uncond=None, lr: float = 1e-2, restart: bool = False,
+                 lr_decay: float = 100.0):
         """added_cond / added_uncond, lr, restart: `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`) — the
         conditional and unconditional UNet calls take their own SDXL `added_cond_kwargs` (folded into two tables of
         per-step time-embedding rows), lr = 5e-2, and the embedding restarts from its initial value every timestep."""
@@ -54,7 +55,7 @@ class NullTextOptimizer:
             self.temb_c = torch.zeros_like(self.temb)
         else:
             self.temb_table_c, self.temb_c = self.temb_table, self.temb
-        self.lr, self.restart = float(lr), bool(restart)
+        self.lr, self.restart, self.lr_decay = float(lr), bool(restart), float(lr_decay)      # lr_i = lr (1 - i / lr_decay)
         self.cond16 = hip.to_f16(cond.to(dev).float().contiguous())
         L, Cc = self.cond16.shape[1:]
         self.param = torch.zeros(1, L, Cc, **f32)
@@ -135,7 +136,7 @@ class NullTextOptimizer:
         self.coef.copy_(self.coef_table[i])
         self.target.copy_(latents[len(latents) - i - 2].to(self.dev).float())
         self.m.zero_(), self.v.zero_(), self.adam_step.zero_()          # `Adam([uncond], lr=...)` anew (nti.py:17)
-        self.hyper[0:1].fill_(self.lr * (1.0 - i / 100.0))
+        self.hyper[0:1].fill_(self.lr * (1.0 - i / self.lr_decay))
         self._run(0)
         self._done, self._loss = 0, float("nan")
 

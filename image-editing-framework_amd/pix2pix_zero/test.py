@@ -21,7 +21,7 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI, NTI_XL  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL_5e2 as NTI_XL  # noqa: E402  (this folder's copy: lr 5e-2)
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
 from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI, P2P_Zero_XL, P2P_Zero_XL_NTI  # noqa: E402
 

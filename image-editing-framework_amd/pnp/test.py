@@ -21,7 +21,7 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
 from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
-from ief_amd.p2p.inversion.nti import NTI, NTI_XL  # noqa: E402
+from ief_amd.p2p.inversion.nti import NTI, NTI_XL_5e2 as NTI_XL  # noqa: E402  (this folder's copy: lr 5e-2)
 from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI, PnP_XL, PnP_XL_NTI  # noqa: E402
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]

@@ -167,9 +167,10 @@ def ddim_inversion_loop(sd, cfg, cond_emb, latent, sched: DDIMRef, num_steps: Op
 def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps: int = 10,
                       epsilon: float = 1e-5, guidance_scale: float = 7.5,
                       num_outer: Optional[int] = None, added_cond=None, added_uncond=None, lr: float = 1e-2,
-                      restart: bool = False):
+                      restart: bool = False, lr_decay: float = 100.0):
     """`/root/reference/p2p/inversion/nti.py:9-45` with the oracle UNet as `model.unet`.
-    `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`) is the same loop with lr = 5e-2 (:69), the embedding
+    `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`; the masactrl and pnp folders hold the same file, the
+    p2p folder's copy uses lr = 0.5 (1 - i / 500), `p2p/inversion/nti.py:50,69`) is the same loop with lr = 5e-2 (:69), the embedding
     RESTARTED from the negative prompt embedding at every timestep (:67, `restart`), and the conditional / unconditional
     UNet calls taking their own `added_cond_kwargs` (:58-61,74,76,90-92)."""
     from torch.optim.adam import Adam
@@ -186,7 +187,7 @@ def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps
     for i in range(n):
         uncond = (uncond0 if restart else uncond).clone().detach()
         uncond.requires_grad = True
-        opt = Adam([uncond], lr=lr * (1.0 - i / 100.0))
+        opt = Adam([uncond], lr=lr * (1.0 - i / lr_decay))
         prev = latents[len(latents) - i - 2]
         t = sched.timesteps[i]
         with torch.no_grad():

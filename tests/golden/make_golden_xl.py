@@ -88,6 +88,15 @@ def main():
     out["timesteps"] = sched.timesteps.numpy()
     out["inv_latents"] = np.stack([l.numpy() for l in lat])
     out["nti_uncond"] = np.stack([u.numpy() for u in lst])
+    # G11: the P2P folder's copy of NTI_XL (`/root/reference/p2p/inversion/nti.py:47-96`): lr = 0.5 (1 - i / 500)
+    import importlib.util
+    for mod in ("inversion.ddim", "inversion.nti", "inversion"):
+        sys.modules.pop(mod, None)
+    sys.path[0] = "/root/reference/p2p"
+    from inversion import nti as p2p_nti  # noqa: E402
+    assert p2p_nti.__file__.startswith("/root/reference/p2p/")
+    lst2 = p2p_nti.NTI_XL().null_optimization(model, lat, context, 10, 1e-5, 7.5, height=64, width=64)
+    out["nti_uncond_p2p"] = np.stack([u.numpy() for u in lst2])
     np.savez_compressed(os.path.join(HERE, "nti_xl.npz"), **out)
     print("nti_xl.npz", {k: v.shape for k, v in out.items()})
 

@@ -302,6 +302,11 @@ def test_oracle_xl_inversion_and_nti_match_reference(golden_dir):
                                         added_cond=a_c, added_uncond=a_u, lr=5e-2, restart=True)
         got = np.stack([u.numpy() for u in out])
         assert got.shape == z["nti_uncond"].shape and np.allclose(got, z["nti_uncond"], atol=1e-6)
+        # G11: the P2P folder's copy of NTI_XL: lr = 0.5 (1 - i / 500)
+        out2 = p2p_ref.null_optimization(None, None, [torch.from_numpy(a) for a in z["inv_latents"]], ctx, sched, 10, 1e-5, 7.5,
+                                         added_cond=a_c, added_uncond=a_u, lr=0.5, lr_decay=500.0, restart=True)
+        assert np.allclose(np.stack([u.numpy() for u in out2]), z["nti_uncond_p2p"], atol=1e-5)
+        assert not np.allclose(z["nti_uncond_p2p"], z["nti_uncond"], atol=1e-3)
         # the knobs matter: without the restart, or with the SD1.x learning rate, the trajectory is a different one
         for kw in (dict(lr=5e-2, restart=False), dict(lr=1e-2, restart=True)):
             other = p2p_ref.null_optimization(None, None, [torch.from_numpy(a) for a in z["inv_latents"]], ctx, sched, 10, 1e-5,
