@@ -423,3 +423,30 @@ def test_producer_statistics_are_only_requested_where_they_are_valid():
                 (7, 1, 1, 1000, 320, None)):        # not an NHWC activation
         cs, att, ptr = ask(*bad)
         assert cs is None and att is None and not ptr, bad
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/masactrl"), reason="reference checkout not present")
+def test_reference_masactrl_registration_walks_our_tree(cpu_unet):
+    """the reference's own `masactrl/model/register.py` finds and patches our Attention modules, counts them, and its
+    `unregister_attention_control` leaves them native again (drop-in editor API of the MasaCtrl folder)"""
+    import importlib.util
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, "/root/reference/masactrl")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "model" or k.startswith("model.")}
+    try:
+        spec = importlib.util.spec_from_file_location("ref_masa_register", "/root/reference/masactrl/model/register.py")
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        editor = ref.AttentionBase()
+        model = SimpleNamespace(unet=cpu_unet)
+        ref.regiter_attention_editor_diffusers(model, editor)
+        assert editor.num_att_layers == len(cpu_unet.attention_modules()) == 32
+        assert not any(m.is_native() for m in cpu_unet.attention_modules())
+        ref.unregister_attention_control(model, editor)
+        assert editor.num_att_layers == 0 and all(m.is_native() for m in cpu_unet.attention_modules())
+    finally:
+        sys.path.remove("/root/reference/masactrl")
+        for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)

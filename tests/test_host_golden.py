@@ -314,3 +314,33 @@ def test_oracle_xl_inversion_and_nti_match_reference(golden_dir):
             assert not np.allclose(np.stack([u.numpy() for u in other]), z["nti_uncond"], atol=1e-4)
     finally:
         p2p_ref.unet_ref.unet_forward = saved
+
+
+# ------------------------------------------------------------------------------------ G12: MasaCtrl hooked attention
+def test_oracle_attention_matches_reference_masactrl_hook(golden_dir):
+    """the reference's `masactrl/model/register.py` hooked forward + `AttentionBase.forward` on a toy tree of Attention
+    modules (`tests/golden/make_golden_masa.py`): the oracle's `unet_ref.attention` — head split, scale, softmax, output
+    projection, self and cross — reproduces every module's output; the layer count and the editor's counters are the ones
+    the product's `AttentionBase` keeps"""
+    from oracle import unet_ref
+    from ief_amd.masactrl.model.attention_base import AttentionBase
+    z = np.load(os.path.join(golden_dir, "masactrl_register.npz"))
+    x, ctx = torch.from_numpy(z["x"]), torch.from_numpy(z["ctx"])
+    assert int(z["num_att_layers"]) == 8 and int(z["cur_step_after_8_calls"]) == 1 and int(z["cur_att_layer_after_8_calls"]) == 0
+    worst = 0.0
+    for name in ("down0", "down1", "mid", "up0"):
+        for kind in ("attn1", "attn2"):
+            p = f"{name}.{kind}"
+            sd = {f"{p}.{w}": torch.from_numpy(z[f"{p}.{w}"]) for w in ("to_q.weight", "to_k.weight", "to_v.weight",
+                                                                         "to_out.0.weight", "to_out.0.bias")}
+            got = unet_ref.attention(sd, p, x, ctx if kind == "attn2" else None, int(z[f"{p}.heads"]), None, name)
+            worst = max(worst, (got - torch.from_numpy(z[f"{p}.out"])).abs().max().item())
+    assert worst < 1e-5, worst
+    # the product's editor base class counts like the reference's (8 calls of an 8-layer net = one step)
+    e = AttentionBase()
+    e.num_att_layers = 8
+    q = torch.randn(4, 16, 32)
+    attn = torch.softmax(torch.randn(4, 16, 16), -1)
+    for _ in range(8):
+        e(q, q, q, None, attn, False, "down", 2)
+    assert e.cur_step == 1 and e.cur_att_layer == 0
