@@ -272,21 +272,23 @@ def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
     achieved = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
     # this process; see profiles/r01_pmc_traffic.json for the command and the gfx950 FETCH_SIZE correction)
-    traffic = None
+    traffic, traffic_detail = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pmc = json.load(f)
         hit = [v for k, v in pmc.items() if not k.startswith("_") and v.get("family") == name]
-        if hit:
-            traffic = {"hbm_bytes_per_launch": hit[0]["hbm_bytes"], "algorithmic_bytes_per_launch": hit[0]["algorithmic_bytes"],
-                       "shape": hit[0]["shape"], "source": "profiles/r01_pmc_traffic.json"}
+        if hit:      # `traffic` = HBM bytes per launch of the family's most frequent member (PMC passes), details beside it
+            traffic = hit[0]["hbm_bytes"]
+            traffic_detail = {"algorithmic_bytes_per_launch": hit[0]["algorithmic_bytes"], "shape": hit[0]["shape"],
+                              "source": "profiles/r01_pmc_traffic.json"}
     except (OSError, ValueError, KeyError):
         traffic = None
     return {
         "bound": "mfma", "kernel": name, "launches_per_step": n,
         "avg_launch_ms": round(ms / n, 4), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
         "achieved": round(achieved, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
-        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic,
+        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+        "traffic_detail": traffic_detail,
         "kernel_share_of_step": round(ms / total_ms, 3),
         "whole_step": {"alg_tflop_per_step": round(alg_flop / 1e12, 3), "survey_tflop_per_step_512px": FLOP_PER_STEP / 1e12,
                        "achieved": round(steps_per_sec / world * alg_flop / 1e12, 2),
