@@ -239,6 +239,7 @@ _CSTAT_MIN_HW = 1024
 
 def _attach_cstat(lib, p, out, M, N, hw):
     """decide whether this launch emits column statistics; returns the scratch tensor to keep alive (or None)"""
+    out.__dict__.pop("_cstat", None)          # a re-used output buffer must not keep the statistics of an earlier launch
     if not GN_CSTAT or hw is None or hw < _CSTAT_MIN_HW or p.splits > 1 or (p.flags & 2) or AUTOTUNE:
         return None
     bm = lib.ief_gemm_tile_bm(p.tile_hint)

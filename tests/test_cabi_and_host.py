@@ -423,6 +423,14 @@ def test_producer_statistics_are_only_requested_where_they_are_valid():
                 (7, 1, 1, 1000, 320, None)):        # not an NHWC activation
         cs, att, ptr = ask(*bad)
         assert cs is None and att is None and not ptr, bad
+    # a re-used output buffer loses the statistics of an earlier launch when the next one does not produce any
+    out = torch.empty(16384, 320, dtype=torch.float16)
+    p = hip.IefGemmParams()
+    p.tile_hint, p.splits, p.flags = 7, 1, 1
+    assert hip._attach_cstat(lib, p, out, 16384, 320, 4096) is not None and out._cstat is not None
+    p2 = hip.IefGemmParams()
+    p2.tile_hint, p2.splits, p2.flags = 7, 4, 1
+    assert hip._attach_cstat(lib, p2, out, 16384, 320, 4096) is None and getattr(out, "_cstat", None) is None
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/masactrl"), reason="reference checkout not present")
