@@ -765,6 +765,9 @@ def _attn_common(p, q, k, v, out, heads):
     p.ldq, p.ldk, p.ldv, p.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
 
 
+_FLASH_VARIANT_ENV = int(os.environ.get("IEF_FLASH_VARIANT", "0"))      # read once: which flash kernel variant 0 means
+
+
 def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None, variant=0):
     """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok).
     lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes."""
@@ -774,7 +777,7 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     p = IefAttnParams()
     _attn_common(p, q, k, v, out, heads)
     p.scale = scale
-    p.variant = variant if variant else int(os.environ.get("IEF_FLASH_VARIANT", 0))     # env: A/B runs only
+    p.variant = variant if variant else _FLASH_VARIANT_ENV                              # env: A/B runs only
     if lse is not None:
         if tuple(_dev32(lse, "lse").shape) != (q.shape[0], heads, q.shape[1]):
             raise ValueError("attn_flash: lse must be fp32 [B, heads, N]")
