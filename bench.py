@@ -140,18 +140,16 @@ def main():
             room = MAX_STEPS - ctrl.cur_step
             if room == 0:
                 ctrl.reset()
-                loop.plan.sync_step()
-                loop.step.zero_()
+                loop.rewind()
                 room = MAX_STEPS
             k = min(room, n - done)
             for _ in range(k):
-                loop.graph.replay()
-                loop.plan.replay_done()
+                loop.step_once()
             done += k
 
     loop.run(x_T, num_steps=0)          # allocates, warms up eagerly (untimed) and captures the graph
     run_steps(args.warmup)
-    ctrl.reset(); loop.plan.sync_step(); loop.step.zero_(); loop.lat.copy_(x_T.expand_as(loop.lat))
+    ctrl.reset(); loop.rewind(x_T)
 
     def barrier():
         if dist is not None:
@@ -221,7 +219,7 @@ def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_lis
         loops.append(lp); ctrls.append(c)
     run_interleaved(loops, 4)
     for lp, c in zip(loops, ctrls):
-        c.reset(); lp.plan.sync_step(); lp.step.zero_(); lp.lat.copy_(x_T.expand_as(lp.lat))
+        c.reset(); lp.rewind(x_T)
     barrier()
     t0 = time.perf_counter()
     run_interleaved(loops, steps)

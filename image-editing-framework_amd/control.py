@@ -156,7 +156,9 @@ class ControlPlan:
             return ("masactrl", tuple(sorted(self.masa_layers)), (max(self.masa_steps) + 2) if self.masa_steps else 1)
         if self.kind == "pnp":
             idx = {id(m): m._exec_index for m in unet.attention_modules()}
-            inj = unet.up_blocks[1].resnets[1]._inject is self if len(unet.up_blocks) > 1 else False
+            # the injected resnet as `pnp/model/register.py:_conv_module` picks it: resnets[0] on the SDXL family, else [1]
+            inj = (unet.up_blocks[1].resnets[0 if unet.cfg.addition_embed else 1]._inject is self
+                   if len(unet.up_blocks) > 1 else False)
             return ("pnp", tuple(sorted(idx[i] for i in self.pnp_layers)), self.num_steps, bool(inj))
         return (self.kind,)
 

@@ -243,20 +243,26 @@ extern "C" int ief_cast_f16_to_f32(const ief_half* x, float* out, long long n, v
 // out[:] = table[step[0]][:]   (4-byte words).  Step-dependent inputs of the UNet (time-embedding
 // projections, P2P gate coefficients, self-replace source maps, DDIM alphas) live in per-step
 // tables; this copy runs INSIDE the captured graph and reads the step index from device memory.
+// The row index is clamped to [0, n_rows - 1]: a replay past the end of a schedule re-reads the last row (tables keep an
+// identity / final row there) instead of reading beyond the allocation.
 __global__ __launch_bounds__(256) void select_step_kernel(const uint32_t* __restrict__ table, uint32_t* __restrict__ out,
-                                                          const int* __restrict__ step, long long words) {
-    const long long base = (long long)step[0] * words;
+                                                          const int* __restrict__ step, long long words, int n_rows) {
+    int row = step[0];
+    row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+    const long long base = (long long)row * words;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256)
         out[i] = table[base + i];
 }
-extern "C" int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, void* stream) {
+extern "C" int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, int n_rows,
+                               void* stream) {
     if (!table || !out || !step) return IEF_EINVAL;
+    if (n_rows <= 0) return IEF_ESHAPE;
     if (bytes_per_step <= 0 || (bytes_per_step & 3)) return IEF_EALIGN;
     const long long words = bytes_per_step / 4;
     int grid = (int)((words + 255) / 256);
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(select_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)table,
-                       (uint32_t*)out, step, words);
+                       (uint32_t*)out, step, words, n_rows);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

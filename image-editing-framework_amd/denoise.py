@@ -57,6 +57,7 @@ class FusedDenoiser:
         self.graph = None
         self.plan = self.unet._plan
         self._keep, self._pooled_started, self._pool_key = None, False, None
+        self._done = 0          # steps taken since the last rewind (host mirror of the device step counter)
 
     def _fill(self, context, guidance_scale, uncond_list, added_cond_kwargs=None):
         """(re)compute every table the step graph reads, IN PLACE once the buffers exist (re-use of a captured loop)"""
@@ -115,6 +116,7 @@ class FusedDenoiser:
             self.plan.load_from(fresh, self.B)
             self.plan.sync_step()
         self.step.zero_()
+        self._done = 0
 
     # ------------------------------------------------------------------ one step, stream-ordered
     def _step_body(self):
@@ -174,6 +176,7 @@ class FusedDenoiser:
         need the registration, so several started loops can be stepped in turn (`run_interleaved`)."""
         self.lat.copy_(latents.to(self.lat.device).float().expand_as(self.lat))
         self.step.zero_()
+        self._done = 0
         if self.use_graph and self.graph is None:
             self._capture()
         elif not self.use_graph:
@@ -186,7 +189,22 @@ class FusedDenoiser:
         if self.plan is not None and self.graph is not None:
             self.plan.sync_step()
 
+    def rewind(self, latents: Optional[torch.Tensor] = None):
+        """back to step 0 of the schedule (device and host counters, the plan's counter from its controller)"""
+        if latents is not None:
+            self.lat.copy_(latents.to(self.lat.device).float().expand_as(self.lat))
+        self.step.zero_()
+        self._done = 0
+        if self.plan is not None:
+            self.plan.sync_step()
+
     def step_once(self):
+        # the per-step tables have num_steps rows: a replay past them would re-read the last row (the kernel clamps the row
+        # index) and silently apply the final timestep again
+        if self._done >= self.num_steps:
+            raise IndexError(f"step {self._done} is past the {self.num_steps}-step schedule this loop was built for; "
+                             "rewind() or start() it first")
+        self._done += 1
         if self.graph is not None:
             self.graph.replay()
             if self.plan is not None:

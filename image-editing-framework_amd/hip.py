@@ -12,6 +12,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_longlo
 import torch
 
 # IEF_HIP_LIB / IEF_PLAN_FILE: A/B two builds of the library (and their tuned tables) on one GPU box
+ABI_VERSION = 2   # include/ief_hip.h IEF_ABI_VERSION
 _LIB_PATH = os.environ.get("IEF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libief_hip.so")
 _lib = None
 
@@ -129,7 +130,7 @@ def load():
     lib.ief_silu_f16.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_cast_f32_to_f16.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_cast_f16_to_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
-    lib.ief_select_step.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_select_step.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p]
     lib.ief_advance_step.argtypes = [c_void_p, c_void_p]
     lib.ief_add_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_softmax_rows_f16.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -156,7 +157,7 @@ def load():
     lib.ief_nti_loss_grad_f32.argtypes = [c_void_p] * 7 + [c_int, c_float, c_void_p]
     lib.ief_nti_adam_f32.argtypes = [c_void_p] * 8 + [c_int, c_void_p]
     lib.ief_gather_rows_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]
-    if lib.ief_abi_version() != 1:
+    if lib.ief_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
     for which, st in enumerate((IefGemmParams, IefAttnParams, IefCrossParams, IefAttnBwdParams)):
@@ -230,16 +231,29 @@ class _Timed:
 
 
 # GroupNorm statistics from the producer: a conv / 1x1-projection launch whose output is an NHWC activation of a level with
-# at least this many pixels per image leaves per-tile column sums next to it (`out._cstat`); `groupnorm` uses them when the
-# input would otherwise take the three-launch path.  The attribute lives on the tensor OBJECT the producer returns: a
-# view / reshape drops it and the consumer falls back to computing the statistics itself, it can never read stale ones.
+# at least this many pixels per image can leave per-tile column sums next to it (`col_stats=True` -> `(out, ColStats)`);
+# the caller hands that object to the `groupnorm` that consumes the output (`cstat=` / `cstat2=`), which then folds the
+# sums instead of running its own statistics pass.  The hand-off is an explicit value travelling beside the tensor it
+# describes: nothing is attached to tensor objects, so a buffer re-written by any other launch cannot be paired with
+# statistics of its earlier contents unless the caller itself keeps passing the old object.
 GN_CSTAT = os.environ.get("IEF_GN_CSTAT", "1") == "1"
 _CSTAT_MIN_HW = 1024
 
 
+class ColStats:
+    """(sum, sum of squares) per M tile and output channel of ONE launch's fp16 output (IefGemmParams.cstat_out)"""
+    __slots__ = ("buf", "bm", "hw", "ptr", "numel")
+
+    def __init__(self, buf, bm, hw, out):
+        self.buf, self.bm, self.hw = buf, bm, hw
+        self.ptr, self.numel = out.data_ptr(), out.numel()
+
+    def describes(self, t) -> bool:
+        return t.data_ptr() == self.ptr and t.numel() == self.numel
+
+
 def _attach_cstat(lib, p, out, M, N, hw):
-    """decide whether this launch emits column statistics; returns the scratch tensor to keep alive (or None)"""
-    out.__dict__.pop("_cstat", None)          # a re-used output buffer must not keep the statistics of an earlier launch
+    """decide whether this launch emits column statistics; returns the ColStats (owning the scratch tensor) or None"""
     if not GN_CSTAT or hw is None or hw < _CSTAT_MIN_HW or p.splits > 1 or (p.flags & 2) or AUTOTUNE:
         return None
     bm = lib.ief_gemm_tile_bm(p.tile_hint)
@@ -247,8 +261,7 @@ def _attach_cstat(lib, p, out, M, N, hw):
         return None
     cs = torch.empty(M // bm, N, 2, dtype=torch.float32, device=out.device)
     p.cstat_out = cs.data_ptr()
-    out._cstat = (cs, bm, hw)
-    return cs
+    return ColStats(cs, bm, hw, out)
 
 
 def pick_tile(M: int, N: int, batch: int = 1) -> int:
@@ -441,13 +454,14 @@ def _rows_ld(t, name):
 
 # ------------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, tile_hint=0, splits=1,
-         stages=2, geglu=False, ln=None, row_stats=False):
+         stages=2, geglu=False, ln=None, row_stats=False, col_stats=False):
     """out[..., n] = (a[..., :] . w[n, :] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale
 
     a: fp16 [..., K] (last dim contiguous, uniform row stride); w: fp16 [N, K]; bias/rowvec fp32.
     LayerNorm folding (see include/ief_hip.h): `row_stats=True` also returns the per-row moments of the output,
     a fp32 [M, tiles_n, 2] tensor; `ln=(stats, colsum, eps)` consumes the moments of `a`'s rows: the product is then
     rstd * (a . w - mean * colsum) + bias, i.e. LayerNorm(a) . W^T when w = W * gamma and bias carries beta . W^T.
+    `col_stats=True` (a 1x1 projection over an NHWC activation): returns (out, ColStats | None) for the consuming GroupNorm.
     """
     lib = load()
     M, K, lda = _rows_ld(a, "a")
@@ -503,19 +517,22 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
             raise ValueError("gemm: colsum must have N entries")
         p.rstat_in, p.rstat_slots, p.colsum, p.ln_eps = st_in.data_ptr(), st_in.shape[1], colsum.data_ptr(), eps
     p.flags, p.zeros = (3 if geglu else 1), _zeros(a.device)
-    if a.dim() == 4 and out.dim() == 4 and out.is_contiguous():       # a 1x1 projection over an NHWC activation
-        _attach_cstat(lib, p, out, M, N, a.shape[1] * a.shape[2])
+    cst = None
+    if col_stats and a.dim() == 4 and out.dim() == 4 and out.is_contiguous():       # a 1x1 projection over an NHWC activation
+        cst = _attach_cstat(lib, p, out, M, N, a.shape[1] * a.shape[2])
     with _Timed(_kname(p.tile_hint, False, p.stages) + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
+    if col_stats:
+        return out, cst
     return (out, stats) if row_stats else out
 
 
 def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, tile_hint=0,
-            extra=None, splits=1, stages=2, pad_hi_only=False):
+            extra=None, splits=1, stages=2, pad_hi_only=False, col_stats=False):
     """3x3 / pad 1 convolution over NHWC fp16.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat),
     w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather.
     extra=(e1, e2|None): fused 1x1 convolution over more NHWC sources sampled at the output pixel; w is
-    then [Cout, 9*(C1+C2) + CE1 + CE2]."""
+    then [Cout, 9*(C1+C2) + CE1 + CE2].  `col_stats=True`: returns (out, ColStats | None) for the consuming GroupNorm."""
     lib = load()
     _dev16(x, "x")
     _dev16(w, "w")
@@ -581,17 +598,16 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
         p.ws = ws.data_ptr()
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
-    if out.is_contiguous():
-        _attach_cstat(lib, p, out, M, Cout, Ho * Wo)
+    cst = _attach_cstat(lib, p, out, M, Cout, Ho * Wo) if col_stats and out.is_contiguous() else None
     with _Timed(_kname(p.tile_hint, True, p.stages) + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
-    return out
+    return (out, cst) if col_stats else out
 
 
-def conv3x3_shortcut(h, w_fused, bias_fused, x, skip=None):
+def conv3x3_shortcut(h, w_fused, bias_fused, x, skip=None, col_stats=False):
     """ResnetBlock2D tail with a channel-changing shortcut in ONE launch:
     conv3x3(h) + conv1x1([x | skip]) + (b2 + bs); w_fused [Cout, 9*Cout + Cin]."""
-    return conv3x3(h, w_fused, bias_fused, extra=(x, skip))
+    return conv3x3(h, w_fused, bias_fused, extra=(x, skip), col_stats=col_stats)
 
 
 def softmax_rows_(x):
@@ -685,9 +701,10 @@ def conv_out(x, w, bias, out=None):
 
 
 # ------------------------------------------------------------------------------- norms
-def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return_stats=False):
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return_stats=False, cstat=None, cstat2=None):
     """GroupNorm over NHWC / tokens-major fp16 [B, ..., C] (+ optional channel-concat x2), optional SiLU.
-    return_stats: also return the fp32 (mean, rstd) [B, groups, 2] the backward reuses."""
+    return_stats: also return the fp32 (mean, rstd) [B, groups, 2] the backward reuses.
+    cstat / cstat2: the ColStats the launches that PRODUCED x / x2 returned (`col_stats=True`), or None."""
     lib = load()
     _dev16(x, "x")
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
@@ -697,17 +714,20 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
     HW = x.numel() // (B * C1)
     if out is None:
         out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float16, device=x.device)
-    cs1, cs2 = getattr(x, "_cstat", None), None if x2 is None else getattr(x2, "_cstat", None)
+    cs1, cs2 = cstat, None if x2 is None else cstat2
+    for t, c, nm in ((x, cs1, "cstat"), (x2, cs2, "cstat2")):
+        if c is not None and not c.describes(t):
+            raise ValueError(f"groupnorm: {nm} was produced for another tensor (address / size mismatch)")
     cpg = (C1 + C2) // groups
     single_launch = not (cpg & 1) and HW * cpg * 2 <= 48 * 1024           # the C side's one-workgroup-per-group condition
-    if (GN_CSTAT and not return_stats and not single_launch and cs1 is not None and cs1[2] == HW
-            and (x2 is None or (cs2 is not None and cs2[2] == HW))):
+    if (GN_CSTAT and not return_stats and not single_launch and cs1 is not None and cs1.hw == HW
+            and (x2 is None or (cs2 is not None and cs2.hw == HW))):
         # statistics were left by the producers' epilogues: fold them (one small launch) and apply
         stats = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
         with _Timed("groupnorm(stats+apply)", 0.0):
             _check(lib.ief_groupnorm_cstat_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
-                                               _dev32(beta, "beta").data_ptr(), cs1[0].data_ptr(), cs1[1],
-                                               None if cs2 is None else cs2[0].data_ptr(), 0 if cs2 is None else cs2[1],
+                                               _dev32(beta, "beta").data_ptr(), cs1.buf.data_ptr(), cs1.bm,
+                                               None if cs2 is None else cs2.buf.data_ptr(), 0 if cs2 is None else cs2.bm,
                                                stats.data_ptr(), B, HW, groups, eps, 1 if silu else 0, _stream()),
                    "ief_groupnorm_cstat_f16")
         return out
@@ -905,13 +925,13 @@ def to_f32(x, out=None):
 
 
 def select_step(table, out, step):
-    """out[...] = table[step[0], ...] inside the stream (graph-capturable); step: device int32 [1]."""
+    """out[...] = table[clamp(step[0], 0, rows - 1), ...] inside the stream (graph-capturable); step: device int32 [1]."""
     lib = load()
     nbytes = out.numel() * out.element_size()
     if table[0].numel() * table.element_size() != nbytes or not table.is_contiguous() or not out.is_contiguous():
         raise ValueError("select_step: table[step] and out must have identical contiguous byte size")
-    _check(lib.ief_select_step(table.data_ptr(), out.data_ptr(), _devi32(step, "step").data_ptr(), nbytes, _stream()),
-           "ief_select_step")
+    _check(lib.ief_select_step(table.data_ptr(), out.data_ptr(), _devi32(step, "step").data_ptr(), nbytes, table.shape[0],
+                               _stream()), "ief_select_step")
     return out
 
 

@@ -62,12 +62,16 @@ class SyntheticPIE(torch.utils.data.Dataset):
     def __init__(self, root, n, size=512, seed=0):
         os.makedirs(root, exist_ok=True)
         self.items = []
-        rng = np.random.RandomState(seed)
         for i in range(n):
             path = os.path.join(root, f"syn_{i:04d}.png")
             if not os.path.exists(path):
+                # pixels depend on (seed, i) only — not on which files already exist — and the file appears atomically:
+                # under torchrun every rank builds this dataset into the same directory
+                rng = np.random.RandomState([seed, i])
                 low = rng.randint(0, 256, size=(size // 32, size // 32, 3)).astype(np.uint8)
-                Image.fromarray(low).resize((size, size), Image.BICUBIC).save(path)
+                tmp = f"{path}.{os.getpid()}.tmp"
+                Image.fromarray(low).resize((size, size), Image.BICUBIC).save(tmp, format="PNG")
+                os.replace(tmp, path)
             src, tgt = _SYN_PAIRS[i % len(_SYN_PAIRS)]
             self.items.append((path, src, tgt))
 

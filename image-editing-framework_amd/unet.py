@@ -94,7 +94,7 @@ class Conv2d(nn.Module):
 
     def forward(self, x, **kw):
         if self.kernel_size == 1:
-            return hip.gemm(x, self.weight, bias=self.bias, residual=kw.get("residual"))
+            return hip.gemm(x, self.weight, bias=self.bias, residual=kw.get("residual"), col_stats=kw.get("col_stats", False))
         return hip.conv3x3(x, self.weight, self.bias, stride=self.stride, **kw)
 
 
@@ -103,8 +103,9 @@ class GroupNorm(nn.Module):
         super().__init__()
         self.weight, self.bias, self.num_groups, self.eps = weight, bias, num_groups, eps
 
-    def forward(self, x, silu=False, x2=None, return_stats=False):
-        return hip.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2, return_stats=return_stats)
+    def forward(self, x, silu=False, x2=None, return_stats=False, cstat=None, cstat2=None):
+        return hip.groupnorm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, x2=x2, return_stats=return_stats,
+                             cstat=cstat, cstat2=cstat2)
 
 
 class LayerNorm(nn.Module):
@@ -344,10 +345,12 @@ class Transformer2DModel(nn.Module):
             [BasicTransformerBlock(sd, f"{prefix}.transformer_blocks.{k}", dim, heads, cross_dim, dev,
                                    name if k == 0 else f"{name}.b{k}") for k in range(depth)])
 
-    def forward(self, x, encoder_hidden_states=None):
+    def forward(self, x, encoder_hidden_states=None, cstat=None, col_stats=False):
+        """cstat: the producer's column statistics of x (hip.ColStats) for the GroupNorm; col_stats: also return those of
+        the output (proj_out's launch) for the next block's GroupNorm"""
         B, H, W, C = x.shape
         if all(blk.foldable() for blk in self.transformer_blocks):
-            h, st = hip.gemm(self.norm(x), self.proj_in.weight, bias=self.proj_in.bias, row_stats=True)
+            h, st = hip.gemm(self.norm(x, cstat=cstat), self.proj_in.weight, bias=self.proj_in.bias, row_stats=True)
             h = h.reshape(B, H * W, C)
             last = len(self.transformer_blocks) - 1
             for k, blk in enumerate(self.transformer_blocks):
@@ -355,11 +358,11 @@ class Transformer2DModel(nn.Module):
                     h, st = blk(h, encoder_hidden_states, ln_stats=st, want_stats=True)
                 else:
                     h = blk(h, encoder_hidden_states, ln_stats=st)
-            return self.proj_out(h.reshape(B, H, W, C), residual=x)
-        h = self.proj_in(self.norm(x)).reshape(B, H * W, C)
+            return self.proj_out(h.reshape(B, H, W, C), residual=x, col_stats=col_stats)
+        h = self.proj_in(self.norm(x, cstat=cstat)).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, encoder_hidden_states)
-        return self.proj_out(h.reshape(B, H, W, C), residual=x)
+        return self.proj_out(h.reshape(B, H, W, C), residual=x, col_stats=col_stats)
 
 
 # ------------------------------------------------------------------------------------- resnet
@@ -396,11 +399,13 @@ class ResnetBlock2D(nn.Module):
         self.temb_slot = temb_slot  # (offset, width) into the UNet's per-step time-embedding row
         self._inject = None         # control.ControlPlan of a registered Plug-and-Play feature injection
 
-    def forward(self, x, temb_row, skip=None):
-        """x [B,H,W,C1] (+ skip [B,H,W,C2] = un-materialised channel concat); temb_row fp32 [B or 1, Cout]."""
-        h = self.norm1(x, silu=True, x2=skip)
-        h = hip.conv3x3(h, self.conv1.weight, self.conv1.bias, rowvec=temb_row)
-        h = self.norm2(h, silu=True)
+    def forward(self, x, temb_row, skip=None, cstat=None, cstat_skip=None, col_stats=False):
+        """x [B,H,W,C1] (+ skip [B,H,W,C2] = un-materialised channel concat); temb_row fp32 [B or 1, Cout].
+        cstat / cstat_skip: column statistics the producers of x / skip left (hip.ColStats or None);
+        col_stats: return (out, ColStats | None) so the next GroupNorm can skip its statistics pass."""
+        h = self.norm1(x, silu=True, x2=skip, cstat=cstat, cstat2=cstat_skip)
+        h, hs = hip.conv3x3(h, self.conv1.weight, self.conv1.bias, rowvec=temb_row, col_stats=True)
+        h = self.norm2(h, silu=True, cstat=hs)
         if self._inject is not None:
             # Plug-and-Play replaces conv2's OUTPUT rows by the source image's (pnp/model/register.py:161-166); conv2 acts
             # per batch row, so gathering its input rows is the same thing and keeps the fused shortcut / residual add
@@ -408,8 +413,8 @@ class ResnetBlock2D(nn.Module):
             if src is not None:
                 h = hip.gather_rows(h, src)
         if self.conv_shortcut is None:
-            return hip.conv3x3(h, self.conv2.weight, self.conv2.bias, residual=x)
-        return hip.conv3x3_shortcut(h, self.w2_fused, self.b2_fused, x, skip)
+            return hip.conv3x3(h, self.conv2.weight, self.conv2.bias, residual=x, col_stats=col_stats)
+        return hip.conv3x3_shortcut(h, self.w2_fused, self.b2_fused, x, skip, col_stats=col_stats)
 
 
 class Downsample2D(nn.Module):
@@ -417,8 +422,8 @@ class Downsample2D(nn.Module):
         super().__init__()
         self.conv = Conv2d(_f16(sd[prefix + ".conv.weight"].permute(0, 2, 3, 1), dev), _f32(sd[prefix + ".conv.bias"], dev), 3, stride=2)
 
-    def forward(self, x):
-        return self.conv(x)
+    def forward(self, x, col_stats=False):
+        return self.conv(x, col_stats=col_stats)
 
 
 class Upsample2D(nn.Module):
@@ -428,8 +433,8 @@ class Upsample2D(nn.Module):
         super().__init__()
         self.conv = Conv2d(_f16(sd[prefix + ".conv.weight"].permute(0, 2, 3, 1), dev), _f32(sd[prefix + ".conv.bias"], dev), 3)
 
-    def forward(self, x):
-        return hip.conv3x3(x, self.conv.weight, self.conv.bias, upsample=True)
+    def forward(self, x, col_stats=False):
+        return hip.conv3x3(x, self.conv.weight, self.conv.bias, upsample=True, col_stats=col_stats)
 
 
 # ------------------------------------------------------------------------------------- blocks
@@ -661,32 +666,35 @@ class UNet2DConditionModel(nn.Module):
             if taps is not None:
                 taps[name] = v.float().permute(0, 3, 1, 2).cpu()
 
-        h = hip.conv_in(x, self.conv_in.weight, self.conv_in.bias)
+        # `hs` travels beside `h`: the column statistics its producing launch left for the next GroupNorm (hip.ColStats),
+        # or None when that launch does not emit them (small levels, split-K plans, conv_in)
+        h, hs = hip.conv_in(x, self.conv_in.weight, self.conv_in.bias), None
         tap("conv_in", h)
-        skips = [h]
+        skips = [(h, hs)]
         for bi, blk in enumerate(self.down_blocks):
             for j, res in enumerate(blk.resnets):
-                h = res(h, trow(res))
+                h, hs = res(h, trow(res), cstat=hs, col_stats=True)
                 if blk.has_cross_attention:
-                    h = blk.attentions[j](h, ctx)
-                skips.append(h)
+                    h, hs = blk.attentions[j](h, ctx, cstat=hs, col_stats=True)
+                skips.append((h, hs))
             if blk.downsamplers is not None:
-                h = blk.downsamplers[0](h)
-                skips.append(h)
+                h, hs = blk.downsamplers[0](h, col_stats=True)
+                skips.append((h, hs))
             tap(f"down{bi}", h)
-        h = self.mid_block.resnets[0](h, trow(self.mid_block.resnets[0]))
-        h = self.mid_block.attentions[0](h, ctx)
-        h = self.mid_block.resnets[1](h, trow(self.mid_block.resnets[1]))
+        h, hs = self.mid_block.resnets[0](h, trow(self.mid_block.resnets[0]), cstat=hs, col_stats=True)
+        h, hs = self.mid_block.attentions[0](h, ctx, cstat=hs, col_stats=True)
+        h, hs = self.mid_block.resnets[1](h, trow(self.mid_block.resnets[1]), cstat=hs, col_stats=True)
         tap("mid", h)
         for bi, blk in enumerate(self.up_blocks):
             for j, res in enumerate(blk.resnets):
-                h = res(h, trow(res), skip=skips.pop())
+                sk, sks = skips.pop()
+                h, hs = res(h, trow(res), skip=sk, cstat=hs, cstat_skip=sks, col_stats=True)
                 if blk.has_cross_attention:
-                    h = blk.attentions[j](h, ctx)
+                    h, hs = blk.attentions[j](h, ctx, cstat=hs, col_stats=True)
             if blk.upsamplers is not None:
-                h = blk.upsamplers[0](h)
+                h, hs = blk.upsamplers[0](h, col_stats=True)
             tap(f"up{bi}", h)
-        h = self.conv_norm_out(h, silu=True)
+        h = self.conv_norm_out(h, silu=True, cstat=hs)
         eps = hip.conv_out(h, self.conv_out.weight, self.conv_out.bias)
         if per_step_kv:
             for m in cross:

@@ -134,13 +134,14 @@ class _Resnet:
             self.b2 = _f32(sd[p + ".conv2.bias"], dev)
             self.short = False
 
-    def __call__(self, x):
-        h = hip.groupnorm(x, self.n1[0], self.n1[1], self.G, self.eps, silu=True)
-        h = hip.conv3x3(h, self.w1, self.b1)
-        h = hip.groupnorm(h, self.n2[0], self.n2[1], self.G, self.eps, silu=True)
+    def __call__(self, x, cstat=None):
+        """-> (out, column statistics of out for the next GroupNorm); cstat: those of x from its producer"""
+        h = hip.groupnorm(x, self.n1[0], self.n1[1], self.G, self.eps, silu=True, cstat=cstat)
+        h, hs = hip.conv3x3(h, self.w1, self.b1, col_stats=True)
+        h = hip.groupnorm(h, self.n2[0], self.n2[1], self.G, self.eps, silu=True, cstat=hs)
         if self.short:
-            return hip.conv3x3_shortcut(h, self.w2, self.b2, x)
-        return hip.conv3x3(h, self.w2, self.b2, residual=x)
+            return hip.conv3x3_shortcut(h, self.w2, self.b2, x, col_stats=True)
+        return hip.conv3x3(h, self.w2, self.b2, residual=x, col_stats=True)
 
 
 class _MidAttention:
@@ -153,10 +154,10 @@ class _MidAttention:
         self.bqkv = _f32(torch.cat([sd[f"{p}.to_{n}.bias"] for n in "qkv"], 0), dev)
         self.wo, self.bo = _f16(sd[p + ".to_out.0.weight"], dev), _f32(sd[p + ".to_out.0.bias"], dev)
 
-    def __call__(self, x):
+    def __call__(self, x, cstat=None):
         B, H, W, C = x.shape
         N = H * W
-        h = hip.groupnorm(x, self.gn[0], self.gn[1], self.G, self.eps, silu=False).reshape(B, N, C)
+        h = hip.groupnorm(x, self.gn[0], self.gn[1], self.G, self.eps, silu=False, cstat=cstat).reshape(B, N, C)
         qkv = hip.gemm(h, self.wqkv, bias=self.bqkv)
         out = torch.empty(B, N, C, dtype=torch.float16, device=x.device)
         for b in range(B):
@@ -165,7 +166,7 @@ class _MidAttention:
             hip.softmax_rows_(probs)
             hip.gemm(probs, hip.transpose(v.contiguous()), out=out[b])  # P @ V  (V^T is the K-major operand)
         y = hip.gemm(out, self.wo, bias=self.bo, residual=x.reshape(B, N, C))
-        return y.reshape(B, H, W, C)
+        return y.reshape(B, H, W, C), None
 
 
 class AutoencoderKL:
@@ -229,15 +230,15 @@ class AutoencoderKL:
         """image fp32 NCHW [B,3,H,W] in [-1,1] -> {'latent_dist': dist}, dist.mean [B,4,H/8,W/8] fp32"""
         x = image.to(self.device, torch.float32).contiguous()
         G, eps = self.cfg.norm_num_groups, self.cfg.eps
-        h = hip.conv_in(x, self.e_in[0], self.e_in[1])
+        h, hs = hip.conv_in(x, self.e_in[0], self.e_in[1]), None
         for res, ds in self.e_down:
             for r in res:
-                h = r(h)
+                h, hs = r(h, hs)
             if ds is not None:
-                h = hip.conv3x3(h, ds[0], ds[1], stride=2, pad_hi_only=True)
+                h, hs = hip.conv3x3(h, ds[0], ds[1], stride=2, pad_hi_only=True, col_stats=True)
         for m in self.e_mid:
-            h = m(h)
-        h = hip.groupnorm(h, self.e_norm[0], self.e_norm[1], G, eps, silu=True)
+            h, hs = m(h, hs)
+        h = hip.groupnorm(h, self.e_norm[0], self.e_norm[1], G, eps, silu=True, cstat=hs)
         moments = hip.conv_out(h, self.e_out[0], self.e_out[1])
         moments = hip.pointwise_f32(moments, self.quant[0], self.quant[1])
         return {"latent_dist": _Dist(moments)}
@@ -248,15 +249,15 @@ class AutoencoderKL:
         z = z.to(self.device, torch.float32).contiguous()
         G, eps = self.cfg.norm_num_groups, self.cfg.eps
         z = hip.pointwise_f32(z, self.post_quant[0], self.post_quant[1])
-        h = hip.conv_in(z, self.d_in[0], self.d_in[1])
+        h, hs = hip.conv_in(z, self.d_in[0], self.d_in[1]), None
         for m in self.d_mid:
-            h = m(h)
+            h, hs = m(h, hs)
         for res, us in self.d_up:
             for r in res:
-                h = r(h)
+                h, hs = r(h, hs)
             if us is not None:
-                h = hip.conv3x3(h, us[0], us[1], upsample=True)
-        h = hip.groupnorm(h, self.d_norm[0], self.d_norm[1], G, eps, silu=True)
+                h, hs = hip.conv3x3(h, us[0], us[1], upsample=True, col_stats=True)
+        h = hip.groupnorm(h, self.d_norm[0], self.d_norm[1], G, eps, silu=True, cstat=hs)
         return {"sample": hip.conv_out(h, self.d_out[0], self.d_out[1])}
 
 

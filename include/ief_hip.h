@@ -28,7 +28,7 @@ typedef uint16_t ief_half;
 extern "C" {
 #endif
 
-#define IEF_ABI_VERSION 1
+#define IEF_ABI_VERSION 2
 int ief_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char* ief_target_arch(void);
@@ -206,7 +206,9 @@ int ief_silu_f16(const ief_half* x, ief_half* out, long long n, void* stream);
  * out[r][:] = table[idx[0] (device int32)][r][:], element size `esize` bytes, row bytes `rowbytes` */
 int ief_cast_f32_to_f16(const float* x, ief_half* out, long long n, void* stream);
 int ief_cast_f16_to_f32(const ief_half* x, float* out, long long n, void* stream);
-int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, void* stream);
+/* out[:] = table[min(max(step[0], 0), n_rows - 1)][:]: the row index is read from device memory and CLAMPED to the table,
+ * so a captured step graph replayed past the end of its schedule re-reads the last row instead of foreign memory */
+int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, int n_rows, void* stream);
 int ief_advance_step(int* step, void* stream);
 
 /* ------------------------------------------------------------------ null-text inversion: activation gradients

@@ -491,44 +491,45 @@ def test_producer_column_statistics(kind, B, hw, cin, cout):
     if kind == "conv":
         w = h16(cout, 3, 3, cin, seed=4, scale=(9 * cin) ** -0.5)
         rowvec = f32(B, cout, seed=5, scale=0.2)
-        out = hip.conv3x3(dev(x), dev(w), dev(bias), rowvec=dev(rowvec), residual=dev(res))
+        out, cs = hip.conv3x3(dev(x), dev(w), dev(bias), rowvec=dev(rowvec), residual=dev(res), col_stats=True)
     else:
         w = h16(cout, cin, seed=4, scale=cin ** -0.5)
-        out = hip.gemm(dev(x), dev(w), bias=dev(bias), residual=dev(res))
-    cs = getattr(out, "_cstat", None)
-    assert cs is not None, "no column statistics attached"
-    stat, bm, HW = cs
+        out, cs = hip.gemm(dev(x), dev(w), bias=dev(bias), residual=dev(res), col_stats=True)
+    assert cs is not None and cs.describes(out), "no column statistics returned"
+    stat, bm, HW = cs.buf, cs.bm, cs.hw
     assert HW == hw * hw and stat.shape == (B * HW // bm, cout, 2)
     o = out.float().reshape(B * HW // bm, bm, cout)
     want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
     err = (stat - want).abs().max().item() / want.abs().max().item()
     print(f"{kind} {B}x{hw}x{hw} {cin}->{cout}: tile height {bm}, column statistics rel err {err:.2e}")
     assert err < 1e-5
-    again = (hip.conv3x3(dev(x), dev(w), dev(bias), rowvec=dev(rowvec), residual=dev(res)) if kind == "conv"
-             else hip.gemm(dev(x), dev(w), bias=dev(bias), residual=dev(res)))._cstat[0]
+    again = (hip.conv3x3(dev(x), dev(w), dev(bias), rowvec=dev(rowvec), residual=dev(res), col_stats=True) if kind == "conv"
+             else hip.gemm(dev(x), dev(w), bias=dev(bias), residual=dev(res), col_stats=True))[1].buf
     assert torch.equal(again, stat)                     # fixed summation order
 
 
 @pytest.mark.parametrize("C1,C2,hw", [(320, 0, 64), (640, 320, 64), (1280, 640, 32)])
 def test_groupnorm_from_producer_statistics(C1, C2, hw, monkeypatch):
     """the two-launch GroupNorm on the producers' statistics against F.group_norm, against the three-launch path, and bit
-    reproducible; a reshaped input (attribute gone) silently takes the old path"""
+    reproducible; statistics handed over for the wrong tensor are refused"""
     B = 2
     mk = lambda c, seed: hip.conv3x3(dev(h16(B, hw, hw, 64, seed=seed)), dev(h16(c, 3, 3, 64, seed=seed + 1, scale=1 / 24.0)),
-                                     dev(f32(c, seed=seed + 2, scale=0.3)))
-    x = mk(C1, 1)
-    x2 = mk(C2, 5) if C2 else None
-    assert x._cstat is not None and (x2 is None or x2._cstat is not None)
+                                     dev(f32(c, seed=seed + 2, scale=0.3)), col_stats=True)
+    x, cs = mk(C1, 1)
+    x2, cs2 = mk(C2, 5) if C2 else (None, None)
+    assert cs is not None and (x2 is None or cs2 is not None)
     C = C1 + C2
     gamma, beta = dev(1 + f32(C, seed=9, scale=0.1)), dev(f32(C, seed=10, scale=0.1))
-    got = hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True, x2=x2)
+    got = hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True, x2=x2, cstat=cs, cstat2=cs2)
     xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
     ref = F.silu(F.group_norm(xin.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
     close(got, ref.cpu(), 2e-3, 2e-3)
-    assert torch.equal(got, hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True, x2=x2))
-    plain = hip.groupnorm(x.reshape(B, hw * hw, C1), gamma, beta, 32, 1e-5, silu=True,
-                          x2=None if x2 is None else x2.reshape(B, hw * hw, C2))            # views carry no statistics
-    assert (got.reshape(plain.shape).float() - plain.float()).abs().max().item() <= 4e-3
+    assert torch.equal(got, hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True, x2=x2, cstat=cs, cstat2=cs2))
+    plain = hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True, x2=x2)                       # no statistics handed over
+    assert (got.float() - plain.float()).abs().max().item() <= 4e-3
+    with pytest.raises(ValueError):                                                          # statistics of another tensor
+        hip.groupnorm(torch.empty_like(x), gamma, beta, 32, 1e-5, silu=True, x2=x2, cstat=cs, cstat2=cs2)
     monkeypatch.setattr(hip, "GN_CSTAT", False)
-    off = hip.conv3x3(dev(h16(B, hw, hw, 64, seed=1)), dev(h16(C1, 3, 3, 64, seed=2, scale=1 / 24.0)), dev(f32(C1, seed=3, scale=0.3)))
-    assert getattr(off, "_cstat", None) is None and torch.equal(off, x)
+    off, none = hip.conv3x3(dev(h16(B, hw, hw, 64, seed=1)), dev(h16(C1, 3, 3, 64, seed=2, scale=1 / 24.0)),
+                            dev(f32(C1, seed=3, scale=0.3)), col_stats=True)
+    assert none is None and torch.equal(off, x)
