@@ -15,11 +15,17 @@ the one-time RCCL broadcast of the packed weights from rank 0.  value = total st
 divided by the slowest rank's time ("weak" scaling).
 
 The JSON line also carries
-  roofline      dominant kernel (the 3x3 implicit-GEMM conv template, all tile instantiations): algorithmic FLOP per launch
-                / average launch duration measured live with HIP events on the launch stream,
-                against the 2.5 PFLOP/s dense fp16 MFMA peak
+  roofline      the kernel TEMPLATE with the largest share of the step (all tile / ring-depth instantiations of one
+                template count as one kernel): sum of algorithmic FLOP / sum of launch durations measured live with HIP
+                events on the launch stream, against the 2.5 PFLOP/s dense fp16 MFMA peak; `frac_rocprof` is the same
+                fraction from the committed rocprofv3 kernel-trace of this command (profiles/), `roofline_frac` prices
+                every launch against min(MFMA peak, arithmetic intensity x HBM peak)
   cpu_baseline  the fp32 CPU oracle (`oracle/`, reference execution semantics: materialised maps +
-                Python controller) timed on this host's cores on a bounded sample of the same workload
+                Python controller) timed on this host's cores on a bounded sample of the same workload (>= 3 steps)
+  images_per_sec          PIE-Bench loop of `/root/reference/p2p/test.py:114-181` on synthetic 512x512 images, in the
+                          reference's per-image order (invert at UNet batch 1, edit at batch 4, VAE both ends)
+  images_per_sec_batched  the same images with 4 inverted per batched DDIM loop and 4 edits in flight (same pixels)
+  steps_per_sec_1024      the same edit step on 128x128 latents (1024x1024 px), with its own `roofline_1024`
 """
 import argparse
 import json
@@ -54,6 +60,8 @@ def parse():
                     "(comma list, '' to skip); reported beside the headline value, which is ONE edit at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--pie-images", type=int, default=8, help="synthetic PIE images timed per GPU for images_per_sec (0: skip)")
+    ap.add_argument("--steps-1024", type=int, default=10, help="timed edit steps on 128x128 latents (0: skip)")
     return ap.parse_args()
 
 
@@ -83,6 +91,73 @@ def build_pipe(cfg_name, dev, rank, world):
     return pipe, cfg
 
 
+def make_added(cfg, hw, rank, dev):
+    """SDXL family: pooled text embedding + six time ids per UNet batch row (P2P_XL.encode_prompt_xl); constant over the
+    steps, folded by the loop into its per-step time-embedding rows.  None for the other families."""
+    if not cfg.addition_embed:
+        return None
+    g = torch.Generator().manual_seed(4321 + rank)
+    size = float(hw * 8)
+    return {"text_embeds": (torch.randn(4, cfg.pooled_text_dim, generator=g) * 0.5).to(dev),
+            "time_ids": torch.tensor([[size, size, 0.0, 0.0, size, size]] * 4, device=dev)}
+
+
+class EditJob:
+    """one P2P AttentionRefine edit (controller + captured step loop) on `hw` x `hw` latents"""
+
+    def __init__(self, pipe, cfg, ctx, hw, dev, rank, uncond_list):
+        from ief_amd.denoise import FusedDenoiser
+        from ief_amd.p2p.model.attention_control import AttentionRefine
+        from ief_amd.p2p.model.register import register_attention_control
+        self.pipe, self.hw = pipe, hw
+        # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19)
+        self.x_T = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(8888 + rank)).to(dev)
+        self.ctrl = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
+        register_attention_control(pipe, self.ctrl)
+        self.added = make_added(cfg, hw, rank, dev)
+        self.loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=self.added)
+        self.loop.run(self.x_T, num_steps=0)      # allocates, warms up eagerly (untimed) and captures the graph
+
+    def rewind(self):
+        self.ctrl.reset()
+        self.loop.rewind(self.x_T)
+
+    def run_steps(self, n):
+        """n steps, restarting the edit (controller + step counters) whenever 50 are used up"""
+        done = 0
+        while done < n:
+            room = MAX_STEPS - self.ctrl.cur_step
+            if room == 0:
+                self.ctrl.reset()
+                self.loop.rewind()
+                room = MAX_STEPS
+            k = min(room, n - done)
+            for _ in range(k):
+                self.loop.step_once()
+            done += k
+
+    def timed(self, steps, warmup, barrier, dist, dev):
+        """(seconds for `steps` steps: max over ranks)"""
+        self.run_steps(warmup)
+        self.rewind()
+        barrier()
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([elapsed], device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = te.item()
+        assert torch.isfinite(self.loop.lat).all()
+        return elapsed
+
+    def close(self):
+        from ief_amd.p2p.model.register import unregister_attention_control
+        self.loop.release()
+        unregister_attention_control(self.pipe, self.ctrl)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -98,9 +173,6 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from ief_amd import hip
-    from ief_amd.denoise import FusedDenoiser
-    from ief_amd.p2p.model.attention_control import AttentionRefine
-    from ief_amd.p2p.model.register import register_attention_control
     from ief_amd.p2p.model.sd_utils import _encode_prompts
     hip.load()
 
@@ -109,71 +181,31 @@ def main():
     nparams = _w.num_params(cfg)
     pipe.scheduler.set_timesteps(MAX_STEPS)
     hw = args.latent or cfg.sample_size
-    # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19)
-    x_T = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(8888 + rank)).to(dev)
     with torch.no_grad():
         u, c = _encode_prompts(pipe, PROMPTS)
     ctx = torch.cat([u, c])
-    ctrl = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
-    register_attention_control(pipe, ctrl)
     # configs[1] (edit_real.py, null-text inversion): P2P_NTI swaps in one optimised unconditional embedding per step
     # (/root/reference/p2p/model/sd_utils.py:133-138); synthetic stand-ins of the right shape here
     uncond_list = None
     if args.uncond == "per-step":
         g = torch.Generator().manual_seed(1234 + rank)
         uncond_list = [(u[:1].cpu() + 0.01 * torch.randn(1, *u.shape[1:], generator=g)).to(dev) for _ in range(MAX_STEPS)]
-    # SDXL family: pooled text embedding + six time ids per UNet batch row (P2P_XL.encode_prompt_xl); constant over the
-    # steps, folded by the loop into its per-step time-embedding rows
-    global ADDED
-    ADDED = None
-    if cfg.addition_embed:
-        g = torch.Generator().manual_seed(4321 + rank)
-        size = float(hw * 8)
-        ADDED = {"text_embeds": (torch.randn(4, cfg.pooled_text_dim, generator=g) * 0.5).to(dev),
-                 "time_ids": torch.tensor([[size, size, 0.0, 0.0, size, size]] * 4, device=dev)}
-    loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=ADDED)
-
-    def run_steps(n):
-        """n steps, restarting the edit (controller + step counters) whenever 50 are used up"""
-        done = 0
-        while done < n:
-            room = MAX_STEPS - ctrl.cur_step
-            if room == 0:
-                ctrl.reset()
-                loop.rewind()
-                room = MAX_STEPS
-            k = min(room, n - done)
-            for _ in range(k):
-                loop.step_once()
-            done += k
-
-    loop.run(x_T, num_steps=0)          # allocates, warms up eagerly (untimed) and captures the graph
-    run_steps(args.warmup)
-    ctrl.reset(); loop.rewind(x_T)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = te.item()
-    assert torch.isfinite(loop.lat).all()
+    # ---- headline: K edit steps between barriers
+    job = EditJob(pipe, cfg, ctx, hw, dev, rank, uncond_list)
+    elapsed = job.timed(args.steps, args.warmup, barrier, dist, dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
 
-    # throughput schedule: E independent edits in flight per GPU (denoise.run_interleaved); the headline stays E = 1
+    # ---- throughput schedule: E independent edits in flight per GPU (denoise.run_interleaved); the headline stays E = 1
     in_flight = {}
     for E in [int(e) for e in args.in_flight.split(",") if e.strip()]:
-        in_flight[str(E)] = round(edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_list), 3)
-    register_attention_control(pipe, ctrl)
+        in_flight[str(E)] = round(edits_in_flight(pipe, cfg, ctx, job.x_T, hw, E, dev, dist, barrier, world, rank, uncond_list), 3)
 
     out = {
         "metric": f"denoising steps/sec ({MODEL_NAMES.get(args.config, args.config)} {hw * 8}x{hw * 8} P2P edit step, UNet batch 4)",
@@ -190,9 +222,34 @@ def main():
         "throughput_edits_in_flight": in_flight,
     }
     if rank == 0:
-        out["roofline"] = roofline(pipe, loop, ctrl, x_T, value, world)
+        register_job(pipe, job)
+        out["roofline"] = roofline(job, value, world, args.config)      # last use of this job: it ends eager
+    job.close()
+
+    # ---- the same edit step on 128x128 latents (1024x1024 px): north_star's second latent size
+    if args.steps_1024 > 0 and hw != 128:
+        job2 = EditJob(pipe, cfg, ctx, 128, dev, rank, uncond_list)
+        el2 = job2.timed(args.steps_1024, 2, barrier, dist, dev)
+        out["steps_per_sec_1024"] = round(world * args.steps_1024 / el2, 3)
+        out["ms_per_step_1024"] = round(el2 / args.steps_1024 * 1e3, 3)
+        if rank == 0:
+            register_job(pipe, job2)
+            out["roofline_1024"] = roofline(job2, out["steps_per_sec_1024"], world, args.config)
+        job2.close()
+        del job2
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE.json's second metric: PIE-Bench images/sec (reference per-image order, then the batched schedule)
+    if args.pie_images > 0 and not cfg.addition_embed:
+        out.update(pie_images_per_sec(pipe, dev, rank, world, dist, barrier, args.pie_images))
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pipe, cfg, ctx, x_T, ctrl, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pipe, cfg, ctx, job.x_T, job.ctrl, job.added, args.cpu_seconds)
+            if "images_per_sec" in out:
+                # one PIE image = 50 inversion forwards at batch 1 + 50 edit steps at batch 4 (+ VAE, ignored here):
+                # 250 sample-forwards = 62.5 batch-4 steps of the CPU oracle
+                out["cpu_baseline"]["images_per_sec_derived"] = round(out["cpu_baseline"]["value"] / 62.5, 6)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -201,19 +258,24 @@ def main():
 
 MODEL_NAMES = {"sd15": "SD1.5", "sd21": "SD2.1", "sdxl": "SDXL", "tiny": "tiny", "small": "small", "small21": "small21",
                "smallxl": "smallxl"}
-ADDED = None
 
 
-def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_list=None, steps=40):
+def register_job(pipe, job):
+    from ief_amd.p2p.model.register import register_attention_control
+    register_attention_control(pipe, job.ctrl)
+
+
+def edits_in_flight(pipe, cfg, ctx, x_T, hw, E, dev, dist, barrier, world, rank, uncond_list=None, steps=40):
     """steps/s (all ranks) with E independent P2P edits stepped concurrently on each GPU"""
     from ief_amd.denoise import FusedDenoiser, run_interleaved
     from ief_amd.p2p.model.attention_control import AttentionRefine
     from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control
     loops, ctrls = [], []
+    added = make_added(cfg, hw, rank, dev)
     for _ in range(E):
         c = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
         register_attention_control(pipe, c)
-        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=ADDED)
+        lp = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=added)
         lp.start(x_T)
         unregister_attention_control(pipe, None)
         loops.append(lp); ctrls.append(c)
@@ -234,17 +296,62 @@ def edits_in_flight(pipe, ctx, x_T, hw, E, dev, dist, barrier, world, uncond_lis
     return world * E * steps / dt
 
 
+def pie_images_per_sec(pipe, dev, rank, world, dist, barrier, n):
+    """the PIE-Bench loop (`/root/reference/p2p/test.py:114-181`, our `p2p/test.py:run_items`) on n synthetic 512x512
+    images per GPU: VAE encode -> 50-step DDIM inversion (UNet batch 1) -> 50-step P2P edit (batch 4) -> VAE decode ->
+    uint8, nothing saved.  One untimed image first (captures / pools the two step graphs)."""
+    import importlib.util
+    import tempfile
+    pdir = os.path.join(ROOT, "image-editing-framework_amd", "p2p")
+    if pdir not in sys.path:
+        sys.path.insert(0, pdir)
+    spec = importlib.util.spec_from_file_location("ief_p2p_pie_driver", os.path.join(pdir, "test.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    from ief_amd.p2p.dataset.pie import SyntheticPIE
+    from ief_amd.p2p.inversion.ddim import ddim_inversion
+    from ief_amd.p2p.model.sd_utils import P2P
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    root = tempfile.mkdtemp(prefix=f"ief_bench_pie_r{rank}_")
+    items = list(SyntheticPIE(root, n + 4, size=size, seed=rank).items)
+    editor, invertor = P2P(model=pipe, num_inference_steps=MAX_STEPS), ddim_inversion()
+    res = {}
+    for key, kw, warm in (("images_per_sec", dict(invert_batch=1, in_flight=1), 1),
+                          ("images_per_sec_batched", dict(invert_batch=4, in_flight=4), 4)):
+        drv.run_items(pipe, editor, invertor, items[:warm], size, dev, "ddim", **kw)
+        barrier()
+        t0 = time.perf_counter()
+        drv.run_items(pipe, editor, invertor, items[-n:], size, dev, "ddim", **kw)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([dt], device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            dt = te.item()
+        res[key] = round(world * n / dt, 4)
+    res["images_config"] = (f"{n} synthetic {size}x{size} images per GPU, ddim inversion, 50 + 50 steps, guidance 7.5, cross 0.8 / "
+                            "self 0.6, PNGs not written; images_per_sec = reference per-image order, images_per_sec_batched = "
+                            "--invert_batch 4 --in_flight 4 (identical pixels)")
+    return res
+
+
 def _family(kernel_name: str) -> str:
     if kernel_name.startswith("igemm_f16_kernel"):
         return ("igemm_f16_kernel<.., CONV=true> (3x3 implicit-GEMM convolution)" if kernel_name.rstrip(">").endswith("true")
                 else "igemm_f16_kernel<.., CONV=false> (linear / 1x1)")
+    if kernel_name.startswith("attn_flash"):
+        return kernel_name.split("<")[0] + "<..> (self-attention, all head dims)"
     return kernel_name
 
 
-def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
+PEAK_HBM = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.3e12 measured with a float4 copy)
+
+
+def roofline(job, steps_per_sec, world, config):
     """dominant kernel's algorithmic FLOP/s from per-launch HIP-event timings of one eager step"""
     from ief_amd import hip
-    loop.release()
+    loop, ctrl, x_T = job.loop, job.ctrl, job.x_T
+    loop.release()                         # drops the captured graph: the rest of this job runs eagerly
     ctrl.reset()
     loop.use_graph = False
     loop.lat.copy_(x_T.expand_as(loop.lat)); loop.step.zero_()
@@ -252,50 +359,65 @@ def roofline(pipe, loop, ctrl, x_T, steps_per_sec, world):
     torch.cuda.synchronize()
     # keep the GPU busy while the host enqueues the step: with ~430 short launches the host (10 us per launch from
     # Python) would otherwise starve the stream and every event pair would include the wait for its launch
-    torch.cuda._sleep(int(1.2e8))
+    torch.cuda._sleep(int(1.2e8 * max(1, (job.hw // 64) ** 2 // 2)))
     hip.profile_begin()
     loop._step_body()
-    rec = hip.profile_end()
+    rec = hip.profile_end(with_bytes=True)
     agg, fam = {}, {}
-    for name, flops, ms in rec:
+    for name, flops, ms, nbytes in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += ms
-        f = fam.setdefault(_family(name), [0, 0.0, 0.0])
-        f[0] += 1; f[1] += flops; f[2] += ms
+        # price of this launch on the roofline: the larger of its MFMA time and its HBM time
+        floor_ms = max(flops / PEAK_MFMA_F16, nbytes / PEAK_HBM) * 1e3
+        f = fam.setdefault(_family(name), [0, 0.0, 0.0, 0.0, 0.0])
+        f[0] += 1; f[1] += flops; f[2] += ms; f[3] += nbytes; f[4] += floor_ms
     total_ms = sum(a[2] for a in agg.values())
     alg_flop = sum(a[1] for a in agg.values())   # matmul / conv / attention FLOPs of one step, counted per launch
     # dominant kernel = the MFMA kernel template with the largest share of the step; its tile / ring-depth
     # instantiations (chosen per layer shape by the tuned plan table) are one kernel for this purpose
-    name, (n, flops, ms) = max(((k, v) for k, v in fam.items() if v[1] > 0), key=lambda kv: kv[1][2])
+    name, (n, flops, ms, nbytes, floor_ms) = max(((k, v) for k, v in fam.items() if v[1] > 0), key=lambda kv: kv[1][2])
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
-    # this process; see profiles/r01_pmc_traffic.json for the command and the gfx950 FETCH_SIZE correction)
-    traffic, traffic_detail = None, None
+    # the committed rocprofv3 --kernel-trace summary of this command (profiles/): average duration of the same template
+    # without the HIP-event pair's ~3 us, and the PMC traffic of its most frequent member -- only for the configuration
+    # those profiles were taken on
+    prof = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        hit = [v for k, v in pmc.items() if not k.startswith("_") and v.get("family") == name]
-        if hit:      # `traffic` = HBM bytes per launch of the family's most frequent member (PMC passes), details beside it
-            traffic = hit[0]["hbm_bytes"]
-            traffic_detail = {"algorithmic_bytes_per_launch": hit[0]["algorithmic_bytes"], "shape": hit[0]["shape"],
-                              "source": "profiles/r01_pmc_traffic.json"}
-    except (OSError, ValueError, KeyError):
-        traffic = None
-    return {
-        "bound": "mfma", "kernel": name, "launches_per_step": n,
+        with open(os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")) as f:
+            prof = json.load(f).get(f"{config}|{job.hw}", {}).get(name, {})
+    except (OSError, ValueError):
+        prof = {}
+    out = {
+        "bound": "mfma" if flops / PEAK_MFMA_F16 >= nbytes / PEAK_HBM else "hbm",
+        "kernel": name, "launches_per_step": n,
         "avg_launch_ms": round(ms / n, 4), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
+        "alg_mbytes_per_launch": round(nbytes / n / 1e6, 3),
         "achieved": round(achieved, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
-        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-        "traffic_detail": traffic_detail,
+        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4),
+        "timing": "HIP events around every launch on the launch stream (includes ~3 us of event pair per launch)",
+        # each launch priced at max(FLOP / MFMA peak, algorithmic bytes / HBM peak): what share of the measured time the
+        # roofline accounts for (the square K = C projections are HBM-side on this measure)
+        "roofline_frac": round(floor_ms / ms, 4),
+        "achieved_hbm_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+        "traffic": prof.get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch (PMC, committed profile; null when "
+                                                                      "no profile of this configuration is committed)",
+        "traffic_source": prof.get("traffic_source"),
         "kernel_share_of_step": round(ms / total_ms, 3),
-        "whole_step": {"alg_tflop_per_step": round(alg_flop / 1e12, 3), "survey_tflop_per_step_512px": FLOP_PER_STEP / 1e12,
+        "whole_step": {"alg_tflop_per_step": round(alg_flop / 1e12, 3),
                        "achieved": round(steps_per_sec / world * alg_flop / 1e12, 2),
                        "frac": round(steps_per_sec / world * alg_flop / PEAK_MFMA_F16, 4)},
         "per_kernel_ms": {k: round(v[2], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
     }
+    if "avg_launch_us_rocprof" in prof:
+        us = prof["avg_launch_us_rocprof"]
+        out["avg_launch_ms_rocprof"] = round(us * 1e-3, 4)
+        out["frac_rocprof"] = round(flops / n / (us * 1e-6) / PEAK_MFMA_F16, 4)
+        out["rocprof_source"] = prof.get("source")
+    if job.hw == 64 and config == "sd15":
+        out["whole_step"]["survey_tflop_per_step_512px"] = FLOP_PER_STEP / 1e12
+    return out
 
 
-def cpu_baseline(pipe, cfg, ctx, x_T, ctrl, budget_s):
+def cpu_baseline(pipe, cfg, ctx, x_T, ctrl, added, budget_s):
     """the oracle (reference semantics, fp32 eager) on this host: bounded sample of the same workload"""
     from oracle import p2p_ref, unet_ref
     sd = pipe._state_dict
@@ -312,7 +434,7 @@ def cpu_baseline(pipe, cfg, ctx, x_T, ctrl, budget_s):
         t = sched.timesteps[i]
         with torch.no_grad():
             eps = unet_ref.unet_forward(sd, cfg, torch.cat([lat] * 2), t, c, hook=ref_ctrl,
-                                        added_cond_kwargs=None if ADDED is None else {k: v.cpu() for k, v in ADDED.items()})
+                                        added_cond_kwargs=None if added is None else {k: v.cpu() for k, v in added.items()})
         e_u, e_c = eps.chunk(2)
         return sched.step(e_u + 7.5 * (e_c - e_u), int(t), lat)
 
@@ -322,7 +444,7 @@ def cpu_baseline(pipe, cfg, ctx, x_T, ctrl, budget_s):
         lat = step(1 + n, lat)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 8:
+        if n >= 3 and (dt >= budget_s or n >= 8):      # at least 3 timed steps after the warm-up
             break
     return {"value": round(n / dt, 5), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} timed B=4 P2P edit steps of the fp32 eager oracle (materialised maps + Python controller) "

@@ -91,6 +91,7 @@ class ControlPlan:
             slots = Bp - 1
             assert mt.shape == (slots, XL, XL) and coef_table.shape == (num_steps + 1, slots, 2, XL)
             self.mt = mt.to(device=dev, dtype=torch.float16).contiguous()
+            self.mt32 = mt.to(device=dev, dtype=torch.float32).contiguous()      # the reference-precision kernels' copy
             self.coef_table = coef_table.to(device=dev, dtype=torch.float32).contiguous()
             self.coef_cur = torch.zeros(slots, 2, XL, dtype=torch.float32, device=dev)
             es = torch.full((B,), -1, dtype=torch.int32)
@@ -168,6 +169,7 @@ class ControlPlan:
         self.controller = other.controller
         if self.kind == "p2p":
             self.mt.copy_(other.mt)
+            self.mt32.copy_(other.mt32)
             self.coef_table.copy_(other.coef_table)
             self.self_table.copy_(other.self_table)
             self.self_window = other.self_window
@@ -266,5 +268,6 @@ class ControlPlan:
 
     def cross_edit(self, B: int, attn):
         if self.kind == "p2p" and self.applies(B):
-            return dict(edit_src=self.edit_src, edit_slot=self.edit_slot, mt=self.mt, coef=self.coef_cur)
+            mt = self.mt32 if attn.to_q.weight.dtype == torch.float32 else self.mt
+            return dict(edit_src=self.edit_src, edit_slot=self.edit_slot, mt=mt, coef=self.coef_cur)
         return {}

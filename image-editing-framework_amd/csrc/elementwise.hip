@@ -284,6 +284,7 @@ extern "C" int ief_struct_size(int which) {
         case 2: return (int)sizeof(IefCrossParams);
         case 3: return (int)sizeof(IefAttnBwdParams);
         case 4: return (int)sizeof(IefMapLossParams);
+        case 5: return (int)sizeof(IefGemmF32Params);
         default: return -1;
     }
 }

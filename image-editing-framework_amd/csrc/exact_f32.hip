@@ -1,0 +1,595 @@
+// Reference-precision ("exact") mode of the denoising path: fp32 storage, fp32 operands, fp32 accumulation.
+//
+// The reference computes in fp32 (`/root/reference/p2p/edit_syn.py:38`).  The default path stores activations and
+// weights in fp16; its ~2e-3 error per UNet forward comes from the OPERAND rounding of every contraction (fp16 weights
+// 1.0e-3 + fp16 inputs 0.9e-3; an fp32 residual stream alone changes nothing — DESIGN.md §4), so a mode that meets
+// north_star's 1e-3 bound on edited images needs full-precision operands.  gfx950 has an fp32-input MFMA
+// (`v_mfma_f32_32x32x2_f32`, 64 FLOP/clk/SIMD = 157 TFLOP/s, bitwise an fp32 fma chain): every contraction of this
+// mode runs on it, every other op is fp32 VALU.
+//
+//   igemm_f32_kernel<CONV, TRANSB, NT>  linear / 1x1 / 3x3 implicit GEMM (concat sources, nearest-2x, stride 2, fused 1x1
+//                                       shortcut sources, bias + per-image row vector + residual epilogue) and the two
+//                                       batched products of a MATERIALISED attention (scores = Q K^T, out = P V with
+//                                       TRANSB), with batch-row indirection for Q / K / V (P2P self-replace, MasaCtrl,
+//                                       Plug-and-Play)
+//   softmax_rows_f32, p2p_cross_edit_f32   the map pipeline between the two products (`register.py:47-48`,
+//                                       `attention_base.py:118-121`): maps live in HBM in this mode, as in the reference
+//   groupnorm / layernorm / geglu / add / silu / timestep embedding / boundary convs in fp32
+//
+// Tile: 128 x (64 NT) x 32, 4 waves (2 x 2), each wave 2 x NT MFMA tiles of 32 x 32; operands staged through LDS with
+// 36-float rows (conflict-free ds_read_b128: consecutive rows start 4 banks apart mod 64), next K tile prefetched into
+// registers while the current one is multiplied.  The k index INSIDE an 8-deep group is permuted identically for A and B
+// (lane half h takes k = 4h..4h+3), which lets a lane fetch its four operands of four MFMAs with one 16-byte LDS read.
+#include "ief_common.h"
+#include "ief_params.h"
+
+#define XBM 128
+#define XBK 32
+#define XLD 36
+
+__device__ __forceinline__ float silu_x(float x) { return x / (1.0f + expf(-x)); }
+
+struct RowCoord { int b, oy, ox, ok; };
+
+template <bool CONV, bool TRANSB, int NT>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const IefGemmF32Params p) {
+    constexpr int XBN = 64 * NT;
+    __shared__ __attribute__((aligned(16))) float smem_x[2 * (XBM + XBN) * XLD];
+    float* As = smem_x;                       // [2][XBM][XLD]
+    float* Bs = smem_x + 2 * XBM * XLD;       // [2][XBN][XLD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntn = (p.N + XBN - 1) / XBN;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * XBM, n0 = tn * XBN;
+    const float* A = p.A;
+    const float* W = p.W;
+    float* Out = p.Out;
+    if (p.heads > 0) {                         // batched product: blockIdx.z = batch row * heads + head
+        const int b = blockIdx.z / p.heads, h = blockIdx.z - b * p.heads;
+        const int ba = p.a_src ? p.a_src[b] : b, bw = p.w_src ? p.w_src[b] : b;
+        A += (long long)ba * p.sAb + (long long)h * p.sAh;
+        W += (long long)bw * p.sWb + (long long)h * p.sWh;
+        Out += (long long)b * p.sOb + (long long)h * p.sOh;
+    }
+    const int M = p.M, N = p.N, K = p.K;
+    // ---- loader assignment: A tile = 128 rows x 8 chunks of 4 floats; thread -> 4 rows (32 apart), one chunk column
+    const int a_kc = tid & 7, a_r0 = tid >> 3;
+    RowCoord rc[4];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + a_r0 + 32 * i;
+            rc[i].ok = m < M;
+            const int mm = rc[i].ok ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            rc[i].b = mm / hw;
+            const int rem = mm - rc[i].b * hw;
+            rc[i].oy = rem / p.Wo;
+            rc[i].ox = rem - rc[i].oy * p.Wo;
+        }
+    }
+    const int Ct = p.C1 + p.C2, K9 = 9 * Ct;
+    const int pad_lo = p.pad_hi_only ? 0 : 1;
+    const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;   // dims of the stored source
+
+    f32x4 ra[4], rb[2 * NT];
+    auto load_tile = [&](int k0) {
+        const int kk = k0 + a_kc * 4;
+        if (CONV) {
+            const float* src = nullptr;
+            int cs = 0, chs = 0, ky = 0, kx = 0, mode = 0;       // mode 0: zero, 1: 3x3 tap, 2: 1x1 extra source
+            if (kk < K9) {
+                const int tap = kk / Ct, ch = kk - tap * Ct;
+                ky = tap / 3; kx = tap - 3 * ky;
+                if (ch < p.C1) { src = p.A; cs = p.C1; chs = ch; } else { src = p.A2; cs = p.C2; chs = ch - p.C1; }
+                mode = 1;
+            } else if (kk < K) {
+                const int ch2 = kk - K9;
+                if (ch2 < p.CE1) { src = p.E1; cs = p.CE1; chs = ch2; } else { src = p.E2; cs = p.CE2; chs = ch2 - p.CE1; }
+                mode = 2;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rc[i].ok && mode == 1) {
+                    int iy = rc[i].oy * p.stride + ky - pad_lo, ix = rc[i].ox * p.stride + kx - pad_lo;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd) {
+                        if (p.ups) { iy >>= 1; ix >>= 1; }
+                        v = *(const f32x4*)(src + (((long long)rc[i].b * Hs + iy) * Ws + ix) * cs + chs);
+                    }
+                } else if (rc[i].ok && mode == 2) {
+                    v = *(const f32x4*)(src + (((long long)rc[i].b * p.Ho + rc[i].oy) * p.Wo + rc[i].ox) * cs + chs);
+                }
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + a_r0 + 32 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < M && kk < K) {
+                    const float* ap = A + (long long)m * p.lda + kk;
+                    if (!p.a_scalar) v = *(const f32x4*)ap;
+                    else {                      // rows of 77 keys: neither the row stride nor K is a multiple of 4 floats
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (kk + j < K) v[j] = ap[j];
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+        if (!TRANSB) {                  // W [N][K]: rows n0 + a_r0 + 32 i
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) {
+                const int n = n0 + a_r0 + 32 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < N && kk < K) v = *(const f32x4*)(W + (long long)n * p.ldw + kk);
+                rb[i] = v;
+            }
+        } else {                        // W [K][N]: thread -> k row (tid & 31), chunk columns (tid >> 5) + 8 i of 4 n each
+            const int kr = k0 + (tid & 31);
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) {
+                const int n = n0 + ((tid >> 5) + 8 * i) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kr < K && n < N) v = *(const f32x4*)(W + (long long)kr * p.ldw + n);   // N % 4 == 0 (host-checked)
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * XBM * XLD;
+        float* bs = Bs + buf * XBN * XLD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(as + (a_r0 + 32 * i) * XLD + a_kc * 4) = ra[i];
+        if (!TRANSB) {
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) *(f32x4*)(bs + (a_r0 + 32 * i) * XLD + a_kc * 4) = rb[i];
+        } else {
+            const int kr = tid & 31;
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) {
+                const int nl = ((tid >> 5) + 8 * i) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bs[(nl + j) * XLD + kr] = rb[i][j];
+            }
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (K + XBK - 1) / XBK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * XBK);
+        const float* as = As + buf * XBM * XLD + (wm * 64 + li) * XLD + 4 * lh;
+        const float* bs = Bs + buf * XBN * XLD + (wn * 32 * NT + li) * XLD + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < XBK / 8; ++g) {
+            f32x4 fa[2], fb[NT];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = *(const f32x4*)(as + a * 32 * XLD + g * 8);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) fb[b] = *(const f32x4*)(bs + b * 32 * XLD + g * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue: (acc + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]) * out_scale, fp32
+    const float* R = p.residual;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + wn * 32 * NT + b * 32 + li;
+            if (n >= N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= M) continue;
+                float v = acc[a][b][r] + bv;
+                if (p.rowvec) v += p.rowvec[(long long)(m / p.rows_per_batch) * N + n];
+                if (R) v += R[(long long)m * p.ldr + n];
+                Out[(long long)m * p.ldo + n] = v * p.out_scale;
+            }
+        }
+}
+
+template <bool CONV, bool TRANSB, int NT>
+static int launch_igemm_f32(const IefGemmF32Params& p, hipStream_t st) {
+    constexpr int XBN = 64 * NT;
+    const int tiles = ((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN);
+    const int z = p.heads > 0 ? p.batch * p.heads : 1;
+    hipLaunchKernelGGL((igemm_f32_kernel<CONV, TRANSB, NT>), dim3(tiles, 1, z), dim3(256), 0, st, p);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
+    if (!pp || !pp->A || !pp->W || !pp->Out) return IEF_EINVAL;
+    IefGemmF32Params p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IEF_ESHAPE;
+    if (p.rowvec && p.rows_per_batch <= 0) return IEF_ESHAPE;
+    if (p.heads > 0 && p.batch <= 0) return IEF_ESHAPE;
+    if (p.heads == 0 && (p.a_src || p.w_src)) return IEF_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.conv) {
+        if (p.transb || p.heads > 0) return IEF_ESHAPE;
+        if ((p.C1 & 3) || (p.C2 & 3) || (p.CE1 & 3) || (p.CE2 & 3) || p.C1 <= 0) return IEF_ESHAPE;
+        if ((p.C2 > 0 && !p.A2) || (p.CE1 > 0 && !p.E1) || (p.CE2 > 0 && !p.E2)) return IEF_EINVAL;
+        if (p.K != 9 * (p.C1 + p.C2) + p.CE1 + p.CE2 || p.M != p.batch_images * p.Ho * p.Wo) return IEF_ESHAPE;
+        if (p.stride != 1 && p.stride != 2) return IEF_ESHAPE;
+        if (p.ups && ((p.H | p.Wd) & 1)) return IEF_ESHAPE;
+        return p.N <= 64 ? launch_igemm_f32<true, false, 1>(p, st) : launch_igemm_f32<true, false, 2>(p, st);
+    }
+    p.a_scalar = ((p.lda & 3) || (p.K & 3)) ? 1 : 0;          // A rows not 16-byte chunked: element loads for A
+    if (p.ldw & 3) return IEF_EALIGN;
+    if (!p.transb && (p.K & 3)) return IEF_ESHAPE;             // W [N][K] rows are read in 16-byte chunks along K
+    if (p.transb) {
+        if (p.N & 3) return IEF_ESHAPE;
+        return p.N <= 64 ? launch_igemm_f32<false, true, 1>(p, st) : launch_igemm_f32<false, true, 2>(p, st);
+    }
+    return p.N <= 64 ? launch_igemm_f32<false, false, 1>(p, st) : launch_igemm_f32<false, false, 2>(p, st);
+}
+
+// --------------------------------------------------------------------------------------------- attention maps
+// in-place softmax over rows of length L (fp32), one wave per row; three passes over a row that stays in L1/L2
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* __restrict__ x, long long rows, int L) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = x + row * L;
+    const int lane = threadIdx.x & 63;
+    float m = -INFINITY;
+    for (int i = lane; i < L; i += 64) m = fmaxf(m, r[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) s += expf(r[i] - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < L; i += 64) r[i] = expf(r[i] - m) * inv;
+}
+extern "C" int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream) {
+    if (!x) return IEF_EINVAL;
+    if (rows <= 0 || L <= 0) return IEF_ESHAPE;
+    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, L);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// Prompt-to-Prompt cross-attention edit on materialised maps [B*heads][N][L] (L <= 96), in place on the target rows:
+//   P'[w] = c1[w] * sum_v P_src[v] * M[v][w] + c2[w] * P_tgt[w]       (`attention_base.py:118-121`, `attention_control.py:15-46`)
+// edit_src[b] = batch row holding the source maps (or < 0: row untouched), edit_slot[b] = which (M, c1, c2);
+// MT fp32 [slots][96][96] = M transposed and zero-padded, coef fp32 [slots][2][96].  One wave per map row.
+__global__ __launch_bounds__(256) void p2p_cross_edit_f32_kernel(float* __restrict__ P, const int* __restrict__ edit_src,
+                                                                 const int* __restrict__ edit_slot, const float* __restrict__ MT,
+                                                                 const float* __restrict__ coef, int B, int heads, int N, int L) {
+    __shared__ float srow[4][96];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long rid = (long long)blockIdx.x * 4 + w;            // over B * heads * N
+    const long long total = (long long)B * heads * N;
+    const bool live = rid < total;
+    const long long rr = live ? rid : 0;
+    const int b = (int)(rr / ((long long)heads * N));
+    const long long hq = rr - (long long)b * heads * N;
+    const int sb = live ? edit_src[b] : -1;
+    if (sb >= 0) {
+        const float* ps = P + ((long long)sb * heads * N + hq) * L;
+        for (int i = lane; i < 96; i += 64) srow[w][i] = i < L ? ps[i] : 0.f;
+    }
+    __syncthreads();
+    if (sb < 0) return;
+    const int slot = edit_slot[b];
+    float* pt = P + rr * L;
+    const float* mt = MT + (long long)slot * 96 * 96;
+    const float* c1 = coef + (long long)slot * 2 * 96;
+    const float* c2 = c1 + 96;
+    for (int col = lane; col < L; col += 64) {
+        const float* mrow = mt + col * 96;
+        float s = 0.f;
+        for (int v = 0; v < L; ++v) s += srow[w][v] * mrow[v];
+        pt[col] = c1[col] * s + c2[col] * pt[col];
+    }
+}
+extern "C" int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* edit_slot, const float* MT, const float* coef,
+                                      int B, int heads, int N, int L, void* stream) {
+    if (!P || !edit_src || !edit_slot || !MT || !coef) return IEF_EINVAL;
+    if (B <= 0 || heads <= 0 || N <= 0 || L <= 0 || L > 96) return IEF_ESHAPE;
+    const long long total = (long long)B * heads * N;
+    hipLaunchKernelGGL(p2p_cross_edit_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P,
+                       edit_src, edit_slot, MT, coef, B, heads, N, L);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// --------------------------------------------------------------------------------------------- norms
+// GroupNorm (+ SiLU) over [B][HW][C1 (+ C2 concat)] fp32: one workgroup per (batch, group); mean first, then the centred
+// second moment (two-pass: no cancellation), then apply — three sweeps of a slab that stays in L2
+__global__ __launch_bounds__(256) void groupnorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
+                                                            float* __restrict__ out, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int HW, int groups, float eps, int silu) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int C = C1 + C2, cpg = C / groups;
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    const int c0 = g * cpg;
+    const long long n = (long long)HW * cpg;
+    auto at = [&](long long i) -> float {
+        const long long pix = i / cpg;
+        const int c = c0 + (int)(i - pix * cpg);
+        return c < C1 ? x[((long long)b * HW + pix) * C1 + c] : x2[((long long)b * HW + pix) * C2 + (c - C1)];
+    };
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) bc = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        return bc;
+    };
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += at(i);
+    const float mean = block_sum(s) / (float)n;
+    float q = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) { const float d = at(i) - mean; q += d * d; }
+    const float var = block_sum(q) / (float)n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const long long pix = i / cpg;
+        const int c = c0 + (int)(i - pix * cpg);
+        float v = (at(i) - mean) * rstd * gamma[c] + beta[c];
+        if (silu) v = silu_x(v);
+        out[((long long)b * HW + pix) * C + c] = v;
+    }
+}
+extern "C" int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma,
+                                      const float* beta, int B, int HW, int groups, float eps, int silu, void* stream) {
+    if (!x || !out || !gamma || !beta || (C2 > 0 && !x2)) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups) return IEF_ESHAPE;
+    hipLaunchKernelGGL(groupnorm_f32_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, x2, C1, C2, out, gamma,
+                       beta, HW, groups, eps, silu);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// LayerNorm over rows of C fp32, one wave per row, two-pass statistics
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            long long rows, int C, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* r = x + row * C;
+    float* o = out + row * C;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += r[i];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int i = lane; i < C; i += 64) { const float d = r[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    for (int i = lane; i < C; i += 64) o[i] = (r[i] - mean) * rstd * gamma[i] + beta[i];
+}
+extern "C" int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C,
+                                 float eps, void* stream) {
+    if (!x || !out || !gamma || !beta) return IEF_EINVAL;
+    if (rows <= 0 || C <= 0) return IEF_ESHAPE;
+    hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, gamma,
+                       beta, rows, C, eps);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// --------------------------------------------------------------------------------------------- elementwise
+// which: 0 add (a + b), 1 silu(a), 2 GEGLU on the interleaved FF1 layout [8 hidden | 8 gate] groups: out[.., Ch]
+__global__ __launch_bounds__(256) void ew_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                     long long n, int which, int Ch) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (which == 0) out[i] = a[i] + b[i];
+        else if (which == 1) out[i] = silu_x(a[i]);
+        else {
+            const long long row = i / Ch;
+            const int c = (int)(i - row * Ch);
+            const float* pr = a + row * 2 * Ch + (c >> 3) * 16 + (c & 7);
+            out[i] = pr[0] * gelu_f(pr[8]);
+        }
+    }
+}
+static int launch_ew(const float* a, const float* b, float* out, long long n, int which, int Ch, void* stream) {
+    if (!a || !out || (which == 0 && !b)) return IEF_EINVAL;
+    if (n <= 0) return IEF_ESHAPE;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(ew_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, n, which, Ch);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+extern "C" int ief_add_f32(const float* a, const float* b, float* out, long long n, void* stream) { return launch_ew(a, b, out, n, 0, 1, stream); }
+extern "C" int ief_silu_f32(const float* x, float* out, long long n, void* stream) { return launch_ew(x, nullptr, out, n, 1, 1, stream); }
+extern "C" int ief_geglu_il_f32(const float* pre, float* out, long long rows, int Ch, void* stream) {
+    if (Ch <= 0 || (Ch & 7)) return IEF_ESHAPE;
+    return launch_ew(pre, nullptr, out, rows * Ch, 2, Ch, stream);
+}
+
+__global__ void timestep_embedding_f32_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+    const int half_dim = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half_dim) return;
+    const int b = i / half_dim, k = i - b * half_dim;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half_dim);  // ln(10000)
+    const float a = t[b] * freq;
+    out[(long long)b * dim + k] = cosf(a);
+    out[(long long)b * dim + half_dim + k] = sinf(a);
+}
+extern "C" int ief_timestep_embedding_f32(const float* t, float* out, int B, int dim, void* stream) {
+    if (!t || !out) return IEF_EINVAL;
+    if (B <= 0 || dim <= 0 || (dim & 1)) return IEF_ESHAPE;
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, B, dim);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// out[b][:] = in[src[b]][:] for rows of `row_elems` floats (row_elems % 4 == 0)
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out,
+                                                              const int* __restrict__ src, int B, long long row4) {
+    const long long total = (long long)B * row4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / row4);
+        out[i] = in[(long long)src[b] * row4 + (i - (long long)b * row4)];
+    }
+}
+extern "C" int ief_gather_rows_f32(const float* in, float* out, const int* src, int B, long long row_elems, void* stream) {
+    if (!in || !out || !src) return IEF_EINVAL;
+    if (B <= 0 || row_elems <= 0 || (row_elems & 3)) return IEF_ESHAPE;
+    if (((uintptr_t)in | (uintptr_t)out) & 15) return IEF_EALIGN;
+    const long long total = (long long)B * (row_elems / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)in, (f32x4*)out, src,
+                       B, row_elems / 4);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// --------------------------------------------------------------------------------------------- boundary convolutions
+// conv_in:  fp32 NCHW [B,Cin<=8,H,W] -> fp32 NHWC [B,H,W,Cout]; w fp32 [3][3][Cin][Cout].  One thread per (pixel, 4 channels).
+__global__ __launch_bounds__(256) void conv_in_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B, int Cin,
+                                                          int H, int Wd, int Cout) {
+    const int C4 = Cout >> 2;
+    const long long total = (long long)B * H * Wd * C4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        const int b = (int)(pix / (H * Wd));
+        const int rem = (int)(pix - (long long)b * H * Wd);
+        const int oy = rem / Wd, ox = rem - oy * Wd;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float v = x[(((long long)b * Cin + ci) * H + iy) * Wd + ix];
+                const f32x4 wv = *(const f32x4*)(w + ((long long)(tap * Cin + ci)) * Cout + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v * wv[e];
+            }
+        }
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += bias[c4 * 4 + e];
+        }
+        *(f32x4*)(out + pix * Cout + c4 * 4) = acc;
+    }
+}
+extern "C" int ief_conv_in_f32act(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int Wd,
+                                  int Cout, void* stream) {
+    if (!x || !w || !out) return IEF_EINVAL;
+    if (B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cin > 8 || Cout <= 0 || (Cout & 3)) return IEF_ESHAPE;
+    const long long total = (long long)B * H * Wd * (Cout / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(conv_in_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, Cin, H, Wd, Cout);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// conv_out: fp32 NHWC [B,H,W,C] -> fp32 NCHW [B,Cout<=8,H,W]; w fp32 [Cout][3][3][C]; 16 lanes per output pixel split 9*C
+__global__ __launch_bounds__(256) void conv_out_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int B, int C,
+                                                           int H, int Wd, int Cout) {
+    const int sub = threadIdx.x & 15;
+    const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long total = (long long)B * H * Wd;
+    const bool live = pix < total;
+    const long long pc = live ? pix : 0;
+    const int b = (int)(pc / (H * Wd));
+    const int rem = (int)(pc - (long long)b * H * Wd);
+    const int oy = rem / Wd, ox = rem - oy * Wd;
+    const int C4 = C >> 2;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    if (live) {
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
+            const float* xp = x + (((long long)b * H + iy) * Wd + ix) * C;
+            for (int c4 = sub; c4 < C4; c4 += 16) {
+                const f32x4 v = *(const f32x4*)(xp + c4 * 4);
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    if (o < Cout) {
+                        const f32x4 wv = *(const f32x4*)(w + ((long long)o * 9 + tap) * C + c4 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[o] += v[e] * wv[e];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+    }
+    if (live && sub == 0) {
+        for (int o = 0; o < Cout; ++o) out[(((long long)b * Cout + o) * H + oy) * Wd + ox] = acc[o] + (bias ? bias[o] : 0.f);
+    }
+}
+extern "C" int ief_conv_out_f32act(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int Wd,
+                                   int Cout, void* stream) {
+    if (!x || !w || !out) return IEF_EINVAL;
+    if (B <= 0 || H <= 0 || Wd <= 0 || C <= 0 || (C & 3) || Cout <= 0 || Cout > 8) return IEF_ESHAPE;
+    const long long total = (long long)B * H * Wd;
+    hipLaunchKernelGGL(conv_out_f32_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out,
+                       B, C, H, Wd, Cout);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// uint8 image epilogue of `latent2image` (`/root/reference/p2p/model/sd_utils.py:85-88`): decoder output fp32 NCHW in [-1, 1]
+// -> uint8 NHWC, (x / 2 + 0.5).clamp(0, 1) * 255 truncated, so a quarter of the bytes cross PCIe
+__global__ __launch_bounds__(256) void image_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int B, int C, int H,
+                                                       int Wd) {
+    const long long total = (long long)B * H * Wd * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long pix = i / C;
+        const int b = (int)(pix / ((long long)H * Wd));
+        const long long rem = pix - (long long)b * H * Wd;
+        float v = x[((long long)b * C + c) * H * Wd + rem] / 2.0f + 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i] = (uint8_t)(v * 255.0f);
+    }
+}
+extern "C" int ief_image_u8(const float* x, unsigned char* out, int B, int C, int H, int Wd, void* stream) {
+    if (!x || !out) return IEF_EINVAL;
+    if (B <= 0 || C <= 0 || H <= 0 || Wd <= 0) return IEF_ESHAPE;
+    const long long total = (long long)B * H * Wd * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(image_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, B, C, H, Wd);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}

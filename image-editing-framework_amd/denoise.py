@@ -87,11 +87,11 @@ class FusedDenoiser:
         put("temb_table", rows.reshape(len(ts), nb, -1).contiguous())
         if self.temb_cur is None:
             self.temb_cur = torch.zeros(nb, self.temb_table.shape[2], dtype=torch.float32, device=dev)
-        ctx16 = hip.to_f16(context.to(dev).float().contiguous())
+        ctx16 = self.unet._act(context.to(dev))               # the model's activation dtype (fp16; fp32 in the exact mode)
         if uncond_list is not None:  # null-text embeddings: the uncond half changes every step
             rows = []
             for u in uncond_list:
-                u16 = hip.to_f16(u.to(dev).float().contiguous()).expand(self.Bp, *ctx16.shape[1:])
+                u16 = self.unet._act(u.to(dev)).expand(self.Bp, *ctx16.shape[1:])
                 rows.append(torch.cat([u16, ctx16[self.Bp:]], 0))
             put("ctx_table", torch.stack(rows).contiguous())
             if self.ctx is None:

@@ -78,6 +78,22 @@ class IefCrossParams(Structure):
     ]
 
 
+class IefGemmF32Params(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("A2", c_void_p), ("W", c_void_p), ("Out", c_void_p),
+        ("bias", c_void_p), ("rowvec", c_void_p), ("residual", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldw", c_int), ("ldo", c_int), ("ldr", c_int),
+        ("rows_per_batch", c_int), ("out_scale", c_float),
+        ("conv", c_int), ("H", c_int), ("Wd", c_int), ("C1", c_int), ("C2", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("stride", c_int), ("ups", c_int), ("batch_images", c_int), ("pad_hi_only", c_int),
+        ("E1", c_void_p), ("E2", c_void_p), ("CE1", c_int), ("CE2", c_int),
+        ("batch", c_int), ("heads", c_int),
+        ("sAb", c_longlong), ("sAh", c_longlong), ("sWb", c_longlong), ("sWh", c_longlong), ("sOb", c_longlong), ("sOh", c_longlong),
+        ("a_src", c_void_p), ("w_src", c_void_p), ("transb", c_int), ("a_scalar", c_int),
+    ]
+
+
 EXPORTS = [
     "ief_abi_version", "ief_target_arch", "ief_gemm_f16", "ief_conv3x3_f16", "ief_conv_in_f32",
     "ief_conv_out_f32", "ief_gn_splits", "ief_groupnorm_silu_f16", "ief_layernorm_f16", "ief_geglu_f16",
@@ -89,6 +105,10 @@ EXPORTS = [
     "ief_geglu_il_bwd_f16", "ief_zero_insert2x_f16", "ief_pool2x2_sum_f16", "ief_conv_out_bwd_f32",
     "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn", "ief_gather_rows_f16",
     "ief_attn_map_loss_bwd_f16", "ief_axpy_f32", "ief_map_loss_blocks", "ief_groupnorm_cstat_f16", "ief_gemm_tile_bm",
+    # reference-precision (fp32) mode
+    "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
+    "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8",
 ]
 
 
@@ -157,10 +177,25 @@ def load():
     lib.ief_nti_loss_grad_f32.argtypes = [c_void_p] * 7 + [c_int, c_float, c_void_p]
     lib.ief_nti_adam_f32.argtypes = [c_void_p] * 8 + [c_int, c_void_p]
     lib.ief_gather_rows_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]
+    lib.ief_gemm_f32.argtypes = [POINTER(IefGemmF32Params), c_void_p]
+    lib.ief_softmax_rows_f32.argtypes = [c_void_p, c_longlong, c_int, c_void_p]
+    lib.ief_p2p_cross_edit_f32.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
+    lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_float, c_int, c_void_p]
+    lib.ief_layernorm_f32.argtypes = [c_void_p] * 4 + [c_longlong, c_int, c_float, c_void_p]
+    lib.ief_add_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_silu_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
+    lib.ief_geglu_il_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_int, c_void_p]
+    lib.ief_timestep_embedding_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.ief_gather_rows_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]
+    lib.ief_conv_in_f32act.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p]
+    lib.ief_conv_out_f32act.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p]
+    lib.ief_image_u8.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     if lib.ief_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
-    for which, st in enumerate((IefGemmParams, IefAttnParams, IefCrossParams, IefAttnBwdParams)):
+    for which, st in ((0, IefGemmParams), (1, IefAttnParams), (2, IefCrossParams), (3, IefAttnBwdParams), (4, IefMapLossParams),
+                      (5, IefGemmF32Params)):
         if lib.ief_struct_size(which) != ctypes.sizeof(st):
             raise HipExtensionMissing(f"{st.__name__}: ctypes layout ({ctypes.sizeof(st)} B) != library "
                                       f"({lib.ief_struct_size(which)} B); rebuild libief_hip.so")
@@ -207,17 +242,21 @@ def profile_begin():
     _prof = []
 
 
-def profile_end():
-    """-> list of (kernel_name, algorithmic_flops, milliseconds)"""
+def profile_end(with_bytes=False):
+    """-> list of (kernel_name, algorithmic_flops, milliseconds[, algorithmic_bytes])"""
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
-    return [(name, flops, e0.elapsed_time(e1)) for name, flops, e0, e1 in rec]
+    if with_bytes:
+        return [(name, flops, e0.elapsed_time(e1), nbytes) for name, flops, nbytes, e0, e1 in rec]
+    return [(name, flops, e0.elapsed_time(e1)) for name, flops, nbytes, e0, e1 in rec]
 
 
 class _Timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    """`nbytes`: the launch's ALGORITHMIC HBM traffic (every operand read once, the output written once)"""
+
+    def __init__(self, name, flops, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
 
     def __enter__(self):
         if _prof is not None:
@@ -227,7 +266,7 @@ class _Timed:
     def __exit__(self, *a):
         if _prof is not None:
             self.e1.record(torch.cuda.current_stream())
-            _prof.append((self.name, self.flops, self.e0, self.e1))
+            _prof.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
 
 
 # GroupNorm statistics from the producer: a conv / 1x1-projection launch whose output is an NHWC activation of a level with
@@ -425,6 +464,32 @@ def _dev16(t, name):
     return t
 
 
+def _is32(t) -> bool:
+    """True for the fp32 activations / weights of the reference-precision mode (`csrc/exact_f32.hip`)"""
+    return isinstance(t, torch.Tensor) and t.dtype == torch.float32
+
+
+def _act32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{name}: expected an fp32 device tensor (reference-precision mode), got "
+                        f"{type(t).__name__ if not isinstance(t, torch.Tensor) else (t.dtype, t.device)}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+    return t
+
+
+def _rows_ld32(t, name):
+    _act32(t, name)
+    cols = t.shape[-1]
+    ld = t.stride(-2) if t.dim() >= 2 else cols
+    rows = 1
+    for s in t.shape[:-1]:
+        rows *= s
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * ld:
+        raise ValueError(f"{name}: batch stride must equal rows * ld")
+    return rows, cols, ld
+
+
 def _dev32(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise TypeError(f"{name}: expected a contiguous fp32 device tensor")
@@ -462,7 +527,16 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     a fp32 [M, tiles_n, 2] tensor; `ln=(stats, colsum, eps)` consumes the moments of `a`'s rows: the product is then
     rstd * (a . w - mean * colsum) + bias, i.e. LayerNorm(a) . W^T when w = W * gamma and bias carries beta . W^T.
     `col_stats=True` (a 1x1 projection over an NHWC activation): returns (out, ColStats | None) for the consuming GroupNorm.
+    fp32 `a` / `w` (reference-precision mode) run on the fp32-input MFMA; LayerNorm folding does not exist there.
     """
+    if _is32(a):
+        if ln is not None or row_stats:
+            raise ValueError("gemm: LayerNorm folding / row statistics exist only on the fp16 path")
+        o = _gemm_f32(a, w, bias=bias, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
+                      out=None if geglu else out, out_scale=out_scale)
+        if geglu:
+            o = geglu_il(o, out=out)
+        return (o, None) if col_stats else o
     lib = load()
     M, K, lda = _rows_ld(a, "a")
     _dev16(w, "w")
@@ -520,7 +594,8 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     cst = None
     if col_stats and a.dim() == 4 and out.dim() == 4 and out.is_contiguous():       # a 1x1 projection over an NHWC activation
         cst = _attach_cstat(lib, p, out, M, N, a.shape[1] * a.shape[2])
-    with _Timed(_kname(p.tile_hint, False, p.stages) + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K):
+    nbytes = 2.0 * (M * K + N * K + M * No_expect + (M * N if residual is not None else 0))
+    with _Timed(_kname(p.tile_hint, False, p.stages) + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K, nbytes):
         _check(lib.ief_gemm_f16(byref(p), 1, _stream()), "ief_gemm_f16")
     if col_stats:
         return out, cst
@@ -533,6 +608,9 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     w [Cout, 3, 3, C1+C2] fp16; `upsample` = nearest-2x of the input fused into the gather.
     extra=(e1, e2|None): fused 1x1 convolution over more NHWC sources sampled at the output pixel; w is
     then [Cout, 9*(C1+C2) + CE1 + CE2].  `col_stats=True`: returns (out, ColStats | None) for the consuming GroupNorm."""
+    if _is32(x):
+        o = _conv3x3_f32(x, w, bias, x2, stride, upsample, rowvec, residual, out, extra, pad_hi_only)
+        return (o, None) if col_stats else o
     lib = load()
     _dev16(x, "x")
     _dev16(w, "w")
@@ -599,9 +677,102 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
     cst = _attach_cstat(lib, p, out, M, Cout, Ho * Wo) if col_stats and out.is_contiguous() else None
-    with _Timed(_kname(p.tile_hint, True, p.stages) + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K):
+    nbytes = 2.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * (2 if residual is not None else 1))
+    with _Timed(_kname(p.tile_hint, True, p.stages) + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
         _check(lib.ief_conv3x3_f16(byref(p), _stream()), "ief_conv3x3_f16")
     return (out, cst) if col_stats else out
+
+
+def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, transb=False):
+    """fp32 out[..., n] = (a . w[n] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale;
+    transb: w is [K, N] (rows along K) instead of [N, K]"""
+    lib = load()
+    M, K, lda = _rows_ld32(a, "a")
+    _act32(w, "w")
+    if w.dim() != 2:
+        raise ValueError("gemm: w must be 2-D")
+    N = w.shape[1] if transb else w.shape[0]
+    if (w.shape[0] if transb else w.shape[1]) != K:
+        raise ValueError(f"gemm: K mismatch {tuple(w.shape)} vs {K}")
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+    Mo, No, ldo = _rows_ld32(out, "out")
+    if (Mo, No) != (M, N):
+        raise ValueError("gemm: out shape mismatch")
+    p = IefGemmF32Params()
+    p.A, p.W, p.Out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
+    if rowvec is not None:
+        p.rowvec, p.rows_per_batch = _dev32(rowvec, "rowvec").data_ptr(), rows_per_batch
+    if residual is not None:
+        Mr, Nr, ldr = _rows_ld32(residual, "residual")
+        if (Mr, Nr) != (M, N):
+            raise ValueError("gemm: residual shape mismatch")
+        p.residual, p.ldr = residual.data_ptr(), ldr
+    p.M, p.N, p.K, p.lda, p.ldw, p.ldo = M, N, K, lda, w.stride(0), ldo
+    p.out_scale, p.transb = out_scale, 1 if transb else 0
+    nbytes = 4.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))
+    with _Timed(f"igemm_f32_kernel<false, {'true' if transb else 'false'}>", 2.0 * M * N * K, nbytes):
+        _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32")
+    return out
+
+
+def gemm_nt(a, b, out=None):
+    """out = a @ b for a [M, K], b [K, N] (no transposed copy of b on the fp32 path)"""
+    if _is32(a):
+        return _gemm_f32(a, b, out=out, transb=True)
+    return gemm(a, transpose(b.contiguous()), out=out)
+
+
+def _conv3x3_f32(x, w, bias, x2, stride, upsample, rowvec, residual, out, extra, pad_hi_only):
+    lib = load()
+    _act32(x, "x"), _act32(w, "w")
+    if not x.is_contiguous() or (x2 is not None and not _act32(x2, "x2").is_contiguous()) or not w.is_contiguous():
+        raise ValueError("conv3x3: x, x2, w must be contiguous")
+    B, Hp, Wp, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cout = w.shape[0]
+    e1 = e2 = None
+    CE1 = CE2 = 0
+    if extra is not None:
+        e1, e2 = extra
+        CE1 = _act32(e1, "extra").shape[-1]
+        CE2 = 0 if e2 is None else _act32(e2, "extra").shape[-1]
+        for e in (e1, e2):
+            if e is not None and (not e.is_contiguous() or tuple(e.shape[:3]) != (B, Hp, Wp)):
+                raise ValueError("conv3x3: extra sources must be contiguous NHWC at the output resolution")
+        if tuple(w.shape) != (Cout, 9 * (C1 + C2) + CE1 + CE2):
+            raise ValueError("conv3x3: fused weight must be [Cout, 9*(C1+C2)+CE1+CE2]")
+    elif tuple(w.shape[1:]) != (3, 3, C1 + C2):
+        raise ValueError(f"conv3x3: weight shape {tuple(w.shape)} does not match C1+C2={C1 + C2}")
+    H, Wd = (Hp * 2, Wp * 2) if upsample else (Hp, Wp)
+    pad_total = 1 if pad_hi_only else 2
+    Ho, Wo = (H + pad_total - 3) // stride + 1, (Wd + pad_total - 3) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    p = IefGemmF32Params()
+    p.A, p.A2, p.W, p.Out = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
+    p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
+    if rowvec is not None:
+        _dev32(rowvec, "rowvec")
+        if rowvec.dim() != 2 or rowvec.shape[1] != Cout or rowvec.shape[0] not in (1, B):
+            raise ValueError("conv3x3: rowvec must be [B, Cout] or [1, Cout]")
+        p.rowvec = rowvec.data_ptr()
+        p.rows_per_batch = Ho * Wo if rowvec.shape[0] == B and B > 1 else B * Ho * Wo
+    if residual is not None:
+        if tuple(_act32(residual, "residual").shape) != tuple(out.shape) or not residual.is_contiguous():
+            raise ValueError("conv3x3: residual must match the output and be contiguous")
+        p.residual, p.ldr = residual.data_ptr(), Cout
+    M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
+    p.M, p.N, p.K, p.ldo, p.ldw = M, Cout, K, Cout, K
+    p.conv, p.H, p.Wd, p.C1, p.C2, p.Ho, p.Wo = 1, H, Wd, C1, C2, Ho, Wo
+    p.stride, p.ups, p.batch_images, p.pad_hi_only = stride, 1 if upsample else 0, B, 1 if pad_hi_only else 0
+    p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
+    p.out_scale = 1.0
+    nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * (2 if residual is not None else 1))
+    with _Timed("igemm_f32_kernel<true, false>", 2.0 * M * Cout * K, nbytes):
+        _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (conv)")
+    return out
 
 
 def conv3x3_shortcut(h, w_fused, bias_fused, x, skip=None, col_stats=False):
@@ -611,8 +782,13 @@ def conv3x3_shortcut(h, w_fused, bias_fused, x, skip=None, col_stats=False):
 
 
 def softmax_rows_(x):
-    """in-place softmax over the last dim of a contiguous fp16 tensor"""
+    """in-place softmax over the last dim of a contiguous fp16 (or, reference-precision mode, fp32) tensor"""
     lib = load()
+    if _is32(x):
+        if not _act32(x, "x").is_contiguous():
+            raise ValueError("softmax_rows_: x must be contiguous")
+        _check(lib.ief_softmax_rows_f32(x.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], _stream()), "ief_softmax_rows_f32")
+        return x
     _dev16(x, "x")
     if not x.is_contiguous():
         raise ValueError("softmax_rows_: x must be contiguous")
@@ -647,6 +823,13 @@ def pointwise_f32(x, w, bias=None):
 
 def add(a, b, out=None):
     lib = load()
+    if _is32(a):
+        _act32(a, "a"), _act32(b, "b")
+        if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+            raise ValueError("add: operands must be contiguous and of equal shape")
+        out = torch.empty_like(a) if out is None else out
+        _check(lib.ief_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "ief_add_f32")
+        return out
     _dev16(a, "a")
     _dev16(b, "b")
     if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
@@ -660,6 +843,14 @@ def add(a, b, out=None):
 def gather_rows(x, src):
     """out[b] = x[src[b]] along the batch dimension; src: device int32 [B]"""
     lib = load()
+    if _is32(x):
+        _devi32(src, "src")
+        if not _act32(x, "x").is_contiguous() or src.numel() != x.shape[0]:
+            raise ValueError("gather_rows: contiguous x [B, ...] and src [B] expected")
+        out = torch.empty_like(x)
+        _check(lib.ief_gather_rows_f32(x.data_ptr(), out.data_ptr(), src.data_ptr(), x.shape[0], x.numel() // x.shape[0],
+                                       _stream()), "ief_gather_rows_f32")
+        return out
     _dev16(x, "x")
     _devi32(src, "src")
     if not x.is_contiguous() or src.numel() != x.shape[0]:
@@ -671,9 +862,18 @@ def gather_rows(x, src):
 
 
 def conv_in(x, w, bias, out=None):
-    """latent fp32 NCHW [B,Cin,H,W] -> fp16 NHWC [B,H,W,Cout]; w fp16 [3,3,Cin,Cout] (k-major)."""
+    """latent fp32 NCHW [B,Cin,H,W] -> fp16 NHWC [B,H,W,Cout]; w fp16 [3,3,Cin,Cout] (k-major).  fp32 w: fp32 NHWC out."""
     lib = load()
     _dev32(x, "x")
+    if _is32(w):
+        B, Cin, H, Wd = x.shape
+        if tuple(w.shape[:3]) != (3, 3, Cin) or not _act32(w, "w").is_contiguous():
+            raise ValueError("conv_in: weight must be contiguous [3, 3, Cin, Cout]")
+        if out is None:
+            out = torch.empty(B, H, Wd, w.shape[3], dtype=torch.float32, device=x.device)
+        _check(lib.ief_conv_in_f32act(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), B, Cin, H, Wd, w.shape[3],
+                                      _stream()), "ief_conv_in_f32act")
+        return out
     _dev16(w, "w")
     B, Cin, H, Wd = x.shape
     if tuple(w.shape[:3]) != (3, 3, Cin) or not w.is_contiguous():
@@ -687,8 +887,17 @@ def conv_in(x, w, bias, out=None):
 
 
 def conv_out(x, w, bias, out=None):
-    """fp16 NHWC [B,H,W,C] -> fp32 NCHW [B,Cout,H,W]; w fp16 [Cout,3,3,C]."""
+    """fp16 NHWC [B,H,W,C] -> fp32 NCHW [B,Cout,H,W]; w fp16 [Cout,3,3,C] (both fp32 in the reference-precision mode)."""
     lib = load()
+    if _is32(x):
+        B, H, Wd, C = x.shape
+        if not _act32(x, "x").is_contiguous() or not _act32(w, "w").is_contiguous() or tuple(w.shape[1:]) != (3, 3, C):
+            raise ValueError("conv_out: contiguous NHWC x and [Cout, 3, 3, C] weight expected")
+        if out is None:
+            out = torch.empty(B, w.shape[0], H, Wd, dtype=torch.float32, device=x.device)
+        _check(lib.ief_conv_out_f32act(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), B, C, H, Wd, w.shape[0],
+                                       _stream()), "ief_conv_out_f32act")
+        return out
     _dev16(x, "x")
     _dev16(w, "w")
     B, H, Wd, C = x.shape
@@ -706,6 +915,21 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
     return_stats: also return the fp32 (mean, rstd) [B, groups, 2] the backward reuses.
     cstat / cstat2: the ColStats the launches that PRODUCED x / x2 returned (`col_stats=True`), or None."""
     lib = load()
+    if _is32(x):
+        if return_stats:
+            raise ValueError("groupnorm: return_stats exists only on the fp16 path")
+        if not _act32(x, "x").is_contiguous() or (x2 is not None and not _act32(x2, "x2").is_contiguous()):
+            raise ValueError("groupnorm: inputs must be contiguous")
+        B, C1 = x.shape[0], x.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        HW = x.numel() // (B * C1)
+        if out is None:
+            out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float32, device=x.device)
+        with _Timed("groupnorm_f32_kernel", 0.0, 8.0 * (x.numel() + (0 if x2 is None else x2.numel()))):
+            _check(lib.ief_groupnorm_silu_f32(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                              _dev32(beta, "beta").data_ptr(), B, HW, groups, eps, 1 if silu else 0, _stream()),
+                   "ief_groupnorm_silu_f32")
+        return out
     _dev16(x, "x")
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise ValueError("groupnorm: inputs must be contiguous")
@@ -724,7 +948,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
             and (x2 is None or (cs2 is not None and cs2.hw == HW))):
         # statistics were left by the producers' epilogues: fold them (one small launch) and apply
         stats = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
-        with _Timed("groupnorm(stats+apply)", 0.0):
+        with _Timed("groupnorm(stats+apply)", 0.0, 4.0 * x.numel() + (0 if x2 is None else 4.0 * x2.numel())):
             _check(lib.ief_groupnorm_cstat_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
                                                _dev32(beta, "beta").data_ptr(), cs1.buf.data_ptr(), cs1.bm,
                                                None if cs2 is None else cs2.buf.data_ptr(), 0 if cs2 is None else cs2.bm,
@@ -733,7 +957,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
         return out
     splits = lib.ief_gn_splits(HW)
     partial = torch.empty(B * (splits + 1) * groups * 2, dtype=torch.float32, device=x.device)
-    with _Timed("groupnorm(stats+apply)", 0.0):
+    with _Timed("groupnorm(stats+apply)", 0.0, 4.0 * x.numel() + (0 if x2 is None else 4.0 * x2.numel())):
         _check(lib.ief_groupnorm_silu_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
                                           _dev32(beta, "beta").data_ptr(), partial.data_ptr(), B, HW, groups, eps,
                                           1 if silu else 0, _stream()), "ief_groupnorm_silu_f16")
@@ -744,6 +968,14 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
     lib = load()
+    if _is32(x):
+        if not _act32(x, "x").is_contiguous():
+            raise ValueError("layernorm: x must be contiguous")
+        out = torch.empty_like(x) if out is None else out
+        _check(lib.ief_layernorm_f32(x.data_ptr(), out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                     _dev32(beta, "beta").data_ptr(), x.numel() // x.shape[-1], x.shape[-1], eps, _stream()),
+               "ief_layernorm_f32")
+        return out
     _dev16(x, "x")
     if not x.is_contiguous():
         raise ValueError("layernorm: x must be contiguous")
@@ -788,9 +1020,86 @@ def _attn_common(p, q, k, v, out, heads):
 _FLASH_VARIANT_ENV = int(os.environ.get("IEF_FLASH_VARIANT", "0"))      # read once: which flash kernel variant 0 means
 
 
+def _batched32(p, t, heads, d, which):
+    """strides of a [B, rows, heads*d] fp32 operand of a batched product: per batch row and per head"""
+    if t.dim() != 3 or t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
+        raise ValueError(f"{which}: expected [B, rows, heads*d] with batch stride rows * ld")
+    return t.stride(0), d, t.stride(1)
+
+
+def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None):
+    """materialised maps softmax(scale q k^T) as contiguous fp32 [B*heads, N, L] (`register.py:43-47`): one batched
+    launch of the fp32 GEMM over (batch row, head) + a row softmax"""
+    lib = load()
+    _act32(q, "q"), _act32(k, "k")
+    B, N, C = q.shape
+    L = k.shape[1]
+    d = C // heads
+    if out is None:
+        out = torch.empty(B * heads, N, L, dtype=torch.float32, device=q.device)
+    elif tuple(_act32(out, "out").shape) != (B * heads, N, L) or not out.is_contiguous():
+        raise ValueError("attn_probs: out must be contiguous fp32 [B*heads, N, L]")
+    p = IefGemmF32Params()
+    p.A, p.W, p.Out = q.data_ptr(), k.data_ptr(), out.data_ptr()
+    p.M, p.N, p.K = N, L, d
+    p.sAb, p.sAh, p.lda = _batched32(p, q, heads, d, "q")
+    p.sWb, p.sWh, p.ldw = _batched32(p, k, heads, d, "k")
+    p.sOb, p.sOh, p.ldo = heads * N * L, N * L, L
+    p.batch, p.heads, p.out_scale = B, heads, scale
+    p.a_src, p.w_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src"))
+    with _Timed(f"igemm_f32_kernel<scores {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
+        _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention scores)")
+    with _Timed("softmax_rows_f32_kernel", 0.0, 8.0 * out.numel()):
+        _check(lib.ief_softmax_rows_f32(out.data_ptr(), out.numel() // L, L, _stream()), "ief_softmax_rows_f32")
+    return out
+
+
+def _attn_apply_f32(probs, v, heads, v_src=None, out=None):
+    """out [B, N, heads*d] = probs [B*heads, N, L] @ v [B, L, heads*d] per (batch row, head), fp32"""
+    lib = load()
+    _act32(probs, "probs"), _act32(v, "v")
+    if not probs.is_contiguous():
+        raise ValueError("attn_apply: probs must be contiguous")
+    B = v.shape[0]
+    N, L = probs.shape[1], probs.shape[2]
+    d = v.shape[2] // heads
+    if probs.shape[0] != B * heads or v.shape[1] != L:
+        raise ValueError("attn_apply: shape mismatch")
+    if out is None:
+        out = torch.empty(B, N, v.shape[2], dtype=torch.float32, device=v.device)
+    p = IefGemmF32Params()
+    p.A, p.W, p.Out = probs.data_ptr(), v.data_ptr(), out.data_ptr()
+    p.M, p.N, p.K = N, d, L
+    p.sAb, p.sAh, p.lda = heads * N * L, N * L, L
+    p.sWb, p.sWh, p.ldw = _batched32(p, v, heads, d, "v")
+    p.sOb, p.sOh, p.ldo = _batched32(p, _act32(out, "out"), heads, d, "out")
+    p.batch, p.heads, p.out_scale, p.transb = B, heads, 1.0, 1
+    p.w_src = _ptr(_devi32(v_src, "v_src"))
+    with _Timed(f"igemm_f32_kernel<apply {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
+        _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention apply)")
+    return out
+
+
+def p2p_cross_edit_(probs, B, heads, edit_src, edit_slot, mt32, coef):
+    """in place on fp32 maps [B*heads, N, L]: P'[w] = c1[w] (P_src M)[w] + c2[w] P_tgt[w] for the rows edit_src marks"""
+    lib = load()
+    _act32(probs, "probs"), _dev32(mt32, "mt32"), _dev32(coef, "coef")
+    if tuple(mt32.shape[-2:]) != (96, 96) or coef.shape[-1] != 96 or not probs.is_contiguous():
+        raise ValueError("p2p_cross_edit_: mt32 must be [slots,96,96] fp32, coef [slots,2,96] fp32, probs contiguous")
+    _check(lib.ief_p2p_cross_edit_f32(probs.data_ptr(), _devi32(edit_src, "edit_src").data_ptr(),
+                                      _devi32(edit_slot, "edit_slot").data_ptr(), mt32.data_ptr(), coef.data_ptr(), B, heads,
+                                      probs.shape[1], probs.shape[2], _stream()), "ief_p2p_cross_edit_f32")
+    return probs
+
+
 def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None, variant=0):
     """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok).
-    lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes."""
+    lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes.
+    fp32 operands (reference-precision mode): the maps are materialised in HBM, as the reference does."""
+    if _is32(q):
+        if lse is not None:
+            raise ValueError("attn_flash: lse output exists only on the fp16 path")
+        return _attn_apply_f32(_attn_scores_f32(q, k, heads, scale, q_src, k_src), v, heads, v_src, out)
     lib = load()
     if out is None:
         out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)
@@ -804,13 +1113,19 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
         p.lse = lse.data_ptr()
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
     kern = {1: "attn_flash_kernel", 2: "attn_flash_pp_kernel"}.get(p.variant, "attn_flash_sp_kernel")
-    with _Timed(f"{kern}<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
+    with _Timed(f"{kern}<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d, 2.0 * p.B * p.heads * p.d * (2 * p.N + 2 * p.L)):
         _check(lib.ief_attn_flash_f16(byref(p), _stream()), "ief_attn_flash_f16")
     return out
 
 
 def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None, coef=None, out=None):
-    """Cross-attention (<= 96 keys) with the fused Prompt-to-Prompt map edit (see include/ief_hip.h)."""
+    """Cross-attention (<= 96 keys) with the fused Prompt-to-Prompt map edit (see include/ief_hip.h).
+    fp32 operands: materialised maps, `mt` must then be the fp32 table."""
+    if _is32(q):
+        probs = _attn_scores_f32(q, k, heads, scale)
+        if edit_src is not None:
+            p2p_cross_edit_(probs, q.shape[0], heads, edit_src, edit_slot, mt, coef)
+        return _attn_apply_f32(probs, v, heads, None, out)
     lib = load()
     if out is None:
         out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)
@@ -824,13 +1139,16 @@ def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None
         if tuple(mt.shape[-2:]) != (96, 96) or not mt.is_contiguous() or coef.shape[-1] != 96:
             raise ValueError("attn_cross_p2p: mt must be [slots,96,96] fp16, coef [slots,2,96] fp32")
         p.MT, p.coef = mt.data_ptr(), coef.data_ptr()
-    with _Timed(f"attn_cross_p2p_kernel<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d):
+    with _Timed(f"attn_cross_p2p_kernel<{p.d}>", 4.0 * p.B * p.heads * p.N * p.L * p.d,
+                2.0 * p.B * p.heads * p.d * (2 * p.N + 2 * p.L)):
         _check(lib.ief_attn_cross_p2p_f16(byref(p), _stream()), "ief_attn_cross_p2p_f16")
     return out
 
 
 def attn_probs(q, k, heads, scale, out=None):
     """materialised maps [B*heads, N, L] fp16 for the generic controller path (out: where to write them)."""
+    if _is32(q):
+        return _attn_scores_f32(q, k, heads, scale, out=out)
     lib = load()
     B, N, C = q.shape
     L = k.shape[1]
@@ -849,6 +1167,8 @@ def attn_probs(q, k, heads, scale, out=None):
 
 def attn_apply(probs, v, heads, out=None):
     """out [B,N,h*d] = probs [B*heads,N,L] @ v [B,L,h*d]."""
+    if _is32(probs):
+        return _attn_apply_f32(probs, v, heads, None, out)
     lib = load()
     _dev16(probs, "probs")
     if not probs.is_contiguous():
@@ -889,9 +1209,14 @@ def ddim_step(eps, x, a_from: float, a_to: float):
     return out, x0
 
 
-def timestep_embedding(t, dim):
+def timestep_embedding(t, dim, dtype=torch.float16):
     lib = load()
     _dev32(t, "t")
+    if dtype == torch.float32:
+        out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+        _check(lib.ief_timestep_embedding_f32(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream()),
+               "ief_timestep_embedding_f32")
+        return out
     out = torch.empty(t.shape[0], dim, dtype=torch.float16, device=t.device)
     _check(lib.ief_timestep_embedding_f16(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream()),
            "ief_timestep_embedding_f16")
@@ -900,6 +1225,10 @@ def timestep_embedding(t, dim):
 
 def silu(x):
     lib = load()
+    if _is32(x):
+        out = torch.empty_like(_act32(x, "x"))
+        _check(lib.ief_silu_f32(x.contiguous().data_ptr(), out.data_ptr(), x.numel(), _stream()), "ief_silu_f32")
+        return out
     _dev16(x, "x")
     out = torch.empty_like(x)
     _check(lib.ief_silu_f16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ief_silu_f16")
@@ -921,6 +1250,17 @@ def to_f32(x, out=None):
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _check(lib.ief_cast_f16_to_f32(x.contiguous().data_ptr(), out.data_ptr(), x.numel(), _stream()), "ief_cast_f16_to_f32")
+    return out
+
+
+def image_u8(x):
+    """decoder output fp32 NCHW [B,C,H,W] in [-1, 1] -> uint8 NHWC [B,H,W,C] on the device:
+    (x / 2 + 0.5).clamp(0, 1) * 255, truncated (`/root/reference/p2p/model/sd_utils.py:85-88`)"""
+    lib = load()
+    _dev32(x, "x")
+    B, C, H, Wd = x.shape
+    out = torch.empty(B, H, Wd, C, dtype=torch.uint8, device=x.device)
+    _check(lib.ief_image_u8(x.data_ptr(), out.data_ptr(), B, C, H, Wd, _stream()), "ief_image_u8")
     return out
 
 
@@ -1078,9 +1418,17 @@ def layernorm_bwd(x, dy, gamma, eps=1e-5, add=None):
     return dx
 
 
-def geglu_il(pre):
+def geglu_il(pre, out=None):
     """pre [..., 2*Ch] in the interleaved FF1 layout -> hidden * gelu(gate) [..., Ch]"""
     lib = load()
+    if _is32(pre):
+        if not _act32(pre, "pre").is_contiguous():
+            raise ValueError("geglu_il: pre must be contiguous")
+        Ch = pre.shape[-1] // 2
+        if out is None:
+            out = torch.empty(*pre.shape[:-1], Ch, dtype=torch.float32, device=pre.device)
+        _check(lib.ief_geglu_il_f32(pre.data_ptr(), out.data_ptr(), pre.numel() // (2 * Ch), Ch, _stream()), "ief_geglu_il_f32")
+        return out
     _dev16(pre, "pre")
     if not pre.is_contiguous():
         raise ValueError("geglu_il: pre must be contiguous")

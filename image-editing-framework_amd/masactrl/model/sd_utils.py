@@ -3,6 +3,7 @@
 import numpy as np
 import torch
 
+from ... import hip
 from ...denoise import acquire
 from ...p2p.model.sd_utils import encode_prompt_xl
 
@@ -18,11 +19,9 @@ class MasaCtrl:
     def latent2image(self, latents, return_type="np"):
         latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
         image = self.model.vae.decode(latents)["sample"]
-        image = (image / 2 + 0.5).clamp(0, 1)
-        if return_type == "np":
-            image = image.cpu().permute(0, 2, 3, 1).numpy()
-            image = (image * 255).astype(np.uint8)
-        return image
+        if return_type == "np":      # clamp -> NHWC -> uint8 (truncating) as one kernel on the device (hip.image_u8)
+            return hip.image_u8(image.float().contiguous()).cpu().numpy()
+        return (image / 2 + 0.5).clamp(0, 1)
 
     @torch.no_grad()
     def __call__(self, prompt, batch_size=1, height=512, width=512, num_inference_steps=50, guidance_scale=7.5,

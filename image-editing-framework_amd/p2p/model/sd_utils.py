@@ -176,9 +176,9 @@ class P2P:
     def latent2image(self, vae, latents):
         latents = 1 / vae.config.scaling_factor * latents
         image = vae.decode(latents)["sample"]
-        image = (image / 2 + 0.5).clamp(0, 1)
-        image = image.cpu().permute(0, 2, 3, 1).numpy()
-        return (image * 255).astype(np.uint8)
+        # (image / 2 + 0.5).clamp(0, 1) -> NHWC -> * 255 -> uint8 (truncating), `sd_utils.py:85-88`, as one kernel on the
+        # device: uint8 NHWC crosses PCIe instead of fp32 NCHW
+        return hip.image_u8(image.float().contiguous()).cpu().numpy()
 
 
 class P2P_XL(P2P):

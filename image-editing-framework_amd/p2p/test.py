@@ -48,70 +48,22 @@ def edit_type_of(source_prompt: str, target_prompt: str) -> str:
     return "replace" if len(source_prompt.split(" ")) == len(target_prompt.split(" ")) else "refine"
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser("PIE-Bench P2P")
-    ap.add_argument("--sd_version", type=str, default="1.5")
-    ap.add_argument("--dataset_path", type=str, default="./PIE")
-    ap.add_argument("--exp_path", type=str, default="./test_exp")
-    ap.add_argument("--inversion_type", type=str, default="ddim")
-    ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
-    ap.add_argument("--no_save", action="store_true")
-    ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop")
-    ap.add_argument("--in_flight", type=int, default=1,
-                    help="independent images stepped concurrently on one GPU (null-text optimisations and edits)")
-    args = ap.parse_args(argv)
-
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
-    seed_everything(42)
-    pipe = load_pipe(args.sd_version, device)
-    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of test.py:86-104
-    if xl and (args.invert_batch > 1 or args.in_flight > 1):
-        raise NotImplementedError("--invert_batch / --in_flight on the SDXL family: run the reference's per-image order")
-    if args.inversion_type == "ddim":
-        editor = (P2P_XL if xl else P2P)(model=pipe, num_inference_steps=50)
-        invertor = ddim_inversion_xl() if xl else ddim_inversion()
-    elif args.inversion_type == "null-text":
-        editor = (P2P_XL_NTI if xl else P2P_NTI)(model=pipe, num_inference_steps=50)
-        invertor = NTI_XL() if xl else NTI()
-    else:
-        raise ValueError("Please choose right inversion type")
-    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
-
-    if args.synthetic > 0:
-        items = list(SyntheticPIE(os.path.join(args.exp_path, "_synthetic_inputs"), args.synthetic, size=size).items)
-        root = os.path.join(args.exp_path, "_synthetic_inputs")
-    else:
-        items, root = [], os.path.join(args.dataset_path, "annotation_images")
-        for category in CATEGORIES:
-            items += PIE(args.dataset_path, None, category=category).items
-    mine = shard(len(items), rank, world)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    def save(image_path, original, images):
-        if args.no_save:
-            return
-        out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
-        os.makedirs(out_path, exist_ok=True)
-        original.save(os.path.join(out_path, "source.png"))
-        save_img(images[0], os.path.join(out_path, "inversion.png"))
-        save_img(images[1], os.path.join(out_path, "edit.png"))
-
-    nti = args.inversion_type == "null-text"
-    bs = max(1, args.invert_batch)
-    E = max(1, args.in_flight)
+def run_items(pipe, editor, invertor, items, size, device, inversion_type="ddim", invert_batch=1, in_flight=1, save=None):
+    """the per-image loop of `/root/reference/p2p/test.py:116-181` over `items` = [(image path, source prompt, target
+    prompt)]; `save(image_path, original PIL image, uint8 images [2,H,W,3])` is called per image.  invert_batch /
+    in_flight = 1 is the reference's order (invert one image, edit it, next); see the module docstring for the others.
+    Also what `bench.py` times for its images/sec figures."""
+    save = save or (lambda *a: None)
+    nti = inversion_type == "null-text"
+    bs = max(1, invert_batch)
+    E = max(1, in_flight)
     group = max(bs, E)
-    for c0 in range(0, len(mine), group):
-        chunk = [items[i] for i in mine[c0:c0 + group]]
+    for c0 in range(0, len(items), group):
+        chunk = items[c0:c0 + group]
         originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
         if group == 1:
             image_path, source_prompt, target_prompt = chunk[0]
-            images = edit_one(pipe, editor, invertor, originals[0], [source_prompt], [target_prompt], args.inversion_type,
+            images = edit_one(pipe, editor, invertor, originals[0], [source_prompt], [target_prompt], inversion_type,
                               edit_type_of(source_prompt, target_prompt), device)
             save(image_path, originals[0], images)
             continue
@@ -157,6 +109,65 @@ def main(argv=None):
                     ctrl.reset()
             for j, images in zip(part, results):
                 save(chunk[j][0], originals[j], images)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser("PIE-Bench P2P")
+    ap.add_argument("--sd_version", type=str, default="1.5")
+    ap.add_argument("--dataset_path", type=str, default="./PIE")
+    ap.add_argument("--exp_path", type=str, default="./test_exp")
+    ap.add_argument("--inversion_type", type=str, default="ddim")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
+    ap.add_argument("--no_save", action="store_true")
+    ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop")
+    ap.add_argument("--in_flight", type=int, default=1,
+                    help="independent images stepped concurrently on one GPU (null-text optimisations and edits)")
+    args = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    seed_everything(42)
+    pipe = load_pipe(args.sd_version, device)
+    xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of test.py:86-104
+    if xl and (args.invert_batch > 1 or args.in_flight > 1):
+        raise NotImplementedError("--invert_batch / --in_flight on the SDXL family: run the reference's per-image order")
+    if args.inversion_type == "ddim":
+        editor = (P2P_XL if xl else P2P)(model=pipe, num_inference_steps=50)
+        invertor = ddim_inversion_xl() if xl else ddim_inversion()
+    elif args.inversion_type == "null-text":
+        editor = (P2P_XL_NTI if xl else P2P_NTI)(model=pipe, num_inference_steps=50)
+        invertor = NTI_XL() if xl else NTI()
+    else:
+        raise ValueError("Please choose right inversion type")
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+
+    if args.synthetic > 0:
+        items = list(SyntheticPIE(os.path.join(args.exp_path, "_synthetic_inputs"), args.synthetic, size=size).items)
+        root = os.path.join(args.exp_path, "_synthetic_inputs")
+    else:
+        items, root = [], os.path.join(args.dataset_path, "annotation_images")
+        for category in CATEGORIES:
+            items += PIE(args.dataset_path, None, category=category).items
+    mine = shard(len(items), rank, world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+
+    def save(image_path, original, images):
+        if args.no_save:
+            return
+        out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+        os.makedirs(out_path, exist_ok=True)
+        original.save(os.path.join(out_path, "source.png"))
+        save_img(images[0], os.path.join(out_path, "inversion.png"))
+        save_img(images[1], os.path.join(out_path, "edit.png"))
+
+    run_items(pipe, editor, invertor, [items[i] for i in mine], size, device, args.inversion_type, args.invert_batch,
+              args.in_flight, save)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

@@ -60,7 +60,10 @@ class StableDiffusionPipeline:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
-                        keep_state_dict: bool = False, **unused):
+                        keep_state_dict: bool = False, precision: str = "f16", **unused):
+        """precision: "f16" (default: fp16 storage / fp32 accumulation, the fast path whatever `torch_dtype` says) or
+        "f32" — the reference's own precision (`/root/reference/p2p/edit_syn.py:38` loads the pipeline in fp32): UNet and
+        VAE run on the fp32-MFMA kernels, edited images then agree with the fp32 reference to ~1e-4"""
         from .unet import UNet2DConditionModel
         if model_key.startswith("synthetic:"):
             parts = model_key.split(":")
@@ -69,17 +72,17 @@ class StableDiffusionPipeline:
             sd = _weights.synthetic_state_dict(cfg, seed)
             tokenizer = WordPieceTokenizer(cfg.text_max_length)
             text_encoder = SyntheticTextEncoder(cfg.cross_attention_dim)
-            vae = AutoencoderKL(SD_VAE if parts[1] in ("sd15", "sd21") else TINY_VAE, device=device)
+            vae = AutoencoderKL(SD_VAE if parts[1] in ("sd15", "sd21") else TINY_VAE, device=device, precision=precision)
         elif os.path.isdir(model_key):
             cfg, sd = _load_local_unet(model_key)
             tokenizer, text_encoder = _load_local_text(model_key, cfg)
-            vae = _load_local_vae(model_key, device)
+            vae = _load_local_vae(model_key, device, precision)
         else:
             raise FileNotFoundError(
                 f"'{model_key}' is neither 'synthetic:<cfg>' nor a local directory.  Hub names cannot be fetched "
                 "offline: point sd_mapping.sd_maps at a local diffusers-layout directory (README of the reference, "
                 "lines 30-32) or use 'synthetic:sd15'.")
-        unet = UNet2DConditionModel(cfg, sd, device=device)
+        unet = UNet2DConditionModel(cfg, sd, device=device, precision=precision)
         text_encoder = text_encoder.to(device)
         sched = scheduler if scheduler is not None else DDIMScheduler()
         return cls(unet, tokenizer, text_encoder, vae, sched, cfg, sd if keep_state_dict else None)
@@ -212,7 +215,7 @@ def _load_local_unet(path):
     return cfg, {k: v.float() for k, v in sd.items()}
 
 
-def _load_local_vae(path, device):
+def _load_local_vae(path, device, precision="f16"):
     import json
     from safetensors.torch import load_file
     vdir = os.path.join(path, "vae")
@@ -222,7 +225,7 @@ def _load_local_vae(path, device):
                     latent_channels=c["latent_channels"], in_channels=c["in_channels"],
                     norm_num_groups=c["norm_num_groups"], scaling_factor=c.get("scaling_factor", 0.18215))
     sd = {k: v.float() for k, v in load_file(os.path.join(vdir, "diffusion_pytorch_model.safetensors")).items()}
-    return AutoencoderKL(cfg, sd, device=device)
+    return AutoencoderKL(cfg, sd, device=device, precision=precision)
 
 
 def _load_local_text_xl(path, cfg):

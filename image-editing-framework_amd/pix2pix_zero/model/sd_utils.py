@@ -220,11 +220,9 @@ class P2P_Zero:
     def latent2image(self, latents, return_type="np"):
         latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
         image = self.model.vae.decode(latents)["sample"]
-        image = (image / 2 + 0.5).clamp(0, 1)
-        if return_type == "np":
-            image = image.cpu().permute(0, 2, 3, 1).numpy()
-            image = (image * 255).astype(np.uint8)
-        return image
+        if return_type == "np":      # clamp -> NHWC -> uint8 (truncating) as one kernel on the device (hip.image_u8)
+            return hip.image_u8(image.float().contiguous()).cpu().numpy()
+        return (image / 2 + 0.5).clamp(0, 1)
 
 
 class P2P_Zero_NTI(P2P_Zero):

@@ -13,6 +13,7 @@ from typing import List, Optional, Union
 import numpy as np
 import torch
 
+from ... import hip
 from ...denoise import acquire, run_interleaved
 from ...p2p.model.sd_utils import _encode_prompts, encode_prompt_xl
 from .register import (register_attention_control_efficient, register_attention_control_efficient_xl,
@@ -138,11 +139,9 @@ class PnP:
     def latent2image(self, latents, return_type="np"):
         latents = 1 / self.model.vae.config.scaling_factor * latents.detach()
         image = self.model.vae.decode(latents)["sample"]
-        image = (image / 2 + 0.5).clamp(0, 1)
-        if return_type == "np":
-            image = image.cpu().permute(0, 2, 3, 1).numpy()
-            image = (image * 255).astype(np.uint8)
-        return image
+        if return_type == "np":      # clamp -> NHWC -> uint8 (truncating) as one kernel on the device (hip.image_u8)
+            return hip.image_u8(image.float().contiguous()).cpu().numpy()
+        return (image / 2 + 0.5).clamp(0, 1)
 
 
 class PnP_XL(PnP):

@@ -64,8 +64,15 @@ class UNetOutput(dict):
             raise AttributeError(k) from e
 
 
+# storage dtype of the weights being packed: fp16 (default path) or fp32 (reference-precision mode, `precision="f32"`:
+# every hip.* wrapper then dispatches to the fp32-MFMA kernels of csrc/exact_f32.hip by the dtype of what it is handed).
+# Set by UNet2DConditionModel.__init__ for the duration of the construction.
+_PACK = torch.float16
+
+
 def _f16(t, dev):
-    return t.detach().to(device=dev, dtype=torch.float16).contiguous()
+    """a weight / activation-side tensor in the model's storage dtype (fp16 unless the model is built for fp32)"""
+    return t.detach().to(device=dev, dtype=_PACK).contiguous()
 
 
 def _f32(t, dev):
@@ -302,7 +309,7 @@ class BasicTransformerBlock(nn.Module):
         self.attn1 = Attention(sd, prefix + ".attn1", dim, heads, None, dev, name + ".attn1")
         self.attn2 = Attention(sd, prefix + ".attn2", dim, heads, cross_dim, dev, name + ".attn2")
         self.ff = FeedForward(sd, prefix + ".ff", dev)
-        if dev.type == "cuda":
+        if dev.type == "cuda" and _PACK == torch.float16:      # LayerNorm folding lives in the fp16 GEMM's epilogue
             self.attn1.fold_layernorm(self.norm1)
             self.attn2.fold_layernorm(self.norm2)
             self.ff.net[0].fold_layernorm(self.norm3)
@@ -470,9 +477,10 @@ class Timesteps(nn.Module):
     def __init__(self, dim):
         super().__init__()
         self.num_channels = dim
+        self.dtype = _PACK
 
     def forward(self, t):
-        return hip.timestep_embedding(t, self.num_channels)
+        return hip.timestep_embedding(t, self.num_channels, dtype=self.dtype)
 
 
 class TimestepEmbedding(nn.Module):
@@ -487,8 +495,20 @@ class TimestepEmbedding(nn.Module):
 
 
 class UNet2DConditionModel(nn.Module):
-    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", precision: str = "f16"):
+        """precision: "f16" — fp16 storage, fp32 accumulation (the fast path); "f32" — the reference's precision
+        (`/root/reference/p2p/edit_syn.py:38`): fp32 weights and activations on the fp32-input MFMA kernels"""
         super().__init__()
+        global _PACK
+        if precision not in ("f16", "f32"):
+            raise ValueError('precision must be "f16" or "f32"')
+        saved, _PACK = _PACK, (torch.float32 if precision == "f32" else torch.float16)
+        try:
+            self._build(cfg, state_dict, device)
+        finally:
+            _PACK = saved
+
+    def _build(self, cfg, state_dict, device):
         hip.load()  # fail loudly before touching anything else
         dev = torch.device(device)
         # a CPU device is accepted for CONSTRUCTION only (module-tree / packing tests); every forward
@@ -497,7 +517,7 @@ class UNet2DConditionModel(nn.Module):
         self.cfg = cfg
         self.config = _Config(cfg)
         self._device = dev
-        self.dtype = torch.float16
+        self.dtype = _PACK
         ch = cfg.block_out_channels
         nlev = len(ch)
         G, eps = cfg.norm_num_groups, cfg.norm_eps
@@ -611,7 +631,7 @@ class UNet2DConditionModel(nn.Module):
         ids = added_cond_kwargs["time_ids"].to(self._device).float().contiguous()
         B = te.shape[0]
         tim = self.add_time_proj(ids.reshape(-1).contiguous()).reshape(B, -1)
-        return self.add_embedding(torch.cat([hip.to_f16(te), tim], dim=-1).contiguous())
+        return self.add_embedding(torch.cat([self._act(te), tim], dim=-1).contiguous())
 
     def time_rows(self, timesteps_f32, aug=None):
         """fp32 [T, sum Cout]: time_emb_proj(silu(time_embedding(time_proj(t)))) for every resnet at once.
@@ -622,7 +642,7 @@ class UNet2DConditionModel(nn.Module):
             emb = hip.add(emb[:, None, :].expand(T, B, -1).contiguous(), aug[None].expand(T, B, -1).contiguous())
             emb = emb.reshape(T * B, -1)
         rows = hip.gemm(hip.silu(emb), self._temb_w, bias=self._temb_b)
-        return hip.to_f32(rows)
+        return rows if rows.dtype == torch.float32 else hip.to_f32(rows)
 
     def precompute_time_table(self, timesteps):
         """Rows for a whole schedule (one per step); the fused loop then selects a row per step on device."""
@@ -643,7 +663,7 @@ class UNet2DConditionModel(nn.Module):
         x = x.contiguous()
         B = x.shape[0]
         ctx = encoder_hidden_states
-        if ctx.dtype != torch.float16:
+        if ctx.dtype != self.dtype:
             ctx = self._ctx_f16(ctx)
         if temb_row is None:
             t = torch.as_tensor(timestep).to(device=self._device, dtype=torch.float32).reshape(-1)[:1].contiguous()
@@ -717,11 +737,16 @@ class UNet2DConditionModel(nn.Module):
             w = self._w_kv_all = torch.cat([m.w_kv for m in self._cross_modules()], 0).contiguous()
         return w
 
+    def _act(self, t32):
+        """an fp32 device tensor in the model's activation dtype"""
+        t32 = t32.float().contiguous()
+        return t32 if self.dtype == torch.float32 else hip.to_f16(t32)
+
     def _ctx_f16(self, ctx):
-        """fp32 context -> fp16 once per distinct tensor (keeps the cross-attention K/V cache valid)."""
+        """context -> the model's activation dtype, once per distinct tensor (keeps the cross-attention K/V cache valid)."""
         cache = getattr(self, "_ctx_cache", None)
         if cache is None or cache[0] is not ctx or cache[1] != ctx._version:
-            self._ctx_cache = (ctx, ctx._version, hip.to_f16(ctx.float().contiguous()))
+            self._ctx_cache = (ctx, ctx._version, self._act(ctx))
         return self._ctx_cache[2]
 
 

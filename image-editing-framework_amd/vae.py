@@ -108,8 +108,11 @@ def synthetic_vae_state_dict(cfg: VAEConfig, seed: int = 2):
 
 
 # ------------------------------------------------------------------------------------- device modules
+_PACK = torch.float16      # storage dtype while an AutoencoderKL is being packed (fp32 for precision="f32", as in unet.py)
+
+
 def _f16(t, dev):
-    return t.detach().to(device=dev, dtype=torch.float16).contiguous()
+    return t.detach().to(device=dev, dtype=_PACK).contiguous()
 
 
 def _f32(t, dev):
@@ -159,18 +162,27 @@ class _MidAttention:
         N = H * W
         h = hip.groupnorm(x, self.gn[0], self.gn[1], self.G, self.eps, silu=False, cstat=cstat).reshape(B, N, C)
         qkv = hip.gemm(h, self.wqkv, bias=self.bqkv)
-        out = torch.empty(B, N, C, dtype=torch.float16, device=x.device)
+        out = torch.empty(B, N, C, dtype=x.dtype, device=x.device)
         for b in range(B):
             q, k, v = qkv[b, :, :C], qkv[b, :, C:2 * C], qkv[b, :, 2 * C:]
             probs = hip.gemm(q, k, out_scale=C ** -0.5)                 # [N, N] scores
             hip.softmax_rows_(probs)
-            hip.gemm(probs, hip.transpose(v.contiguous()), out=out[b])  # P @ V  (V^T is the K-major operand)
+            hip.gemm_nt(probs, v, out=out[b])                            # P @ V
         y = hip.gemm(out, self.wo, bias=self.bo, residual=x.reshape(B, N, C))
         return y.reshape(B, H, W, C), None
 
 
 class AutoencoderKL:
-    def __init__(self, cfg: VAEConfig = SD_VAE, state_dict=None, device="cuda:0", seed: int = 2):
+    def __init__(self, cfg: VAEConfig = SD_VAE, state_dict=None, device="cuda:0", seed: int = 2, precision: str = "f16"):
+        global _PACK
+        saved, _PACK = _PACK, (torch.float32 if precision == "f32" else torch.float16)
+        try:
+            self._build(cfg, state_dict, device, seed)
+        finally:
+            _PACK = saved
+        self.precision = precision
+
+    def _build(self, cfg, state_dict, device, seed):
         hip.load()
         dev = torch.device(device)
         self.cfg = cfg

@@ -211,6 +211,63 @@ int ief_cast_f16_to_f32(const ief_half* x, float* out, long long n, void* stream
 int ief_select_step(const void* table, void* out, const int* step, long long bytes_per_step, int n_rows, void* stream);
 int ief_advance_step(int* step, void* stream);
 
+/* ------------------------------------------------------------------ reference-precision ("exact") mode: fp32 end to end
+ * The reference computes in fp32 (/root/reference/p2p/edit_syn.py:38).  These entry points are the same operators on
+ * fp32 activations and fp32 weights, contractions on the fp32-input MFMA (csrc/exact_f32.hip); the host picks them by
+ * the dtype of the tensors it is handed (hip.py).  Attention in this mode MATERIALISES its maps in HBM as the
+ * reference does (/root/reference/p2p/model/register.py:43-51): scores and P.V are two batched launches of ief_gemm_f32
+ * with ief_softmax_rows_f32 (and the P2P edit, ief_p2p_cross_edit_f32) between them. */
+typedef struct IefGemmF32Params {
+    const float* A;         /* [M][K] rows (lda) | conv: NHWC source 1 */
+    const float* A2;        /* conv: NHWC source 2 of a channel concat, or NULL */
+    const float* W;         /* [N][K] rows (ldw); transb: [K][N] rows (ldw) */
+    float* Out;             /* [M][N] rows (ldo) */
+    const float* bias;      /* [N] or NULL */
+    const float* rowvec;    /* [M / rows_per_batch][N] or NULL */
+    const float* residual;  /* [M][N] rows (ldr) or NULL */
+    int M, N, K;
+    int lda, ldw, ldo, ldr;
+    int rows_per_batch;
+    float out_scale;        /* out = (acc + bias + rowvec + residual) * out_scale */
+    /* 3x3 implicit GEMM (conv != 0): same meaning as the fields of IefGemmParams */
+    int conv, H, Wd, C1, C2, Ho, Wo, stride, ups, batch_images, pad_hi_only;
+    const float* E1;
+    const float* E2;
+    int CE1, CE2;
+    /* batched product (heads > 0): grid.z = batch * heads; element strides per batch row / head; optional batch-row
+     * indirection of the A and W operands (P2P self-replace, MasaCtrl, Plug-and-Play source rows) */
+    int batch, heads;
+    long long sAb, sAh, sWb, sWh, sOb, sOh;
+    const int* a_src;
+    const int* w_src;
+    int transb;
+    int a_scalar;           /* set by the library: A rows are not 16-byte chunked */
+} IefGemmF32Params;
+int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
+int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
+/* P'[w] = c1[w] * sum_v P_src[v] M[v][w] + c2[w] * P_tgt[w] in place on maps [B*heads][N][L], L <= 96; MT fp32
+ * [slots][96][96] (M transposed, zero padded), coef fp32 [slots][2][96]; edit_src / edit_slot as IefCrossParams */
+int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* edit_slot, const float* MT, const float* coef, int B,
+                           int heads, int N, int L, void* stream);
+int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma, const float* beta,
+                           int B, int HW, int groups, float eps, int silu, void* stream);
+int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C, float eps,
+                      void* stream);
+int ief_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
+int ief_silu_f32(const float* x, float* out, long long n, void* stream);
+/* hidden * gelu(gate) on the interleaved FF1 layout ([8 hidden | 8 gate] groups): pre [rows][2 Ch] -> out [rows][Ch] */
+int ief_geglu_il_f32(const float* pre, float* out, long long rows, int Ch, void* stream);
+int ief_timestep_embedding_f32(const float* t, float* out, int B, int dim, void* stream);
+int ief_gather_rows_f32(const float* in, float* out, const int* src, int B, long long row_elems, void* stream);
+/* boundary convolutions with fp32 activations: fp32 NCHW latents <-> fp32 NHWC; w fp32 [3][3][Cin][Cout] / [Cout][3][3][C] */
+int ief_conv_in_f32act(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int Wd, int Cout,
+                       void* stream);
+int ief_conv_out_f32act(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int Wd, int Cout,
+                        void* stream);
+/* uint8 image epilogue of latent2image (/root/reference/p2p/model/sd_utils.py:85-88): fp32 NCHW in [-1, 1] -> uint8 NHWC,
+ * (x / 2 + 0.5).clamp(0, 1) * 255 truncated */
+int ief_image_u8(const float* x, unsigned char* out, int B, int C, int H, int Wd, void* stream);
+
 /* ------------------------------------------------------------------ null-text inversion: activation gradients
  * The reference optimises the unconditional embedding with torch autograd through the whole UNet
  * (/root/reference/p2p/inversion/nti.py:15-33: `uncond_embeddings.requires_grad`, `loss.backward()`,

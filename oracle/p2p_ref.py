@@ -67,6 +67,7 @@ class P2PControlRef:
     mapper:  replace -> float [Bp-1,77,77];  refine -> int64 [Bp-1,77]
     alphas:  refine  -> float [Bp-1,1,1,77]
     equalizer: reweight -> float [Bp-1,77]
+    prev: reweight -> the controller whose edit is re-weighted (`prev_controller`, attention_control.py:43-44), or None
     """
     mode: str = "empty"
     num_prompts: int = 2
@@ -79,6 +80,7 @@ class P2PControlRef:
     cur_step: int = 0
     cur_att_layer: int = 0
     store: Optional[dict] = None  # AttentionStore semantics when not None
+    prev: Optional["P2PControlRef"] = None
 
     def _edit_cross(self, base, repl):
         if self.mode == "replace":
@@ -87,6 +89,8 @@ class P2PControlRef:
             gathered = base[:, :, self.mapper].permute(2, 0, 1, 3)
             return gathered * self.alphas + repl * (1 - self.alphas)
         if self.mode == "reweight":
+            if self.prev is not None:      # attention_control.py:43-45: the chained controller's edit first, [Bp-1,h,p,n]
+                return self.prev._edit_cross(base, repl) * self.equalizer[:, None, None, :]
             return base[None] * self.equalizer[:, None, None, :]
         raise ValueError(self.mode)
 

@@ -125,6 +125,33 @@ def g3_g4_g5(tok):
     print("p2p_ctrl.npz", len(out), "arrays")
 
 
+def g3_chain(tok):
+    """G3b: AttentionReweight CHAINED on an AttentionRefine (`attention_control.py:42-46`, `prev_controller`): the
+    refinement edit of the source maps, then the per-word equalizer — the combination the P2P notebook uses"""
+    out = {}
+    heads = 2
+    a, b = PROMPT_PAIRS[0]
+    eq = ref_aligner.get_equalizer(tok, b, ("fall",), (3.0,))
+
+    def make():
+        prev = ref_ctrl.AttentionRefine([a, b], tok, 50, 0.8, 0.4, device=CPU)
+        return ref_ctrl.AttentionReweight([a, b], tok, 50, 0.8, 0.4, eq, controller=prev, device=CPU)
+    bh = 2 * 2 * heads
+    for step in (0, 39, 40):
+        c = make()
+        c.num_att_layers = 2
+        c.cur_step = step
+        for li, (is_cross, n, l) in enumerate([(True, 64, 77), (True, 16, 77)]):
+            x = _softmax_maps(1500 + li, bh, n, l)
+            y = c(x.clone(), is_cross, "down")
+            out[f"chain_s{step}_l{li}"] = y[bh // 2:].numpy().astype(np.float32)
+            out[f"chain_s{step}_l{li}_uncond_same"] = np.array(bool(torch.equal(x[: bh // 2], y[: bh // 2])))
+        out[f"chain_s{step}_after"] = np.array([c.cur_step, c.cur_att_layer])
+    out["chain_equalizer"] = eq.numpy()
+    np.savez_compressed(os.path.join(HERE, "p2p_ctrl_chain.npz"), **out)
+    print("p2p_ctrl_chain.npz", len(out), "arrays")
+
+
 class _StubSched:
     """Scheduler constants of SURVEY.md §8a row S; only the attributes ddim.py/nti.py read."""
 
@@ -228,5 +255,6 @@ if __name__ == "__main__":
     tok = WordPieceTokenizer()
     g1_g2(tok)
     g3_g4_g5(tok)
+    g3_chain(tok)
     g6_g8()
     g7_masactrl()

@@ -78,9 +78,13 @@ def test_bench_under_torchrun_one_rank(tmp_path):
     """the exact launch line the driver uses for N > 1, with N = 1 (one GPU on this box)"""
     out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-               "--config", "small", "--no-cpu-baseline"], cwd=ROOT, timeout=900)
+               "--config", "small", "--no-cpu-baseline", "--pie-images", "2", "--steps-1024", "2"], cwd=ROOT, timeout=900)
     rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["value"] > 0 and "roofline" in rec
+    # BASELINE.json's second metric and north_star's second latent size ride on the same line
+    assert rec["images_per_sec"] > 0 and rec["images_per_sec_batched"] > 0
+    assert rec["steps_per_sec_1024"] > 0 and rec["roofline_1024"]["frac"] > 0
+    assert rec["roofline"]["bound"] in ("mfma", "hbm") and 0 < rec["roofline"]["roofline_frac"] <= 1.5
 
 
 def test_pie_driver_batched_inversion_matches_per_image(tmp_path):

@@ -1,0 +1,328 @@
+"""Reference-precision mode (`precision="f32"`, csrc/exact_f32.hip) on a real MI355X.
+
+The reference computes in fp32 (`/root/reference/p2p/edit_syn.py:38`); north_star asks for edited images within 1e-3
+max-abs of it.  The default path (fp16 storage) sits at ~2e-3 per UNet forward because every contraction rounds its
+OPERANDS to fp16 (weights 1.0e-3 + inputs 0.9e-3, measured by rounding them in the oracle).  This mode
+keeps fp32 weights and activations and runs every contraction on the fp32-input MFMA.
+
+Stated tolerances (relative to max |reference| unless said otherwise):
+    single kernels vs torch fp32 on the host        <= 2e-5   (summation order only)
+    one UNet forward (eps) vs the fp32 oracle       <= 1e-4
+    10-step edit: latents                            <= 3e-4
+    10-step edit: decoded images in [0, 1]           max |diff| <= 1e-3   (north_star's bound), uint8 within 1 level
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from ief_amd import hip  # noqa: E402
+from ief_amd.pipeline import StableDiffusionPipeline  # noqa: E402
+from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace  # noqa: E402
+from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control  # noqa: E402
+from ief_amd.p2p.model.sd_utils import P2P, _encode_prompts  # noqa: E402
+from oracle import p2p_ref, unet_ref, vae_ref  # noqa: E402
+
+DEV = torch.device("cuda:0")
+PROMPTS = ["a photo of a house on a mountain", "a photo of a house on a mountain at fall"]
+PROMPTS_EQ = ["a gray horse in the field", "a whie horse in the field"]
+KTOL = 2e-5
+
+
+def f32(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def rel_err(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max()).item()
+
+
+# ----------------------------------------------------------------------------------------------- kernels
+def test_gemm_f32_identity_asymmetric():
+    """A = I with an asymmetric W catches a swapped row / column fragment map of the fp32 MFMA"""
+    a = torch.eye(128)
+    w = torch.arange(96)[:, None] * 0.01 + torch.arange(128)[None, :] * 1.0
+    out = hip.gemm(dev(a), dev(w))
+    assert out.dtype == torch.float32 and torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 72), (16384, 320, 320), (77, 1280, 768), (1024, 40, 1024),
+                                   (4, 1280, 320), (515, 64, 4), (130, 2560, 5120)])
+def test_gemm_f32(M, N, K):
+    a, w = f32(M, K, seed=1), f32(N, K, seed=2, scale=K ** -0.5)
+    bias, res = f32(N, seed=3, scale=0.1), f32(M, N, seed=4)
+    out = hip.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res), out_scale=0.5)
+    ref = (a.double() @ w.double().t() + bias.double() + res.double()) * 0.5
+    assert rel_err(out, ref.float()) < KTOL
+    rv = f32(2, N, seed=5)
+    if M % 2 == 0:
+        out = hip.gemm(dev(a), dev(w), rowvec=dev(rv), rows_per_batch=M // 2)
+        ref = a.double() @ w.double().t() + rv.double().repeat_interleave(M // 2, 0)
+        assert rel_err(out, ref.float()) < KTOL
+    # strided views: a column slice of a wider tensor as A, a column slice as the output
+    wide, owide = f32(M, K + 8, seed=6), torch.zeros(M, N + 4)
+    od = dev(owide)
+    hip.gemm(dev(wide)[:, 4:4 + K], dev(w), out=od[:, :N])
+    assert rel_err(od[:, :N], (wide[:, 4:4 + K].double() @ w.double().t()).float()) < KTOL and od[:, N:].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 40, 77), (4096, 64, 4096), (100, 160, 130), (64, 512, 64)])
+def test_gemm_nt_f32(M, N, K):
+    """out = a @ b with b [K, N] (the P.V product): K = 77 exercises the element-wise A loads (rows of 77 floats)"""
+    a, b = f32(M, K, seed=1, scale=K ** -0.5), f32(K, N, seed=2)
+    assert rel_err(hip.gemm_nt(dev(a), dev(b)), (a.double() @ b.double()).float()) < KTOL
+
+
+@pytest.mark.parametrize("B,H,C1,C2,Cout,stride,ups,extra,hi", [
+    (2, 16, 64, 0, 128, 1, False, False, False), (1, 32, 320, 0, 320, 1, False, False, False),
+    (2, 16, 128, 64, 128, 1, False, True, False), (2, 16, 64, 0, 64, 2, False, False, False),
+    (2, 8, 128, 0, 128, 1, True, False, False), (1, 16, 128, 0, 128, 2, False, False, True),
+    (4, 8, 64, 64, 64, 1, False, False, False), (1, 8, 32, 0, 36, 1, False, False, False)])
+def test_conv3x3_f32(B, H, C1, C2, Cout, stride, ups, extra, hi):
+    """3x3 implicit GEMM on the fp32 MFMA: channel-concat sources, stride 2, fused nearest-2x, fused 1x1 shortcut over the
+    raw inputs, the VAE's bottom/right-only padding; bias + per-image row vector + residual in the epilogue"""
+    x, x2 = f32(B, H, H, C1, seed=1), (f32(B, H, H, C2, seed=2) if C2 else None)
+    Ct = C1 + C2
+    w = f32(Cout, 3, 3, Ct, seed=3, scale=(9 * Ct) ** -0.5)
+    bias, rv = f32(Cout, seed=4, scale=0.1), f32(B, Cout, seed=5, scale=0.2)
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    xn = xin.permute(0, 3, 1, 2).double()
+    if ups:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    if hi:
+        xn = F.pad(xn, (0, 1, 0, 1))
+    ref = F.conv2d(xn, w.permute(0, 3, 1, 2).double(), bias.double(), stride=stride, padding=0 if hi else 1)
+    ref = ref + rv.double()[:, :, None, None]
+    if extra:
+        ws = f32(Cout, Ct, seed=6, scale=Ct ** -0.5)
+        ref = ref + F.conv2d(xin.permute(0, 3, 1, 2).double(), ws.double()[:, :, None, None])
+        wf = torch.cat([w.reshape(Cout, 9 * Ct), ws], 1)
+        out = hip.conv3x3(dev(x), dev(wf), dev(bias), x2=dev(x2), rowvec=dev(rv), extra=(dev(x), dev(x2)))
+    else:
+        res = f32(*ref.permute(0, 2, 3, 1).shape, seed=7)
+        ref = ref + res.permute(0, 3, 1, 2).double()
+        out = hip.conv3x3(dev(x), dev(w), dev(bias), x2=dev(x2), stride=stride, upsample=ups, rowvec=dev(rv),
+                          residual=dev(res), pad_hi_only=hi)
+    assert out.dtype == torch.float32
+    assert rel_err(out, ref.permute(0, 2, 3, 1).float()) < KTOL
+
+
+def _attn_ref(q, k, v, heads, scale, qs=None, ks=None, vs=None, hook=None):
+    B, N, C = q.shape
+    d = C // heads
+    idx = lambda t, s: t if s is None else t[torch.as_tensor(s).long()]
+    q, k, v = idx(q.double(), qs), idx(k.double(), ks), idx(v.double(), vs)
+    L = k.shape[1]
+    qh = q.reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    if hook is not None:
+        p = hook(p)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, N, C).float(), p.float()
+
+
+@pytest.mark.parametrize("B,heads,N,L,d", [(2, 8, 1024, 1024, 40), (4, 8, 256, 256, 80), (2, 2, 200, 144, 64),
+                                           (2, 4, 100, 77, 160), (1, 3, 96, 77, 32)])
+def test_attention_f32_materialised(B, heads, N, L, d):
+    """scores (batched fp32 GEMM over (batch row, head) on strided q | k | v views) + row softmax + P.V, with the batch-row
+    indirection of P2P self-replace / MasaCtrl; maps also handed out as `attn_probs` (generic controller path)"""
+    C = heads * d
+    qkv, kv = f32(B, N, 3 * C, seed=1), f32(B, L, 2 * C, seed=2)
+    qd, kd = dev(qkv), dev(kv)
+    q, k, v = qkv[..., :C], kv[..., :C], kv[..., C:]
+    scale = d ** -0.5
+    out = hip.attn_flash(qd[..., :C], kd[..., :C], kd[..., C:], heads, scale)
+    ref, refp = _attn_ref(q, k, v, heads, scale)
+    assert out.dtype == torch.float32 and rel_err(out, ref) < KTOL
+    probs = hip.attn_probs(qd[..., :C], kd[..., :C], heads, scale)
+    assert probs.shape == (B * heads, N, L) and probs.is_contiguous()
+    assert (probs.cpu() - refp.reshape(B * heads, N, L)).abs().max().item() < 1e-6
+    assert rel_err(hip.attn_apply(probs, kd[..., C:], heads), ref) < KTOL
+    if B >= 2:
+        src = torch.tensor([0] + [0] * (B - 1), dtype=torch.int32)
+        keep = torch.arange(B, dtype=torch.int32)
+        out = hip.attn_flash(qd[..., :C], kd[..., :C], kd[..., C:], heads, scale, q_src=dev(src), k_src=dev(src), v_src=dev(keep))
+        assert rel_err(out, _attn_ref(q, k, v, heads, scale, src, src, keep)[0]) < KTOL
+        out = hip.attn_flash(qd[..., :C], kd[..., :C], kd[..., C:], heads, scale, k_src=dev(src), v_src=dev(src))
+        assert rel_err(out, _attn_ref(q, k, v, heads, scale, None, src, src)[0]) < KTOL
+
+
+def test_cross_attention_p2p_edit_f32():
+    """`attn_cross_p2p` on fp32 operands: maps materialised, P' = c1 (P_src M) + c2 P_tgt applied in place on the target
+    rows (`/root/reference/p2p/model/attention_base.py:118-121`), then P.V"""
+    B, heads, N, L, d = 4, 8, 256, 77, 40
+    C = heads * d
+    q, k, v = f32(B, N, C, seed=1), f32(B, L, C, seed=2, scale=1.5), f32(B, L, C, seed=3)
+    g = torch.Generator().manual_seed(0)
+    mapper = torch.randint(-1, 77, (77,), generator=g)
+    a = (mapper != -1).float()
+    M = torch.zeros(77, 77)
+    M[mapper % 77, torch.arange(77)] = 1.0
+    M[5, 5], M[5, 6] = 1.0 / 3.0, 2.0 / 3.0                 # not representable in fp16: the table must be fp32
+    gate = (torch.rand(77, generator=g) > 0.3).float()
+    c1, c2 = gate * a, 1 - gate * a
+    mt = torch.zeros(1, 96, 96)
+    mt[0, :77, :77] = M.t()
+    coef = torch.zeros(1, 2, 96)
+    coef[0, 0, :77], coef[0, 1, :77] = c1, c2
+    es, sl = torch.tensor([-1, -1, -1, 2], dtype=torch.int32), torch.zeros(4, dtype=torch.int32)
+    out = hip.attn_cross_p2p(dev(q), dev(k), dev(v), heads, d ** -0.5, dev(es), dev(sl), dev(mt), dev(coef))
+
+    def hook(p):
+        p = p.clone()
+        p[3] = c1.double() * (p[2] @ M.double()) + c2.double() * p[3]
+        return p
+    assert rel_err(out, _attn_ref(q, k, v, heads, d ** -0.5, hook=hook)[0]) < KTOL
+    assert rel_err(hip.attn_cross_p2p(dev(q), dev(k), dev(v), heads, d ** -0.5), _attn_ref(q, k, v, heads, d ** -0.5)[0]) < KTOL
+
+
+def test_norms_and_elementwise_f32():
+    B, HW, C1, C2, G = 2, 1024, 320, 160, 32
+    x, x2 = f32(B, HW, C1, seed=1) * 2 + 0.5, f32(B, HW, C2, seed=2)
+    gamma, beta = 1 + f32(C1 + C2, seed=3, scale=0.1), f32(C1 + C2, seed=4, scale=0.1)
+    got = hip.groupnorm(dev(x), dev(gamma), dev(beta), G, 1e-5, silu=True, x2=dev(x2))
+    xin = torch.cat([x, x2], -1).double().permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xin, G, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 1)
+    assert got.dtype == torch.float32 and rel_err(got, ref.float()) < KTOL
+    got = hip.groupnorm(dev(x), dev(gamma[:C1]), dev(beta[:C1]), G, 1e-6)
+    ref = F.group_norm(x.double().permute(0, 2, 1), G, gamma[:C1].double(), beta[:C1].double(), 1e-6).permute(0, 2, 1)
+    assert rel_err(got, ref.float()) < KTOL
+    y = f32(300, 640, seed=5) * 3 + 1
+    g2, b2 = 1 + f32(640, seed=6, scale=0.1), f32(640, seed=7, scale=0.1)
+    assert rel_err(hip.layernorm(dev(y), dev(g2), dev(b2)), F.layer_norm(y.double(), (640,), g2.double(), b2.double()).float()) < KTOL
+    assert rel_err(hip.add(dev(y), dev(y * 0.5)), y * 1.5) < 1e-7
+    assert rel_err(hip.silu(dev(y)), F.silu(y.double()).float()) < 1e-6
+    # GEGLU on the interleaved FF1 layout: [8 hidden | 8 gate] groups
+    pre = f32(50, 2 * 64, seed=8)
+    grp = pre.reshape(50, 8, 2, 8)
+    ref = (grp[:, :, 0].double() * F.gelu(grp[:, :, 1].double())).reshape(50, 64)
+    assert rel_err(hip.geglu_il(dev(pre)), ref.float()) < 1e-6
+    t = torch.tensor([981.0, 1.0, 500.0])
+    emb = hip.timestep_embedding(dev(t), 320, dtype=torch.float32)
+    ref = unet_ref.timestep_embedding(t, 320)
+    assert (emb.cpu() - ref).abs().max().item() < 2e-4          # fp32 sin / cos of angles up to 981
+    src = torch.tensor([2, 0, 2, 1], dtype=torch.int32)
+    z = f32(4, 8, 8, 16, seed=9)
+    assert torch.equal(hip.gather_rows(dev(z), dev(src)).cpu(), z[src.long()])
+    s = f32(64, 77, seed=10) * 4
+    assert (hip.softmax_rows_(dev(s).clone()).cpu() - torch.softmax(s.double(), -1).float()).abs().max().item() < 1e-6
+
+
+def test_boundary_convs_and_image_epilogue_f32():
+    x = f32(2, 4, 16, 16, seed=1)
+    w_in, b_in = f32(64, 4, 3, 3, seed=2, scale=1 / 6.0), f32(64, seed=3, scale=0.1)
+    h = hip.conv_in(dev(x), dev(w_in.permute(2, 3, 1, 0).contiguous()), dev(b_in))
+    ref = F.conv2d(x.double(), w_in.double(), b_in.double(), padding=1).permute(0, 2, 3, 1)
+    assert h.dtype == torch.float32 and rel_err(h, ref.float()) < KTOL
+    w_out, b_out = f32(4, 64, 3, 3, seed=4, scale=1 / 24.0), f32(4, seed=5, scale=0.1)
+    y = hip.conv_out(h, dev(w_out.permute(0, 2, 3, 1).contiguous()), dev(b_out))
+    ref2 = F.conv2d(ref.permute(0, 3, 1, 2), w_out.double(), b_out.double(), padding=1)
+    assert y.shape == (2, 4, 16, 16) and rel_err(y, ref2.float()) < KTOL
+    img = f32(2, 3, 32, 40, seed=6) * 0.8
+    got = hip.image_u8(dev(img)).cpu().numpy()
+    want = ((img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).astype("uint8")     # sd_utils.py:85-88
+    assert got.shape == (2, 32, 40, 3) and (got == want).all()
+
+
+# ----------------------------------------------------------------------------------------------- whole path
+@pytest.fixture(scope="module")
+def tiny32():
+    return StableDiffusionPipeline.from_pretrained("synthetic:tiny", keep_state_dict=True, precision="f32")
+
+
+@pytest.fixture(scope="module")
+def small32():
+    return StableDiffusionPipeline.from_pretrained("synthetic:small", keep_state_dict=True, precision="f32")
+
+
+def _inputs(cfg, B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, 4, cfg.sample_size, cfg.sample_size, generator=g),
+            torch.randn(B, 77, cfg.cross_attention_dim, generator=g))
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 2), ("small", 4)])
+def test_unet_forward_exact_vs_oracle(name, B, tiny32, small32):
+    pipe = {"tiny": tiny32, "small": small32}[name]
+    assert pipe.unet.dtype == torch.float32
+    x, ctx = _inputs(pipe.cfg, B)
+    for t in (981, 1):
+        eps = pipe.unet(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV))["sample"]
+        ref = unet_ref.unet_forward(pipe._state_dict, pipe.cfg, x, torch.tensor(t), ctx)
+        e = rel_err(eps, ref)
+        print(f"exact {name} B={B} t={t}: rel err {e:.3e}")
+        assert e < 1e-4
+
+
+@pytest.mark.parametrize("kind,step", [("refine", 0), ("refine", 25), ("replace", 3)])
+def test_p2p_controlled_forward_exact(kind, step, small32):
+    """the lowered controller on the fp32 path (row indirection for self-replace, fp32 edit table on the materialised
+    cross maps) and the generic path (fp32 maps handed to the Python controller) against the oracle"""
+    pipe = small32
+    cfg = pipe.cfg
+    x1, ctx = _inputs(cfg, 4, seed=3)
+    x = torch.cat([x1[:1], 0.8 * x1[:1] + 0.6 * x1[1:2]] * 2)
+    make = (lambda: AttentionRefine(PROMPTS, pipe.tokenizer, 50, 0.8, 0.4, device=DEV)) if kind == "refine" else \
+        (lambda: AttentionReplace(PROMPTS_EQ, pipe.tokenizer, 50, 0.8, 0.4, device=DEV))
+    outs = {}
+    for fused in (True, False):
+        c = make()
+        register_attention_control(pipe, c, fused=fused)
+        c.cur_step = step
+        outs[fused] = pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
+        assert c.cur_step == step + 1 and c.cur_att_layer == 0
+        unregister_attention_control(pipe, c)
+    c = make()
+    rc = p2p_ref.P2PControlRef(mode=kind, num_prompts=2, cross_alpha=c.cross_replace_alpha.float().cpu(),
+                               num_self_replace=c.num_self_replace, mapper=c.mapper.cpu(),
+                               alphas=c.alphas.float().cpu() if hasattr(c, "alphas") else None)
+    rc.num_att_layers = unet_ref.count_attention_layers(cfg)
+    rc.cur_step = step
+    ref = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx, hook=rc)
+    plain = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx)
+    e_f, e_g, effect = rel_err(outs[True], ref), rel_err(outs[False], ref), rel_err(plain, ref)
+    print(f"exact {kind} step {step}: fused {e_f:.3e} generic {e_g:.3e} (the edit moves eps by {effect:.3e})")
+    assert e_f < 1e-4 and e_g < 1e-4 and effect > 100 * e_f
+
+
+def test_full_edit_images_exact_within_1e3(tiny32):
+    """north_star's bound: `P2P.text2image_ldm_stable` end to end (text encode -> 10-step AttentionRefine edit in the
+    captured step graph -> AutoencoderKL decode) in the reference-precision mode: decoded images in [0, 1] within 1e-3
+    max-abs of the fp32 oracle's, uint8 images within one grey level (truncation at a boundary)"""
+    from ief_amd.vae import synthetic_vae_state_dict
+    pipe = tiny32
+    cfg = pipe.cfg
+    n = 10
+    editor = P2P(pipe, n)
+    x_T = torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(8888))
+    c = AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV)
+    images, _ = editor.text2image_ldm_stable(pipe, PROMPTS, c, num_inference_steps=n, guidance_scale=7.5, latent=x_T.to(DEV))
+    assert pipe.unet._plan is not None and pipe.unet._plan.kind == "p2p" and c.cur_step == n      # the fused, captured path
+    c2 = AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV)
+    lat, _ = editor.text2image_ldm_stable(pipe, PROMPTS, c2, num_inference_steps=n, guidance_scale=7.5, latent=x_T.to(DEV),
+                                          return_latents=True)
+    unregister_attention_control(pipe, c2)
+    with torch.no_grad():
+        u, cnd = _encode_prompts(pipe, PROMPTS)
+    c3 = AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV)
+    rc = p2p_ref.P2PControlRef(mode="refine", num_prompts=2, cross_alpha=c3.cross_replace_alpha.float().cpu(),
+                               num_self_replace=c3.num_self_replace, mapper=c3.mapper.cpu(), alphas=c3.alphas.float().cpu())
+    ref_lat = p2p_ref.edit_loop(pipe._state_dict, cfg, torch.cat([u, cnd]).float().cpu(), x_T, rc, p2p_ref.DDIMRef(n), 7.5)
+    vsd = synthetic_vae_state_dict(pipe.vae.cfg, 2)
+    ref_dec = vae_ref.decode(vsd, pipe.vae.cfg, ref_lat / pipe.vae.cfg.scaling_factor)
+    got_dec = pipe.vae.decode(lat / pipe.vae.cfg.scaling_factor)["sample"].cpu()
+    e_lat = rel_err(lat, ref_lat)
+    d_img = ((got_dec / 2 + 0.5).clamp(0, 1) - (ref_dec / 2 + 0.5).clamp(0, 1)).abs().max().item()
+    diff = abs(images.astype(int) - p2p_ref.latent_to_uint8(ref_dec).astype(int))
+    print(f"exact 10-step edit: latents rel err {e_lat:.3e}; images in [0,1] max |diff| {d_img:.3e}; uint8 max diff {diff.max()}, "
+          f"identical pixels {(diff == 0).mean():.4f}")
+    assert e_lat < 3e-4 and d_img <= 1e-3 and diff.max() <= 1

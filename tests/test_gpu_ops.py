@@ -270,6 +270,49 @@ def test_attn_flash_variants(B, heads, N, L, d, variant):
     assert (lse - lse1).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("B,heads,N,d,variant", [
+    (1, 2, 9216, 64, 0), (1, 2, 9216, 64, 2),      # SD2.1 768x768: 96x96 latents, head dim 64
+    (1, 2, 4096, 64, 0), (2, 2, 1024, 64, 0),      # SDXL 1024x1024: 64x64 / 32x32 levels, head dim 64
+    (1, 2, 16384, 40, 0), (1, 2, 16384, 40, 2),    # SD1.5 geometry on 128x128 latents (1024x1024 px), head dim 40
+])
+def test_attn_flash_full_size_sequences(B, heads, N, d, variant):
+    """the self-attention instantiations of BASELINE.json's configs at their REAL sequence lengths (SD2.1 N = 9216, SDXL
+    N = 4096 / 1024 at d = 64; 1024x1024 latents on the SD1.5 net N = 16384 at d = 40), default and ping-pong kernels,
+    against the materialised fp32 softmax on the host"""
+    C = heads * d
+    q, k, v = h16(B, N, C, seed=11), h16(B, N, C, seed=12), h16(B, N, C, seed=13)
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, d ** -0.5, variant=variant).cpu()
+    for b in range(B):
+        for h in range(heads):          # one (batch, head) at a time: a 16384 x 16384 fp32 map is 1 GiB
+            sl = slice(h * d, (h + 1) * d)
+            p = torch.softmax(q[b, :, sl].float() @ k[b, :, sl].float().t() * d ** -0.5, -1)
+            err = close(out[b, :, sl], p @ v[b, :, sl].float(), 4e-3, 1e-3)
+    print(f"flash d={d} N={N} variant {variant}: last head max err {err:.2e}")
+
+
+@pytest.mark.parametrize("heads,N,d", [(2, 9216, 64), (2, 4096, 64), (2, 16384, 40)])
+def test_attn_cross_p2p_full_size_sequences(heads, N, d):
+    """the fused cross-attention edit at the query counts of the full-size configurations (77 keys)"""
+    B, L = 4, 77
+    C = heads * d
+    q, k, v = h16(B, N, C, seed=1), h16(B, L, C, seed=2, scale=1.5), h16(B, L, C, seed=3)
+    M, c1, c2 = _p2p_tables("refine")
+    mt = torch.zeros(1, 96, 96, dtype=torch.float16)
+    mt[0, :77, :77] = M.t().half()
+    coef = torch.zeros(1, 2, 96)
+    coef[0, 0, :77], coef[0, 1, :77] = c1, c2
+    edit_src = torch.tensor([-1, -1, -1, 2], dtype=torch.int32)
+    out = hip.attn_cross_p2p(dev(q), dev(k), dev(v), heads, d ** -0.5, dev(edit_src), dev(torch.zeros(4, dtype=torch.int32)),
+                             dev(mt), dev(coef))
+
+    def hook(p):
+        p = p.clone()
+        p[3] = c1 * (p[2] @ M.half().float()) + c2 * p[3]
+        return p
+    ref, _ = _attn_ref(q, k, v, heads, d ** -0.5, hook=hook)
+    close(out, ref, 4e-3, 1e-3)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attn_flash_peaky_rows(variant):
     """forces the online-softmax rescale: one key per tile dominates, growing tile by tile."""
@@ -422,6 +465,12 @@ def test_timestep_embedding_silu_casts_select():
     assert torch.equal(out.cpu(), table[3])
     hip.advance_step(step)
     assert step.item() == 4
+    # a step counter past the table (a captured loop replayed too often) or below it reads the last / first row, never
+    # memory outside the table
+    for s, row in ((5, 4), (1 << 20, 4), (-3, 0)):
+        step.fill_(s)
+        hip.select_step(dev(table), out, step)
+        assert torch.equal(out.cpu(), table[row]), s
 
 
 def test_bad_arguments_are_rejected():

@@ -2,12 +2,15 @@
 
 The HIP path stores activations and weights in fp16 (fp32 accumulation / statistics); the oracle
 is fp32 throughout (the reference's precision).  Stated tolerances, relative to
-max|reference|:
-    one UNet forward (eps)                          <= 2e-2
-    fused plan path vs generic Python-controller    <= 1e-2   (same kernels, maps in fp16 both ways)
-    N-step edited latents                           <= 5e-2 after 5 steps (error compounds per step)
-Measured values are printed (`-s`) and recorded in DESIGN.md.
+max|reference| (each <= 2.5x the value measured on MI355X, which the tests print with `-s` and DESIGN.md records):
+    one UNet forward (eps)                          <= 5e-3    (measured 1.6-2.4e-3)
+    fused plan path vs generic Python-controller    <= 5e-3    (same kernels, maps in fp16 both ways; 1.7-2.0e-3)
+    N-step latents (5-6 steps, TINY)                <= 1.2e-2  (error compounds per step; 1.6-4e-3)
+    uint8 images after a 10-step edit + VAE decode  every pixel within 2 grey levels
+The exact (fp32-MFMA) mode's bounds are in test_gpu_exact.py.
 """
+FWD_TOL, LOOP_TOL = 5e-3, 1.2e-2
+
 import pytest
 import torch
 
@@ -16,7 +19,8 @@ pytestmark = pytest.mark.gpu
 from ief_amd import config, weights  # noqa: E402
 from ief_amd.pipeline import StableDiffusionPipeline  # noqa: E402
 from ief_amd.p2p.model.attention_base import EmptyControl  # noqa: E402
-from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace  # noqa: E402
+from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace, AttentionReweight  # noqa: E402
+from ief_amd.p2p.model import seq_aligner  # noqa: E402
 from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control  # noqa: E402
 from ief_amd.p2p.model.sd_utils import P2P  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion  # noqa: E402
@@ -54,7 +58,9 @@ def _ref_controller(ctrl, nprompts):
     """oracle controller carrying the same tables as a product controller object"""
     name = type(ctrl).__name__
     mode = {"AttentionRefine": "refine", "AttentionReplace": "replace", "AttentionReweight": "reweight"}[name]
+    prev = getattr(ctrl, "prev_controller", None)
     return p2p_ref.P2PControlRef(
+        prev=None if prev is None else _ref_controller(prev, nprompts),
         mode=mode, num_prompts=nprompts, cross_alpha=ctrl.cross_replace_alpha.float().cpu(),
         num_self_replace=ctrl.num_self_replace, mapper=ctrl.mapper.cpu() if hasattr(ctrl, "mapper") else None,
         alphas=ctrl.alphas.float().cpu() if hasattr(ctrl, "alphas") else None,
@@ -72,18 +78,29 @@ def test_unet_forward_matches_oracle(name, B, tiny, small):
         e = rel_err(eps, ref)
         print(f"{name} B={B} t={t}: rel err {e:.3e}")
         assert eps.dtype == torch.float32 and eps.shape == ref.shape
-        assert e < 2e-2
+        assert e < FWD_TOL
 
 
-@pytest.mark.parametrize("kind,step", [("refine", 0), ("refine", 25), ("refine", 45), ("replace", 3)])
+@pytest.mark.parametrize("kind,step", [("refine", 0), ("refine", 25), ("refine", 45), ("replace", 3), ("reweight", 3),
+                                       ("reweight_chain", 3), ("reweight_chain", 30)])
 def test_p2p_controlled_forward_fused_generic_oracle(kind, step, small):
+    """every lowerable controller class (`/root/reference/p2p/model/attention_control.py:8-46`; AttentionReweight alone and
+    chained on an AttentionRefine) through the fused kernels AND through the generic path (HIP-materialised maps handed to
+    the Python controller), both against the oracle"""
     pipe = small
     cfg = pipe.cfg
     x1, ctx = _inputs(cfg, 4, seed=3)
     ctx = ctx * 10.0                                      # unit-variance embeddings: peaky cross-attention maps
     x = torch.cat([x1[:1], 0.8 * x1[:1] + 0.6 * x1[1:2]] * 2)  # src/tgt latents diverged, CFG-duplicated
-    make = (lambda: AttentionRefine(PROMPTS, pipe.tokenizer, 50, 0.8, 0.4, device=DEV)) if kind == "refine" else \
-        (lambda: AttentionReplace(PROMPTS_EQ, pipe.tokenizer, 50, 0.8, 0.4, device=DEV))
+    eq = lambda: seq_aligner.get_equalizer(pipe.tokenizer, PROMPTS[1], ("fall",), (4.0,))
+    make = {
+        "refine": lambda: AttentionRefine(PROMPTS, pipe.tokenizer, 50, 0.8, 0.4, device=DEV),
+        "replace": lambda: AttentionReplace(PROMPTS_EQ, pipe.tokenizer, 50, 0.8, 0.4, device=DEV),
+        "reweight": lambda: AttentionReweight(PROMPTS, pipe.tokenizer, 50, 0.8, 0.4, eq(), device=DEV),
+        "reweight_chain": lambda: AttentionReweight(
+            PROMPTS, pipe.tokenizer, 50, 0.8, 0.4, eq(), device=DEV,
+            controller=AttentionRefine(PROMPTS, pipe.tokenizer, 50, 0.8, 0.4, device=DEV)),
+    }[kind]
     outs = {}
     for fused in (True, False):
         c = make()
@@ -101,7 +118,7 @@ def test_p2p_controlled_forward_fused_generic_oracle(kind, step, small):
     effect = rel_err(ref_plain, ref)
     print(f"{kind} step {step}: fused-vs-oracle {e_f:.3e} generic-vs-oracle {e_g:.3e} fused-vs-generic {e_fg:.3e} "
           f"(size of the edit itself {effect:.3e})")
-    assert e_f < 2e-2 and e_g < 2e-2 and e_fg < 1e-2
+    assert e_f < FWD_TOL and e_g < FWD_TOL and e_fg < FWD_TOL
     if step < 40:
         assert effect > 4 * e_f, "the control must change the output by far more than the kernel error"
 
@@ -131,7 +148,7 @@ def test_edit_loop_graph_vs_eager_vs_oracle(tiny):
     ref = p2p_ref.edit_loop(pipe._state_dict, cfg, ctx, x_T, rc, sched, 7.5, num_steps=steps)
     e_g, e_e, e_ge = rel_err(res["graph"], ref), rel_err(res["generic"], ref), rel_err(res["graph"], res["generic"])
     print(f"{steps}-step edit: graph-vs-oracle {e_g:.3e} generic-vs-oracle {e_e:.3e} graph-vs-generic {e_ge:.3e}")
-    assert e_g < 5e-2 and e_e < 5e-2 and e_ge < 3e-2
+    assert e_g < LOOP_TOL and e_e < LOOP_TOL and e_ge < LOOP_TOL
 
 
 def _context(pipe, prompts):
@@ -175,20 +192,7 @@ def test_inversion_loop_graph_vs_oracle(tiny):
     for i in (1, 3, 6):
         e = rel_err(all_lat[i], ref[i])
         print(f"inversion step {i}: rel err {e:.3e}")
-        assert e < 3e-2
-
-
-def test_sd15_full_size_forward_matches_oracle():
-    """SD1.5 shapes, 512x512 (64x64 latent), B=1: the configuration the headline metric is quoted on."""
-    cfg = config.SD15
-    pipe = StableDiffusionPipeline.from_pretrained("synthetic:sd15", keep_state_dict=True)
-    x, ctx = _inputs(cfg, 1, seed=5)
-    eps = pipe.unet(x.to(DEV), 481, encoder_hidden_states=ctx.to(DEV))["sample"]
-    torch.set_num_threads(max(1, torch.get_num_threads()))
-    ref = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(481), ctx)
-    e = rel_err(eps, ref)
-    print(f"sd15 B=1 512^2: rel err {e:.3e}")
-    assert e < 2e-2
+        assert e < LOOP_TOL
 
 
 # ----------------------------------------------------------------------------- MasaCtrl (mutual self-attention)
@@ -215,7 +219,7 @@ def test_masactrl_forward_and_loop_vs_oracle(tiny):
         plain = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx)
         e, effect = rel_err(got, ref), rel_err(plain, ref)
         print(f"masactrl step {step}: fused-vs-oracle {e:.3e}, size of the control {effect:.3e}")
-        assert e < 2e-2
+        assert e < FWD_TOL
         assert (effect > 10 * e) if active else (effect == 0.0)
     # 6-step sampler (graph loop) from a shared x_T: controlled steps 4, 5
     editor = MasaCtrl(pipe, 50)
@@ -244,7 +248,7 @@ def test_masactrl_forward_and_loop_vs_oracle(tiny):
         lat_ref = sched.step(eu + 7.5 * (ec - eu), int(t), lat_ref)
     e = rel_err(lat, lat_ref)
     print(f"masactrl 6-step sampler: rel err {e:.3e}")
-    assert e < 5e-2
+    assert e < LOOP_TOL
 
 
 def test_full_edit_images_vs_oracle(tiny):
@@ -273,7 +277,7 @@ def test_full_edit_images_vs_oracle(tiny):
     diff = abs(images.astype(int) - ref_img.astype(int))
     print(f"10-step edit: latents rel err {e:.3e}; uint8 images max diff {diff.max()}, mean {diff.mean():.3f}, "
           f"pixels within 2 levels {(diff <= 2).mean():.4f}")
-    assert e < 5e-2 and (diff <= 3).mean() > 0.99
+    assert e < LOOP_TOL and diff.max() <= 2
 
 
 def test_pooled_step_graph_reuse_matches_fresh_capture(tiny):

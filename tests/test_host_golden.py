@@ -130,6 +130,54 @@ def test_controller_sweeps_match_reference(which, name, tok, ctrl):
         assert [c.cur_step, c.cur_att_layer] == list(ctrl[f"{name}_s{step}_after"])
 
 
+def _oracle_of(c, nprompt):
+    o = _as_oracle(c, nprompt)
+    if getattr(c, "prev_controller", None) is not None:
+        o.prev = _as_oracle(c.prev_controller, nprompt)
+    return o
+
+
+@pytest.mark.parametrize("which", ["mirror", "oracle", "lowered"])
+def test_chained_reweight_matches_reference(which, tok, golden_dir):
+    """G3b: AttentionReweight(controller=AttentionRefine) — the host mirror, the oracle's `prev` chain, and the device
+    tables the fused cross-attention kernel reads (`register._edit_tables`: P' = c1 (P_src M) + c2 P_tgt) all reproduce the
+    reference's maps"""
+    from ief_amd.p2p.model import register
+    chain = np.load(os.path.join(golden_dir, "p2p_ctrl_chain.npz"))
+    a, b = PROMPT_PAIRS[0]
+    eq = seq_aligner.get_equalizer(tok, b, ("fall",), (3.0,))
+    assert np.array_equal(eq.numpy(), chain["chain_equalizer"])
+
+    def make():
+        prev = attention_control.AttentionRefine([a, b], tok, 50, 0.8, 0.4, device=CPU)
+        return attention_control.AttentionReweight([a, b], tok, 50, 0.8, 0.4, eq, controller=prev, device=CPU)
+    bh = 8
+    for step in (0, 39, 40):
+        c = make()
+        if which == "lowered":
+            plan = register.lower_controller(c, CPU)
+            assert plan is not None and plan.kind == "p2p"
+            c1, c2 = plan.coef_table[step, 0, 0, :77], plan.coef_table[step, 0, 1, :77]
+            M = plan.mt[0, :77, :77].float().t()
+        elif which == "oracle":
+            c = _oracle_of(c, 2)
+        if which != "lowered":
+            c.num_att_layers = 2
+            c.cur_step = step
+        for li, (n, l) in enumerate([(64, 77), (16, 77)]):
+            x = softmax_maps(1500 + li, bh, n, l)
+            if which == "lowered":
+                cond = x[bh // 2:].reshape(2, 2, n, l)
+                y = c1 * (cond[0] @ M) + c2 * cond[1]
+                assert np.allclose(y.numpy(), chain[f"chain_s{step}_l{li}"][2:], rtol=0, atol=1e-6), (step, li)
+                continue
+            y = c(x.clone(), True, "down")
+            assert torch.equal(x[: bh // 2], y[: bh // 2]) == bool(chain[f"chain_s{step}_l{li}_uncond_same"])
+            assert np.array_equal(y[bh // 2:].numpy(), chain[f"chain_s{step}_l{li}"]), (step, li)
+        if which != "lowered":
+            assert [c.cur_step, c.cur_att_layer] == list(chain[f"chain_s{step}_after"])
+
+
 def test_controller_edits_in_place_and_aliases(tok):
     _, make = _controllers(tok)["refine"]
     c = make()
