@@ -60,12 +60,19 @@ def parse():
                     "(comma list, '' to skip); reported beside the headline value, which is ONE edit at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--split", choices=["none", "cfg"], default="none",
+                    help="cfg: --gpus 2 run ONE edit together (rank 0 the unconditional rows of the CFG batch, rank 1 the "
+                    "conditional rows + controller plan, one 128 KiB eps all-gather per step over RCCL; SURVEY.md 8e); "
+                    "value is then the steps/s of that one edit (strong scaling)")
+    ap.add_argument("--exact-steps", type=int, default=5,
+                    help="also time this many edit steps in the reference-precision mode (fp32 weights / activations on the "
+                    "fp32-input MFMA, precision='f32'); N = 1 only; 0: skip")
     ap.add_argument("--pie-images", type=int, default=8, help="synthetic PIE images timed per GPU for images_per_sec (0: skip)")
     ap.add_argument("--steps-1024", type=int, default=10, help="timed edit steps on 128x128 latents (0: skip)")
     return ap.parse_args()
 
 
-def build_pipe(cfg_name, dev, rank, world):
+def build_pipe(cfg_name, dev, rank, world, precision="f16"):
     """rank 0 draws the synthetic weights; other ranks receive the PACKED device tensors by RCCL broadcast."""
     import ief_amd  # noqa: F401
     from ief_amd import config, weights
@@ -79,14 +86,14 @@ def build_pipe(cfg_name, dev, rank, world):
         sd = weights.synthetic_state_dict(cfg, 0)
     else:
         sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(cfg).items()}
-    unet = UNet2DConditionModel(cfg, sd, device=dev)
+    unet = UNet2DConditionModel(cfg, sd, device=dev, precision=precision)
     if world > 1:
         from ief_amd.dist import broadcast_tensors
         broadcast_tensors(unet.packed_tensors(), src=0)   # RCCL over xGMI, a few flat buckets
         torch.cuda.synchronize()
     pipe = StableDiffusionPipeline(unet, WordPieceTokenizer(cfg.text_max_length),
                                    SyntheticTextEncoder(cfg.cross_attention_dim).to(dev),
-                                   AutoencoderKL(SD_VAE if cfg_name in ("sd15", "sd21") else TINY_VAE, device=dev),
+                                   AutoencoderKL(SD_VAE if cfg_name in ("sd15", "sd21") else TINY_VAE, device=dev, precision=precision),
                                    DDIMScheduler(), cfg, sd if rank == 0 else None)
     return pipe, cfg
 
@@ -105,17 +112,23 @@ def make_added(cfg, hw, rank, dev):
 class EditJob:
     """one P2P AttentionRefine edit (controller + captured step loop) on `hw` x `hw` latents"""
 
-    def __init__(self, pipe, cfg, ctx, hw, dev, rank, uncond_list):
-        from ief_amd.denoise import FusedDenoiser
+    def __init__(self, pipe, cfg, ctx, hw, dev, rank, uncond_list, split_group=None):
+        from ief_amd.denoise import CfgSplitDenoiser, FusedDenoiser
         from ief_amd.p2p.model.attention_control import AttentionRefine
         from ief_amd.p2p.model.register import register_attention_control
         self.pipe, self.hw = pipe, hw
-        # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19)
-        self.x_T = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(8888 + rank)).to(dev)
+        # every rank edits its own image: same prompts, rank-specific x_T (seed 8888 + rank, edit_syn.py:19); the two
+        # ranks of a CFG split share ONE image
+        seed = 8888 + (rank if split_group is None else 0)
+        self.x_T = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(seed)).to(dev)
         self.ctrl = AttentionRefine(PROMPTS, pipe.tokenizer, MAX_STEPS, 0.8, 0.4, device=dev)
-        register_attention_control(pipe, self.ctrl)
         self.added = make_added(cfg, hw, rank, dev)
-        self.loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=self.added)
+        if split_group is not None:
+            register_attention_control(pipe, self.ctrl, rows="cond" if rank == 1 else "uncond")
+            self.loop = CfgSplitDenoiser(pipe, ctx, 2, (hw, hw), 7.5, group=split_group, uncond_list=uncond_list)
+        else:
+            register_attention_control(pipe, self.ctrl)
+            self.loop = FusedDenoiser(pipe, ctx, 2, (hw, hw), 7.5, uncond_list=uncond_list, added_cond_kwargs=self.added)
         self.loop.run(self.x_T, num_steps=0)      # allocates, warms up eagerly (untimed) and captures the graph
 
     def rewind(self):
@@ -196,6 +209,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.split == "cfg":
+        if world != 2 or cfg.addition_embed:
+            raise SystemExit("--split cfg runs one SD1.x / SD2.x edit on exactly two ranks (--gpus 2 under torchrun)")
+        job = EditJob(pipe, cfg, ctx, hw, dev, rank, uncond_list, split_group=dist.group.WORLD)
+        elapsed = job.timed(args.steps, args.warmup, barrier, dist, dev)
+        if rank == 0:
+            print(json.dumps({
+                "metric": f"denoising steps/sec ({MODEL_NAMES.get(args.config, args.config)} {hw * 8}x{hw * 8} P2P edit step, ONE "
+                          "edit CFG-split over 2 GPUs)",
+                "value": round(args.steps / elapsed, 3), "unit": "steps/s", "n_gpus": 2, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "config": {"workload": f"{args.config} UNet P2P AttentionRefine edit step, rank 0: unconditional rows (UNet batch 2), "
+                                       f"rank 1: conditional rows + controller plan (UNet batch 2), one eps all-gather per step, "
+                                       f"{hw}x{hw} latents"}}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     # ---- headline: K edit steps between barriers
     job = EditJob(pipe, cfg, ctx, hw, dev, rank, uncond_list)
     elapsed = job.timed(args.steps, args.warmup, barrier, dist, dev)
@@ -242,6 +274,22 @@ def main():
     # ---- BASELINE.json's second metric: PIE-Bench images/sec (reference per-image order, then the batched schedule)
     if args.pie_images > 0 and not cfg.addition_embed:
         out.update(pie_images_per_sec(pipe, dev, rank, world, dist, barrier, args.pie_images))
+
+    # ---- the same edit step in the reference-precision mode (edited images within 1e-3 of the fp32 reference: DESIGN.md §4)
+    if args.exact_steps > 0 and world == 1 and not cfg.addition_embed:
+        sd_host = pipe._state_dict
+        pipe32, _ = build_pipe(args.config, dev, rank, world, precision="f32")
+        pipe32.scheduler.set_timesteps(MAX_STEPS)
+        job3 = EditJob(pipe32, cfg, ctx, hw, dev, rank, uncond_list)
+        el3 = job3.timed(args.exact_steps, 1, barrier, dist, dev)
+        out["exact_mode"] = {"precision": "f32 storage, fp32-input MFMA (v_mfma_f32_32x32x2_f32), attention maps materialised",
+                             "steps_per_sec": round(args.exact_steps / el3, 3), "ms_per_step": round(el3 / args.exact_steps * 1e3, 3),
+                             "steps": args.exact_steps, "peak_tflops_f32_mfma": 157.3,
+                             "achieved_tflops": round(args.exact_steps / el3 * FLOP_PER_STEP / 1e12, 2) if (args.config, hw) == ("sd15", 64) else None}
+        job3.close()
+        del job3, pipe32
+        torch.cuda.empty_cache()
+        pipe._state_dict = sd_host
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -73,12 +73,16 @@ class ControlPlan:
     def __init__(self, controller, kind: str, device, num_prompts: int = 1, num_steps: int = 0,
                  mt: Optional[torch.Tensor] = None, coef_table: Optional[torch.Tensor] = None,
                  self_window=(0, 0), self_max_tokens: int = 256, masa_steps=(), masa_layers=(),
-                 pnp_layers=(), pnp_qk_steps: int = 0, pnp_conv_steps: int = 0):
+                 pnp_layers=(), pnp_qk_steps: int = 0, pnp_conv_steps: int = 0, cond_only: bool = False):
+        """cond_only: the UNet batch holds ONLY the conditional rows [cond_src, cond_tgt...] — the half a controller acts
+        on (`attention_base.py:20-22`) — as on the conditional rank of a 2-GPU CFG split (`denoise.CfgSplitDenoiser`) and
+        in the reference's LOW_RESOURCE protocol (:18-19)"""
         self.controller = controller
         self.kind = kind
         self.device = torch.device(device)
         self.num_prompts = num_prompts
-        self.batch = 2 * num_prompts
+        self.cond_only = bool(cond_only)
+        self.batch = num_prompts if cond_only else 2 * num_prompts
         self.num_steps = num_steps
         self.self_window = self_window
         self.self_max_tokens = self_max_tokens
@@ -94,15 +98,16 @@ class ControlPlan:
             self.mt32 = mt.to(device=dev, dtype=torch.float32).contiguous()      # the reference-precision kernels' copy
             self.coef_table = coef_table.to(device=dev, dtype=torch.float32).contiguous()
             self.coef_cur = torch.zeros(slots, 2, XL, dtype=torch.float32, device=dev)
+            off = 0 if cond_only else Bp          # first conditional row (= the source prompt's) of this UNet batch
             es = torch.full((B,), -1, dtype=torch.int32)
             sl = torch.zeros(B, dtype=torch.int32)
             for k in range(slots):
-                es[Bp + 1 + k] = Bp
-                sl[Bp + 1 + k] = k
+                es[off + 1 + k] = off
+                sl[off + 1 + k] = k
             self.edit_src, self.edit_slot = es.to(dev), sl.to(dev)
             ident = torch.arange(B, dtype=torch.int32)
             repl = ident.clone()
-            repl[Bp + 1:] = Bp
+            repl[off + 1:] = off
             tab = ident.repeat(num_steps + 1, 1)
             lo, hi = self_window
             tab[lo:hi] = repl
@@ -152,7 +157,7 @@ class ControlPlan:
         """everything about this plan that is BAKED into a captured step graph (which kernels run, on which modules,
         with tables of which shape); two plans with equal signatures differ only in table contents"""
         if self.kind == "p2p":
-            return ("p2p", self.num_prompts, self.num_steps, self.self_max_tokens, tuple(self.mt.shape))
+            return ("p2p", self.num_prompts, self.num_steps, self.self_max_tokens, tuple(self.mt.shape), self.cond_only)
         if self.kind == "masactrl":
             return ("masactrl", tuple(sorted(self.masa_layers)), (max(self.masa_steps) + 2) if self.masa_steps else 1)
         if self.kind == "pnp":

@@ -237,6 +237,131 @@ class FusedDenoiser:
         self.graph = None
 
 
+def cfg_split_rows(context: torch.Tensor, num_latents: int, half: int) -> torch.Tensor:
+    """rows of the CFG context [uncond..., cond...] that rank `half` of a 2-GPU CFG split runs (0: unconditional)"""
+    if context.shape[0] != 2 * num_latents or half not in (0, 1):
+        raise ValueError("cfg_split_rows: context must be [2 * num_latents, ...] and half 0 or 1")
+    return context[:num_latents] if half == 0 else context[num_latents:]
+
+
+def exchange_eps(eps_all: torch.Tensor, mine: torch.Tensor, group=None):
+    """the ONE exchange of a CFG-split step: every rank contributes its half of eps ([Bp,4,h,w] fp32, 64 KiB per latent at
+    64x64) and receives both, rank order = [unconditional, conditional] (`/root/reference/p2p/model/sd_utils.py:74`: the
+    chunk(2) the CFG combine reads).  RCCL all-gather on device buffers; on a gloo group (CPU tests, two ranks sharing one
+    GPU) the halves are staged through host memory."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, mine.detach().cpu().contiguous(), group=group)
+        eps_all.copy_(torch.cat(parts).to(eps_all.device))
+    else:
+        dist.all_gather_into_tensor(eps_all, mine.contiguous(), group=group)
+    return eps_all
+
+
+class CfgSplitDenoiser(FusedDenoiser):
+    """ONE edit on TWO GPUs: the CFG batch [uncond_src, uncond_tgt | cond_src, cond_tgt] has no data
+    dependence between its halves inside the UNet — controllers act on the conditional rows only
+    (`/root/reference/p2p/model/attention_base.py:20-22`) — so rank 0 of the pair runs the unconditional rows, rank 1
+    the conditional rows with the controller's plan, and each step needs one exchange: the two eps halves (128 KiB at
+    64x64 latents) are all-gathered before the CFG combine (`sd_utils.py:74-75`).  Both ranks then apply the same fused
+    CFG + DDIM update to their own copy of the latents, which therefore stay identical without a second exchange.
+
+    Per step: captured graph A {row selects, UNet on this rank's rows} -> all-gather -> captured graph B {CFG + DDIM
+    update, advance}.  The controller must be registered with `rows="uncond"` / `rows="cond"` on the two ranks
+    (`p2p.model.register.register_attention_control`); its counters advance on both."""
+
+    def __init__(self, model, context, num_latents, latent_hw, guidance_scale: float, group=None, uncond_list=None,
+                 use_graph: bool = True):
+        import torch.distributed as dist
+        if dist.get_world_size(group) != 2:
+            raise ValueError("a CFG split runs on a group of exactly two ranks")
+        self.group = group
+        self.half = dist.get_rank(group)
+        self._guidance = float(guidance_scale)
+        plan = model.unet._plan
+        want = num_latents
+        if plan is not None and plan.kind == "p2p" and (not plan.cond_only or self.half != 1 or plan.batch != want):
+            raise ValueError('CFG split: register the controller with rows="cond" on rank 1 and rows="uncond" on rank 0')
+        super().__init__(model, cfg_split_rows(context, num_latents, self.half), num_latents, latent_hw, None, mode="denoise",
+                         uncond_list=uncond_list if self.half == 0 else None, use_graph=use_graph)
+        C = self.unet.config.in_channels
+        h, w = latent_hw
+        self.eps_all = torch.zeros(2 * self.Bp, C, h, w, dtype=torch.float32, device=self.lat.device)
+        self.eps_mine = torch.zeros(self.Bp, C, h, w, dtype=torch.float32, device=self.lat.device)
+        self.graph_b = None
+
+    def _fill(self, context, guidance_scale, uncond_list, added_cond_kwargs=None):
+        super()._fill(context, None, uncond_list, added_cond_kwargs)
+        self.coef_table[:, 2] = self._guidance          # the parent wrote 1.0 (no CFG inside ITS step)
+
+    # ---- the two captured halves of a step
+    def _forward_part(self):
+        hip.select_step(self.temb_table, self.temb_cur, self.step)
+        hip.select_step(self.coef_table, self.coef_cur, self.step)
+        if self.ctx_table is not None:
+            hip.select_step(self.ctx_table, self.ctx, self.step)
+        eps = self.unet(self.lat, encoder_hidden_states=self.ctx, temb_row=self.temb_cur)["sample"]
+        self.eps_mine.copy_(eps)
+
+    def _update_part(self):
+        hip.cfg_ddim_step(self.eps_all[: self.Bp], self.eps_all[self.Bp:], self.lat, self.coef_cur, out=self.lat)
+        hip.advance_step(self.step)
+
+    def _step_body(self):
+        self._forward_part()
+        exchange_eps(self.eps_all, self.eps_mine, self.group)
+        self._update_part()
+
+    def _capture(self):
+        plan = self.plan
+        self._set_kv_cache(self.ctx_table is None)
+        saved = self.lat.clone()
+        if plan is not None:
+            plan.prepare(self.B)
+            plan.muted = True
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._forward_part()            # warm-up of the forward half only: no collective on a side stream
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if plan is not None:
+            plan.muted = False
+        self.step.zero_()
+        if plan is not None:
+            plan.sync_step()
+            plan.captured = True
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._forward_part()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b):
+            self._update_part()
+        self.lat.copy_(saved)
+        self.step.zero_()
+        if plan is not None:
+            plan.sync_step()
+
+    def step_once(self):
+        if self._done >= self.num_steps:
+            raise IndexError(f"step {self._done} is past the {self.num_steps}-step schedule this loop was built for")
+        self._done += 1
+        if self.graph is not None:
+            self.graph.replay()
+            exchange_eps(self.eps_all, self.eps_mine, self.group)
+            self.graph_b.replay()
+            if self.plan is not None:
+                self.plan.replay_done()
+        else:
+            self._step_body()
+
+    def release(self):
+        if self.plan is not None:
+            self.plan.captured = False
+        self.graph = self.graph_b = None
+
+
 def acquire(model, context, num_latents, latent_hw, guidance_scale, mode="denoise", uncond_list=None,
             use_graph=True, added_cond_kwargs=None) -> FusedDenoiser:
     """a FusedDenoiser for this job: a pooled one with a captured graph of the same shape / plan signature, re-pointed

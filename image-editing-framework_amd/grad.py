@@ -41,6 +41,9 @@ class UNetAdjoint:
     def __init__(self, unet, grad_scale: float = 1.0, mode: str = "context"):
         if mode not in ("context", "input"):
             raise ValueError("UNetAdjoint: mode must be 'context' or 'input'")
+        if unet.dtype != torch.float16:
+            raise NotImplementedError("the activation-gradient pass (null-text inversion, Pix2Pix-zero) exists on the fp16 "
+                                      'path only: build the pipeline with precision="f16"')
         self.unet = unet
         self.mode = mode
         self.grad_scale = float(grad_scale)

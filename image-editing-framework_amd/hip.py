@@ -1027,9 +1027,9 @@ def _batched32(p, t, heads, d, which):
     return t.stride(0), d, t.stride(1)
 
 
-def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None):
+def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None, softmax=True):
     """materialised maps softmax(scale q k^T) as contiguous fp32 [B*heads, N, L] (`register.py:43-47`): one batched
-    launch of the fp32 GEMM over (batch row, head) + a row softmax"""
+    launch of the fp32 GEMM over (batch row, head) + a row softmax (softmax=False: the scaled scores themselves)"""
     lib = load()
     _act32(q, "q"), _act32(k, "k")
     B, N, C = q.shape
@@ -1049,9 +1049,19 @@ def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None):
     p.a_src, p.w_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src"))
     with _Timed(f"igemm_f32_kernel<scores {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention scores)")
-    with _Timed("softmax_rows_f32_kernel", 0.0, 8.0 * out.numel()):
-        _check(lib.ief_softmax_rows_f32(out.data_ptr(), out.numel() // L, L, _stream()), "ief_softmax_rows_f32")
+    if softmax:
+        with _Timed("softmax_rows_f32_kernel", 0.0, 8.0 * out.numel()):
+            _check(lib.ief_softmax_rows_f32(out.data_ptr(), out.numel() // L, L, _stream()), "ief_softmax_rows_f32")
     return out
+
+
+def attn_scores(q, k, heads, scale):
+    """PRE-softmax scores scale * q k^T as contiguous [B*heads, N, L] in q's dtype — the `sim` tensor MasaCtrl's editor
+    protocol hands to user editors (`/root/reference/masactrl/model/register.py:35`).  Generic-path only (fp32 MFMA)."""
+    if _is32(q):
+        return _attn_scores_f32(q, k, heads, scale, softmax=False)
+    s32 = _attn_scores_f32(to_f32(_dev16(q, "q")), to_f32(_dev16(k, "k")), heads, scale, softmax=False)
+    return to_f16(s32)
 
 
 def _attn_apply_f32(probs, v, heads, v_src=None, out=None):

@@ -61,8 +61,11 @@ class MasaCtrl:
         if self.xl:       # `MasaCtrl_XL.__call__` (:148-149): both text encoders + the pooled / time-id conditioning
             context, added_cond_kwargs = encode_prompt_xl(model, prompt, dev, guidance_scale > 1.0, height, width, batch_size)
         model.scheduler.set_timesteps(num_inference_steps)
+        # a user editor on the generic path runs its own Python inside every forward: step eagerly then (a captured graph
+        # would replay the kernels of the capture pass without calling it)
+        native = all(m.is_native() for m in model.unet.attention_modules())
         loop = acquire(model, context, batch_size, (height // 8, width // 8), g, uncond_list=uncond_list,
-                       added_cond_kwargs=added_cond_kwargs)
+                       added_cond_kwargs=added_cond_kwargs, use_graph=native)
         try:
             latents = loop.run(latents)
         finally:

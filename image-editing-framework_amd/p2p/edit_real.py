@@ -26,6 +26,8 @@ parser.add_argument("--source_prompt", type=str, default="a gray horse in the fi
 parser.add_argument("--target_prompt", type=str, default="a whie horse in the field")
 parser.add_argument("--source_image", type=str, default="./test.jpg")
 parser.add_argument("--inversion_type", type=str, default="null-text")
+# not a reference flag: "f32" = the reference's own precision (fp32 weights / activations; ddim inversion only)
+parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32"])
 
 
 def edit_latent(pipe, editor, x_T, source_prompt, target_prompt, edit_type, device, extra=None, num_inference_steps=50,
@@ -69,7 +71,7 @@ def main(argv=None):
     seed_everything(args.seed)
     out_path = "./exp"
     edit_type = "refine"  # ["refine", "replace"]
-    pipe = load_pipe(args.sd_version, device)
+    pipe = load_pipe(args.sd_version, device, precision=args.precision)
     xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of edit_real.py:97-115
     if args.inversion_type == "ddim":
         editor = (P2P_XL if xl else P2P)(model=pipe, num_inference_steps=50)

@@ -22,6 +22,9 @@ parser.add_argument("--device", type=int, default=0)
 parser.add_argument("--seed", type=int, default=8888)
 parser.add_argument("--source_prompt", type=str, default="a photo of a house on a mountain")
 parser.add_argument("--target_prompt", type=str, default="a photo of a house on a mountain at fall")
+# not a reference flag: "f32" = the reference's own precision (it loads the pipeline in fp32, edit_syn.py:38) on the fp32-MFMA
+# kernels; "f16" (default) = fp16 storage with fp32 accumulation
+parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32"])
 
 
 def main(argv=None):
@@ -34,7 +37,7 @@ def main(argv=None):
     cross_replace_steps, self_replace_steps = 0.8, 0.4
     edit_type = "refine"  # ["refine", "replace"]
 
-    pipe = load_pipe(args.sd_version, device)
+    pipe = load_pipe(args.sd_version, device, precision=args.precision)
     if pipe.__class__.__name__ == "StableDiffusionPipeline":            # dispatch of edit_syn.py:90-93
         editor = P2P(model=pipe, num_inference_steps=num_inference_steps)
     elif pipe.__class__.__name__ == "StableDiffusionXLPipeline":

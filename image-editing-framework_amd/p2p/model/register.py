@@ -84,14 +84,19 @@ def _edit_tables(c):
     raise TypeError(name)
 
 
-def lower_controller(controller, device) -> Optional[ControlPlan]:
-    """ControlPlan for a known controller class, else None (generic path)."""
+def lower_controller(controller, device, rows: str = "all") -> Optional[ControlPlan]:
+    """ControlPlan for a known controller class, else None (generic path).
+    rows: which rows of the CFG batch this UNet runs — "all" ([uncond..., cond...], the reference's batch), "cond" (only
+    the conditional rows: the half every controller acts on) or "uncond" (only the unconditional rows: nothing to edit,
+    the plan just keeps the controller's counters moving).  "cond" / "uncond" are the two ranks of a 2-GPU CFG split."""
+    if rows not in ("all", "cond", "uncond"):
+        raise ValueError('rows must be "all", "cond" or "uncond"')
     name = type(controller).__name__
     if name not in _LOWERABLE:
         return None
     if getattr(controller, "LOW_RESOURCE", False):
         return None  # two half-batch forwards per step: keep the Python protocol
-    if name in ("EmptyControl", "DummyController"):
+    if name in ("EmptyControl", "DummyController") or rows == "uncond":
         return ControlPlan(controller, "empty", device)
     if getattr(controller, "local_blend", None) is not None:
         return None  # LocalBlend needs stored maps
@@ -113,7 +118,7 @@ def lower_controller(controller, device) -> Optional[ControlPlan]:
     mt[:, :77, :77] = M.transpose(1, 2)
     lo, hi = controller.num_self_replace
     return ControlPlan(controller, "p2p", device, num_prompts=slots + 1, num_steps=steps1 - 1, mt=mt, coef_table=coef,
-                       self_window=(int(lo), int(hi)))
+                       self_window=(int(lo), int(hi)), cond_only=(rows == "cond"))
 
 
 # --------------------------------------------------------------------------------------- generic hook
@@ -134,14 +139,17 @@ def _generic_forward(attn, controller, place_in_unet):
     return forward
 
 
-def register_attention_control(model, controller, fused: Optional[bool] = None):
+def register_attention_control(model, controller, fused: Optional[bool] = None, rows: str = "all"):
+    """`rows` (not a reference argument): see `lower_controller`; anything but "all" needs a lowerable controller"""
     if controller is None:
         controller = DummyController()
     unet = model.unet
     mods = _attention_modules(unet)
     plan = None
     if fused is not False and all(getattr(m, "is_native", None) is not None for _, m in mods):
-        plan = lower_controller(controller, unet.device)
+        plan = lower_controller(controller, unet.device, rows)
+    if rows != "all" and plan is None:
+        raise ValueError(f"{type(controller).__name__} cannot be lowered: a CFG-split forward needs a device plan")
     if fused is True and plan is None:
         raise ValueError(f"{type(controller).__name__} cannot be lowered to the fused path")
     for place, m in mods:

@@ -84,7 +84,13 @@ class P2P:
                               guidance_scale: float = 7.5, generator: Optional[torch.Generator] = None,
                               latent: Optional[torch.FloatTensor] = None, low_resource: bool = False,
                               uncond_embeddings_list=None, height: Optional[int] = None, width: Optional[int] = None,
-                              return_latents: bool = False):
+                              return_latents: bool = False, cfg_split_group=None):
+        """cfg_split_group (not a reference argument): a torch.distributed group of TWO ranks that run this ONE edit
+        together — rank 0 the unconditional rows of the CFG batch, rank 1 the conditional rows, one eps exchange per
+        step (`denoise.CfgSplitDenoiser`); both ranks return the same latents / images."""
+        if cfg_split_group is not None:
+            return self._text2image_cfg_split(model, prompt, controller, num_inference_steps, guidance_scale, latent,
+                                              uncond_embeddings_list, height, width, return_latents, cfg_split_group)
         if controller is not None:
             register_attention_control(model, controller)
         if height is None:
@@ -111,6 +117,35 @@ class P2P:
             return latents, latent
         image = self.latent2image(model.vae, latents)
         return image, latent
+
+    @torch.no_grad()
+    def _text2image_cfg_split(self, model, prompt, controller, num_inference_steps, guidance_scale, latent,
+                              uncond_embeddings_list, height, width, return_latents, group):
+        import torch.distributed as dist
+        from ...denoise import CfgSplitDenoiser
+        half = dist.get_rank(group)
+        register_attention_control(model, controller, rows="cond" if half == 1 else "uncond")
+        if height is None:
+            height = width = model.unet.config.sample_size * model.vae_scale_factor
+        batch_size = len(prompt)
+        uncond_embeddings, text_embeddings, added = self._encode(model, prompt, height, width)
+        if added is not None:
+            raise NotImplementedError("CFG split is built for the SD1.x / SD2.x pipelines")
+        latent, latents = self.init_latent(latent, model, height, width, None, batch_size)
+        # both ranks must start from the SAME x_T: take the first rank's (seeded draws agree anyway; a passed-in latent might not)
+        x0 = latents.float().contiguous().cpu()
+        dist.broadcast(x0, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        latents = x0.to(model.device)
+        model.scheduler.set_timesteps(num_inference_steps)
+        loop = CfgSplitDenoiser(model, torch.cat([uncond_embeddings, text_embeddings]), batch_size,
+                                (height // 8, width // 8), guidance_scale, group=group, uncond_list=uncond_embeddings_list)
+        try:
+            latents = loop.run(latents)
+        finally:
+            loop.release()
+        if return_latents:
+            return latents, latent
+        return self.latent2image(model.vae, latents), latent
 
     def _encode(self, model, prompt, height, width):
         """-> (uncond [B,77,C], cond [B,77,C], added_cond_kwargs or None)"""

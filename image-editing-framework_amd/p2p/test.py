@@ -120,6 +120,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
     ap.add_argument("--no_save", action="store_true")
     ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop")
+    ap.add_argument("--precision", type=str, default="f16", choices=["f16", "f32"],
+                    help="f32: the reference's own precision on the fp32-MFMA kernels (ddim inversion only)")
     ap.add_argument("--in_flight", type=int, default=1,
                     help="independent images stepped concurrently on one GPU (null-text optimisations and edits)")
     args = ap.parse_args(argv)
@@ -132,7 +134,7 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
     seed_everything(42)
-    pipe = load_pipe(args.sd_version, device)
+    pipe = load_pipe(args.sd_version, device, precision=args.precision)
     xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of test.py:86-104
     if xl and (args.invert_batch > 1 or args.in_flight > 1):
         raise NotImplementedError("--invert_batch / --in_flight on the SDXL family: run the reference's per-image order")

@@ -184,6 +184,90 @@ def test_two_rank_sharding_and_broadcast_gloo():
     assert all(r[3] == n_items for r in res)
 
 
+# ------------------------------------------------------------------------------------------------ 2-GPU CFG split (host logic)
+def _cfg_split_worker(rank, world, port, q):
+    """one rank of a CFG-split pair on CPU tensors over gloo: a toy per-row 'UNet' stands in for the HIP forward; the row
+    split, the eps exchange, the plan tables and the controller counters are the product's"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ief_amd.denoise import cfg_split_rows, exchange_eps
+    from ief_amd.p2p.model.attention_control import AttentionRefine
+    from ief_amd.p2p.model.register import lower_controller
+    from ief_amd.scheduler import DDIMScheduler
+    from ief_amd.tokenizer import WordPieceTokenizer
+    g = torch.Generator().manual_seed(0)
+    Bp, steps = 2, 4
+    ctx = torch.randn(2 * Bp, 77, 16, generator=g)
+    x_T = torch.randn(1, 4, 8, 8, generator=g).expand(Bp, -1, -1, -1).clone()
+    wmix = torch.randn(16, 4, generator=g) * 0.1
+    sched = DDIMScheduler()
+    sched.set_timesteps(50)
+
+    def toy_unet(x, c, t):          # row-wise: no coupling between batch rows, as in the real UNet without a controller
+        return torch.tanh(x * 0.9 + (c.mean(1) @ wmix)[:, :, None, None] + 1e-3 * t)
+
+    def ddim(eu, ec, x, t):
+        a_t, a_p = sched.step_coeffs(int(t))
+        e = eu + 7.5 * (ec - eu)
+        x0 = (x - (1 - a_t) ** 0.5 * e) / a_t ** 0.5
+        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
+
+    ctrl = AttentionRefine(["a photo of a house on a mountain", "a photo of a house on a mountain at fall"],
+                           WordPieceTokenizer(), 50, 0.8, 0.4, device=torch.device("cpu"))
+    ctrl.num_att_layers = 32
+    plan = lower_controller(ctrl, torch.device("cpu"), rows="cond" if rank == 1 else "uncond")
+    mine_ctx = cfg_split_rows(ctx, Bp, rank)
+    lat = x_T.clone()
+    eps_all = torch.zeros(2 * Bp, 4, 8, 8)
+    for t in sched.timesteps[:steps].tolist():
+        mine = toy_unet(lat, mine_ctx, t)
+        exchange_eps(eps_all, mine)
+        lat = ddim(eps_all[:Bp], eps_all[Bp:], lat, t)
+        plan.replay_done()                           # what the captured loop calls once per step on BOTH ranks
+    # single-process reference: the full CFG batch
+    ref = x_T.clone()
+    for t in sched.timesteps[:steps].tolist():
+        e = toy_unet(torch.cat([ref] * 2), ctx, t)
+        ref = ddim(e[:Bp], e[Bp:], ref, t)
+    full = lower_controller(ctrl, torch.device("cpu"), rows="all")
+    tables = None
+    if rank == 1:
+        tables = (plan.kind, plan.batch, plan.cond_only, plan.edit_src.tolist(), plan.edit_slot.tolist(),
+                  plan.self_table.tolist(), full.edit_src.tolist(), full.self_table.tolist(),
+                  torch.equal(plan.coef_table, full.coef_table), torch.equal(plan.mt, full.mt))
+    else:
+        tables = (plan.kind, plan.batch)
+    q.put((rank, torch.equal(lat, ref), ctrl.cur_step, tables))
+    dist.destroy_process_group()
+
+
+def test_cfg_split_two_ranks_gloo():
+    """rank 0 = unconditional rows, rank 1 = conditional rows + the controller's plan, one eps exchange per
+    step; latents on BOTH ranks equal the single-process full-batch loop bit for bit, counters advance on both"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_cfg_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "split latents differ from the full-batch loop"
+    assert [r[2] for r in res] == [4, 4]
+    assert res[0][3][0] == "empty"                         # unconditional rank: nothing to edit
+    kind, batch, cond_only, es, sl, self_tab, es_full, self_full, same_coef, same_mt = res[1][3]
+    assert (kind, batch, cond_only) == ("p2p", 2, True) and same_coef and same_mt
+    # the conditional rank's tables are the conditional half of the full batch's, rows renumbered from 0
+    assert es == [-1, 0] and es_full == [-1, -1, -1, 2] and sl == [0, 0]
+    assert self_tab == [[c - 2 for c in row[2:]] for row in self_full]
+    with pytest.raises(ValueError):
+        from ief_amd.p2p.model.register import lower_controller
+        lower_controller(None, torch.device("cpu"), rows="half")
+
+
 # ------------------------------------------------------------------------------------------------ Plug-and-Play host logic
 class _FakeSched:
     def __init__(self, n):

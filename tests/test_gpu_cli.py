@@ -87,6 +87,19 @@ def test_bench_under_torchrun_one_rank(tmp_path):
     assert rec["roofline"]["bound"] in ("mfma", "hbm") and 0 < rec["roofline"]["roofline_frac"] <= 1.5
 
 
+def test_cfg_split_two_ranks_one_edit(tmp_path):
+    """ONE edit on two ranks (unconditional rows | conditional rows + controller plan), one eps exchange per
+    step.  Two processes share this box's GPU, so the exchange runs over gloo; the HIP path, the captured half-step graphs
+    and the cond-only plan are the ones two GPUs would run over RCCL.  The split latents must equal the full-batch edit
+    (different UNet batch => different tile plans, so to fp16 rounding, not bit for bit) and be identical on both ranks."""
+    out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29633", os.path.join(ROOT, "tests", "workers", "cfg_split_worker.py")], cwd=ROOT, timeout=600)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    print(rec)
+    assert rec["finite"] and rec["ranks_identical"] and rec["cur_step"] == 6
+    assert rec["rel_split_vs_full"] < 5e-3
+
+
 def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
     """--invert_batch K inverts K images in one batched DDIM loop and --in_flight E steps E edits concurrently; images
     are independent, so the PNGs must match the per-image run."""

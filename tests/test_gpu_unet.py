@@ -251,6 +251,53 @@ def test_masactrl_forward_and_loop_vs_oracle(tiny):
     assert e < LOOP_TOL
 
 
+def test_masactrl_user_editor_takes_the_generic_path(tiny):
+    """any `AttentionBase` subclass that is not one of the two lowered classes gets the reference's dataflow
+    (`/root/reference/masactrl/model/register.py:10-48`): q, k, v as [(B*heads), N, d], `sim` and `attn` materialised by
+    our kernels, the editor's own Python on them — here an editor that sharpens the self-attention maps"""
+    from ief_amd.masactrl.model.attention_base import AttentionBase
+    from ief_amd.masactrl.model.register import regiter_attention_editor_diffusers, unregister_attention_control as unreg
+
+    seen = []
+
+    class Sharpen(AttentionBase):
+        def forward(self, q, k, v, sim, attn, is_cross, place_in_unet, num_heads, **kw):
+            seen.append((tuple(q.shape), tuple(sim.shape), is_cross, place_in_unet,
+                         (sim.float().softmax(-1) - attn.float()).abs().max().item(), kw.get("scale")))
+            if not is_cross:
+                attn = attn.float() ** 2
+                attn = (attn / attn.sum(-1, keepdim=True)).to(v.dtype)
+            return super().forward(q, k, v, sim, attn, is_cross, place_in_unet, num_heads, **kw)
+
+    pipe = tiny
+    cfg = pipe.cfg
+    x, ctx = _inputs(cfg, 2, seed=4)
+    ctx = ctx * 10.0
+    ed = Sharpen()
+    regiter_attention_editor_diffusers(pipe, ed)
+    assert pipe.unet._plan is None and ed.num_att_layers == unet_ref.count_attention_layers(cfg)
+    got = pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
+    assert ed.cur_step == 1 and ed.cur_att_layer == 0 and len(seen) == ed.num_att_layers
+    unreg(pipe, ed)
+    assert all(m.is_native() for m in pipe.unet.attention_modules())
+    q_shape, sim_shape, is_cross, place, sm_err, scale = seen[0]
+    heads0 = cfg.num_heads[0]
+    assert q_shape == (2 * heads0, cfg.sample_size ** 2, cfg.block_out_channels[0] // heads0) and place == "down" and not is_cross
+    assert sim_shape == (2 * heads0, cfg.sample_size ** 2, cfg.sample_size ** 2) and abs(scale - q_shape[2] ** -0.5) < 1e-9
+    assert max(s[4] for s in seen) < 2e-3                      # softmax(sim) is the `attn` that was handed over
+
+    def hook(p, is_cross, place):
+        if not is_cross:
+            p = p ** 2
+            p = p / p.sum(-1, keepdim=True)
+        return p
+    ref = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx, hook=hook)
+    plain = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx)
+    e, effect = rel_err(got, ref), rel_err(plain, ref)
+    print(f"masactrl user editor (generic path): {e:.3e} vs oracle, the editor moves eps by {effect:.3e}")
+    assert e < FWD_TOL and effect > 4 * e
+
+
 def test_full_edit_images_vs_oracle(tiny):
     """`P2P.text2image_ldm_stable` end to end (text encode -> 10-step controlled edit -> AutoencoderKL decode -> uint8)
     against the oracle's loop + VAE: the 'edited images' comparison of north_star, on the TINY shape family."""
