@@ -21,8 +21,9 @@
 //   - v_mfma_f32_16x16x32_f16, (BM/WAVES_M/16) x (BN/WAVES_N/16) accumulator tiles per wave;
 //   - epilogue through LDS in 64-row passes: + bias[n] + rowvec[batch(m)][n] (time embedding)
 //     + residual[m][n], * scale, one 16-B fp16 store per 8 outputs;
-//   - split-K (grid.y) with fp32 partial slabs + a reducer kernel for layers whose M x N gives too
-//     few tiles for 256 CUs (the 16x16 / 8x8 UNet levels);
+//   - split-K (grid.y) with fp32 partial slabs for layers whose M x N gives too few tiles for 256 CUs (the 16x16 /
+//     8x8 UNet levels), combined INSIDE the launch by the last-arriving workgroup of each tile (agent-scope release /
+//     ticket / acquire; IefGemmParams.cnt) or, without counters, by a reducer kernel;
 //   - XCD-aware block remap: consecutive logical tiles (same A panel) share an XCD's L2.
 // BN = 160 tiles exist because SD's channel widths are multiples of 320: N = 320 is 2 x 160 exactly,
 // while 128-wide tiles pad it to 384 and leave 1.5 blocks per CU.
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     static_assert(NS >= 2 && NS <= 4, "LDS ring depth");
     constexpr int STAGE_HALFS = NS * (ROWS_A + ROWS_B) * BK;
     constexpr int G = NA + NB;                      // LDS-DMA instructions a wave issues per K tile
-    constexpr int EPI_HALFS = (64 * (BN + 4) + 64 * (BN / 8) * 2 + 128) * 2;   // fp32 [64][BN+4] + row-moment partials [64][BN/8][2] + row mean / rstd [2][64]
+    constexpr int EPI_HALFS = (64 * (BN + 4) + 64 * (BN / 8) * 2 + 128 + 4) * 2;   // fp32 [64][BN+4] + row-moment partials [64][BN/8][2] + row mean / rstd [2][64] + the split-K "last arriver" word
     __shared__ __attribute__((aligned(16))) half_t smem[STAGE_HALFS > EPI_HALFS ? STAGE_HALFS : EPI_HALFS];
     half_t* As = smem;
     half_t* Bs = smem + NS * ROWS_A * BK;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
             }
         }
         __syncthreads();
-        if (p.cstat_out) {           // column sums over this pass's rows, fixed order: deterministic
+        if (p.cstat_out && p.splits <= 1) {   // column sums over this pass's rows, fixed order: deterministic
             if (tid < BN) {
                 for (int r = 0; r < PROWS; ++r) {
                     const float v = stage[r * LDS_N + tid];
@@ -435,6 +436,90 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                 for (int c = 0; c < CH; ++c) { a1 += rpart[(tid * CH + c) * 2]; a2 += rpart[(tid * CH + c) * 2 + 1]; }
                 float* ro = p.rstat_out + ((long long)m * tiles_n + (n0 / BN)) * 2;
                 ro[0] = a1; ro[1] = a2;
+            }
+        }
+    }
+    if (p.splits > 1 && p.cnt) {
+        // ---- split-K combined inside the launch (guide: "In-launch split-K reduction"): this workgroup's slab tile was
+        // written with plain 16-B stores above.  Every wave drains its stores, the workgroup meets, ONE lane releases at
+        // agent scope (write-back of this XCD's L2) and draws a ticket; whoever draws the last one acquires (drops this
+        // CU's stale lines) and combines.  Correct for any placement of a tile's slices over XCDs / CUs.
+        int* last_word = (int*)(row_rs + 64);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the fence's own wait can be dropped by the compiler
+            const int ticket = __hip_atomic_fetch_add(p.cnt + lid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.splits - 1;
+            if (last) {
+                __hip_atomic_store(p.cnt + lid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *last_word = last;
+        }
+        __syncthreads();
+        if (!*last_word) return;
+        const long long slab = (long long)p.M * p.N;
+        constexpr int PROWS = BM < 64 ? BM : 64;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            for (int c = tid; c < PROWS * CH; c += NT) {
+                const int row = c / CH, nc = c - row * CH;
+                const int m = m0 + pass * 64 + row, n = n0 + nc * 8;
+                float* sp = stage + row * LDS_N + nc * 8;
+                if (m < p.M && n < p.N) {
+                    const float* w = p.ws + (long long)m * p.N + n;
+                    f32x4 a0 = *(const f32x4*)w, a1 = *(const f32x4*)(w + 4);
+                    int sl = 1;
+                    for (; sl + 3 < p.splits; sl += 4) {          // four slabs' loads in flight, added in slab order
+                        f32x4 t0[4], t1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { t0[u] = *(const f32x4*)(w + (sl + u) * slab); t1[u] = *(const f32x4*)(w + (sl + u) * slab + 4); }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { a0 += t0[u]; a1 += t1[u]; }
+                    }
+                    for (; sl < p.splits; ++sl) { a0 += *(const f32x4*)(w + sl * slab); a1 += *(const f32x4*)(w + sl * slab + 4); }
+                    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    if (p.bias) {
+                        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    }
+                    if (p.rowvec) {
+                        const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n;
+                        const f32x4 b0 = *(const f32x4*)rv, b1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    }
+                    if (p.residual) {
+                        const half8 rs = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                    }
+                    half8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
+                    *(half8*)(Out + (long long)m * p.ldo + n) = o;
+                    if (p.cstat_out) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sp[e] = (float)o[e];
+                    }
+                } else if (p.cstat_out) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sp[e] = 0.f;
+                }
+            }
+            if (p.cstat_out) {
+                __syncthreads();
+                if (tid < BN) {
+                    for (int r = 0; r < PROWS; ++r) {
+                        const float v = stage[r * LDS_N + tid];
+                        ccs += v;
+                        ccq += v * v;
+                    }
+                }
+                __syncthreads();
             }
         }
     }
@@ -514,7 +599,7 @@ static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     }
     if (rc) return rc;
     IEF_LAUNCH_CHECK();
-    if (splits > 1) {
+    if (splits > 1 && !p.cnt) {
         const long long total = (long long)p.M * (p.N / 8);
         int grid = (int)((total + 255) / 256);
         if (grid > 4096) grid = 4096;
@@ -579,7 +664,7 @@ static int check_common(const IefGemmParams& p) {
     }
     if (p.rstat_in && (!p.colsum || p.rstat_slots <= 0 || p.splits > 1 || !(p.ln_eps > 0.f))) return IEF_EINVAL;
     if (p.rstat_out && p.splits > 1) return IEF_EINVAL;
-    if (p.cstat_out && (p.splits > 1 || (p.flags & 2) || ief_gemm_tile_bm(p.tile_hint) == 0)) return IEF_EINVAL;
+    if (p.cstat_out && ((p.splits > 1 && !p.cnt) || (p.flags & 2) || ief_gemm_tile_bm(p.tile_hint) == 0)) return IEF_EINVAL;
     // 32-bit byte offsets inside each operand
     if ((long long)p.N * p.ldw * 2 >= (1ll << 32)) return IEF_ESHAPE;
     return IEF_OK;

@@ -288,6 +288,83 @@ __global__ __launch_bounds__(64) void gn_finalize_cstat_kernel(const float* __re
     }
 }
 
+// ONE launch on the producer's statistics: a workgroup owns a channel slice [c_lo, c_hi) (whole groups, whole 8-channel
+// chunks) of a run of pixels of one image.  It first folds the statistics of ITS channels only — a thread per channel sums
+// that channel's per-tile pairs in tile order, then a thread per group sums the group's channels in channel order (fixed
+// orders: bit reproducible) — and then normalises its pixels.  The fold reads nt * slice * 8 bytes, so this form is used
+// while that stays small (the 32x32 / 16x16 levels: 2-8 tiles per image); above, the two-launch form below.
+#define GNS_MAXC 512
+__global__ __launch_bounds__(256) void gn_cstat_fused_kernel(const half_t* __restrict__ x, const half_t* __restrict__ x2, int C1, int C2,
+                                                             half_t* __restrict__ out, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ cs1, int bm1,
+                                                             const float* __restrict__ cs2, int bm2, int HW, int groups, float eps,
+                                                             int apply_silu, int CW, int ppb) {
+    __shared__ float ch_s[GNS_MAXC], ch_q[GNS_MAXC], g_mu[GNS_MAXC / 2], g_rs[GNS_MAXC / 2];
+    const int C = C1 + C2, cpg = C / groups;
+    const int b = blockIdx.z;
+    const int c_lo = blockIdx.y * CW, c_hi = min(C, c_lo + CW), cw = c_hi - c_lo;
+    const int t1 = HW / bm1, t2 = C2 > 0 ? HW / bm2 : 0;
+    for (int i = threadIdx.x; i < cw; i += 256) {
+        const int c = c_lo + i;
+        const bool first = c < C1;
+        const float* cs = first ? cs1 : cs2;
+        const int Cs = first ? C1 : C2, cc = first ? c : c - C1, nt = first ? t1 : t2;
+        float s = 0.f, q = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            const float* o = cs + ((long long)(b * nt + t) * Cs + cc) * 2;
+            s += o[0]; q += o[1];
+        }
+        ch_s[i] = s; ch_q[i] = q;
+    }
+    __syncthreads();
+    const int ng = cw / cpg;
+    for (int g = threadIdx.x; g < ng; g += 256) {
+        float s = 0.f, q = 0.f;
+        for (int j = 0; j < cpg; ++j) { s += ch_s[g * cpg + j]; q += ch_q[g * cpg + j]; }
+        const float inv = 1.0f / ((float)cpg * (float)HW);
+        const float m = s * inv;
+        g_mu[g] = m;
+        g_rs[g] = rsqrtf(fmaxf(q * inv - m * m, 0.f) + eps);
+    }
+    __syncthreads();
+    const int C8s = cw >> 3;                       // 8-channel chunks of the slice
+    const int PY = 256 / C8s;                      // pixel lanes
+    const int cx = threadIdx.x % C8s, py = threadIdx.x / C8s;
+    if (py >= PY) return;
+    const int c = c_lo + cx * 8;
+    float sc[8], sh[8];
+    {
+        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (cx * 8 + e) / cpg;
+            const float ga = e < 4 ? g0[e] : g1[e - 4], be = e < 4 ? b0[e] : b1[e - 4];
+            sc[e] = g_rs[g] * ga;
+            sh[e] = be - g_mu[g] * sc[e];
+        }
+    }
+    const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+    for (int p = p0 + py; p < p1; p += PY) {
+        const long long pix = (long long)b * HW + p;
+        const half8 v = load_cat8(x, x2, C1, C2, pix, c);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (float)v[e] * sc[e] + sh[e];
+            if (apply_silu) y = silu_f(y);
+            o[e] = (half_t)y;
+        }
+        *(half8*)(out + pix * C + c) = o;
+    }
+}
+
+static int lcm_i(int a, int b) {
+    int x = a, y = b;
+    while (y) { const int t = x % y; x = y; y = t; }
+    return a / x * b;
+}
+
 extern "C" int ief_groupnorm_cstat_f16(const ief_half* x, const ief_half* x2, int C1, int C2, ief_half* out,
                                        const float* gamma, const float* beta, const float* cstat1, int bm1,
                                        const float* cstat2, int bm2, float* stats, int B, int HW, int groups, float eps,
@@ -299,6 +376,24 @@ extern "C" int ief_groupnorm_cstat_f16(const ief_half* x, const ief_half* x2, in
     if ((C1 & 7) || (C2 & 7) || (C % groups) || C > 8 * 1024) return IEF_ESHAPE;
     if (bm1 <= 0 || (HW % bm1) || (C2 > 0 && (bm2 <= 0 || (HW % bm2)))) return IEF_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    // one launch when a workgroup's share of the fold is small: slices of whole groups and whole 8-channel chunks
+    {
+        const int cpg = C / groups, unit = lcm_i(cpg, 8);
+        const int nt1 = HW / bm1, nt2 = C2 > 0 ? HW / bm2 : 0;
+        const int nt = nt1 > nt2 ? nt1 : nt2;
+        int CW = unit * ((192 + unit - 1) / unit);            // ~192 channels per slice
+        if (CW > C) CW = C;
+        if (unit <= 256 && CW <= GNS_MAXC && CW / 8 <= 256 && (long long)nt * CW * 8 <= 16 * 1024 && B <= 65535) {
+            const int PY = 256 / (CW / 8);
+            int ppb = PY * 4;                                  // ~4 pixels per thread
+            if (ppb > HW) ppb = HW;
+            dim3 grid((HW + ppb - 1) / ppb, (C + CW - 1) / CW, B);
+            hipLaunchKernelGGL(gn_cstat_fused_kernel, grid, dim3(256), 0, st, x, x2, C1, C2, out, gamma, beta, cstat1, bm1,
+                               cstat2, bm2, HW, groups, eps, apply_silu, CW, ppb);
+            IEF_LAUNCH_CHECK();
+            return IEF_OK;
+        }
+    }
     hipLaunchKernelGGL(gn_finalize_cstat_kernel, dim3(B * groups), dim3(64), 0, st, cstat1, bm1, C1, cstat2, bm2, C2, stats,
                        HW, groups, eps);
     IEF_LAUNCH_CHECK();

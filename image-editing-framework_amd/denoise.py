@@ -148,6 +148,7 @@ class FusedDenoiser:
         if plan is not None:
             plan.prepare(self.B)
             plan.muted = True
+        used0 = hip.counters_used()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -161,8 +162,11 @@ class FusedDenoiser:
         if plan is not None:
             plan.sync_step()
             plan.captured = True
+        # the split-K launches of this graph combine their slabs inside the launch and need arrival counters nobody else
+        # touches while the graph may run: an arena of the size the warm-up pass used, owned by this loop
+        self._arena = hip.counter_arena(hip.counters_used() - used0, self.lat.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with self._arena, torch.cuda.graph(self.graph):
             self._step_body()
         self.lat.copy_(saved)
         self.step.zero_()
@@ -320,6 +324,7 @@ class CfgSplitDenoiser(FusedDenoiser):
         if plan is not None:
             plan.prepare(self.B)
             plan.muted = True
+        used0 = hip.counters_used()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -332,8 +337,9 @@ class CfgSplitDenoiser(FusedDenoiser):
         if plan is not None:
             plan.sync_step()
             plan.captured = True
+        self._arena = hip.counter_arena(hip.counters_used() - used0, self.lat.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with self._arena, torch.cuda.graph(self.graph):
             self._forward_part()
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b):

@@ -35,7 +35,7 @@ class IefGemmParams(Structure):
         ("splits", c_int), ("ws", c_void_p), ("flags", c_int), ("zeros", c_void_p), ("stages", c_int),
         ("pad_hi_only", c_int),
         ("rstat_out", c_void_p), ("rstat_in", c_void_p), ("rstat_slots", c_int), ("colsum", c_void_p), ("ln_eps", c_float),
-        ("cstat_out", c_void_p),
+        ("cstat_out", c_void_p), ("cnt", c_void_p),
     ]
 
 
@@ -276,7 +276,7 @@ class _Timed:
 # describes: nothing is attached to tensor objects, so a buffer re-written by any other launch cannot be paired with
 # statistics of its earlier contents unless the caller itself keeps passing the old object.
 GN_CSTAT = os.environ.get("IEF_GN_CSTAT", "1") == "1"
-_CSTAT_MIN_HW = 1024
+_CSTAT_MIN_HW = 256
 
 
 class ColStats:
@@ -293,7 +293,7 @@ class ColStats:
 
 def _attach_cstat(lib, p, out, M, N, hw):
     """decide whether this launch emits column statistics; returns the ColStats (owning the scratch tensor) or None"""
-    if not GN_CSTAT or hw is None or hw < _CSTAT_MIN_HW or p.splits > 1 or (p.flags & 2) or AUTOTUNE:
+    if not GN_CSTAT or hw is None or hw < _CSTAT_MIN_HW or (p.splits > 1 and not p.cnt) or (p.flags & 2) or AUTOTUNE:
         return None
     bm = lib.ief_gemm_tile_bm(p.tile_hint)
     if bm <= 0 or hw % bm or M % hw:
@@ -321,6 +321,81 @@ def _zeros(device):
     if z is None:
         z = _zero_pages[device] = torch.zeros(128, dtype=torch.float16, device=device)
     return z.data_ptr()
+
+
+# ---- split-K arrival counters (IefGemmParams.cnt): one zeroed int per output tile, zero again when the launch ends.
+# Launches that can overlap must not share counters, so:
+#   eager launches   take the next slots of a ring of 2^20 ints per device (thousands of launches deep: a launch has ended
+#                    long before its slots come round again);
+#   captured launches take slots of an ARENA its owner allocated for that graph (`counter_arena`): a captured step graph
+#                    keeps its own counters for as long as it lives, whatever other graphs or eager launches do; without an
+#                    arena a captured launch falls back to the separate reducer launch.
+SPLITK_INLAUNCH = os.environ.get("IEF_SPLITK_INLAUNCH", "1") == "1"
+# ... and only where the last arriver's serial read stays short: splits x tile bytes (fp32) at most this many KiB.  Measured
+# (same box, SD1.5 batch-4 step): combining EVERY split-K launch in the launch took the step from 7.45 to 7.97 ms — the
+# tuned plans cut K 2-16 ways over 64..256-row tiles, 128 KiB - 1.3 MiB per output tile, which one workgroup reads at
+# ~100 GB/s while the reducer launch reads with the whole chip (the guide's splitk-seam verdict).
+SPLITK_INLAUNCH_MAX_KB = int(os.environ.get("IEF_SPLITK_INLAUNCH_MAX_KB", "64"))
+_CNT_RING = 1 << 20
+_cnt_ring = {}          # device -> [tensor, position]
+_cnt_arena = None       # [tensor, position] while a capture that owns one is running
+_cnt_used = 0           # ints handed out so far (owners size their arena by the delta over a warm-up pass)
+
+
+def counters_used() -> int:
+    return _cnt_used
+
+
+class counter_arena:
+    """`with counter_arena(n, device) as arena:` — split-K launches captured inside take their arrival counters from
+    `arena` (a zeroed int32 tensor the caller keeps alive with the graph)"""
+
+    def __init__(self, n, device):
+        if isinstance(device, int):
+            device = torch.device("cuda", device)
+        self.t = torch.zeros(max(int(n), 1), dtype=torch.int32, device=device)
+
+    def __enter__(self):
+        global _cnt_arena
+        self.prev, _cnt_arena = _cnt_arena, [self.t, 0]
+        return self.t
+
+    def __exit__(self, *a):
+        global _cnt_arena
+        _cnt_arena = self.prev
+
+
+def _splitk_counters(device, n, combine_kb=0):
+    """device pointer of n zeroed ints for one split-K launch, or None (-> separate reducer launch)"""
+    global _cnt_used
+    if not SPLITK_INLAUNCH or combine_kb > SPLITK_INLAUNCH_MAX_KB:
+        return None
+    if _capturing():
+        if _cnt_arena is None or _cnt_arena[1] + n > _cnt_arena[0].numel():
+            return None
+        t, pos = _cnt_arena
+        _cnt_arena[1] = pos + n
+        _cnt_used += n
+        return t.data_ptr() + 4 * pos
+    ring = _cnt_ring.get(device)
+    if ring is None:
+        ring = _cnt_ring[device] = [torch.zeros(_CNT_RING, dtype=torch.int32, device=device), 0]
+    if n > _CNT_RING:
+        return None
+    if ring[1] + n > _CNT_RING:
+        ring[1] = 0
+    ptr = ring[0].data_ptr() + 4 * ring[1]
+    ring[1] += n
+    _cnt_used += n
+    return ptr
+
+
+def _tile_count(lib, tile_hint, M, N, splits=1):
+    """(output tiles, KiB the last arriver of a tile would read: splits x BM x BN fp32)"""
+    bm, bn = lib.ief_gemm_tile_bm(tile_hint), lib.ief_gemm_tile_bn(tile_hint)
+    if bm <= 0 or bn <= 0:
+        return 0, 0
+    return -(-M // bm) * -(-N // bn), splits * bm * bn * 4 // 1024
 
 
 SPLITK = os.environ.get("IEF_SPLITK", "1") != "0"
@@ -406,12 +481,14 @@ def _time_graph(fn, iters=20):
     """us per call of fn(i), i = 0..iters-1, replayed from one hipGraph"""
     st = torch.cuda.Stream()
     st.wait_stream(torch.cuda.current_stream())
+    used0 = counters_used()
     with torch.cuda.stream(st):
         fn(0)
     torch.cuda.current_stream().wait_stream(st)
     torch.cuda.synchronize()
+    arena = counter_arena((counters_used() - used0) * iters, torch.cuda.current_device())   # split-K combines in the launch
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with arena, torch.cuda.graph(g):
         for i in range(iters):
             fn(i)
     g.replay()
@@ -578,6 +655,8 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     if p.splits > 1:
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)
         p.ws = ws.data_ptr()
+        nt, kb = _tile_count(lib, p.tile_hint, M, N, p.splits)
+        p.cnt = _splitk_counters(a.device, nt, kb) if nt else None
     stats = None
     if row_stats:
         bn = lib.ief_gemm_tile_bn(p.tile_hint)
@@ -674,6 +753,8 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     if p.splits > 1:
         ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)
         p.ws = ws.data_ptr()
+        nt, kb = _tile_count(lib, p.tile_hint, M, Cout, p.splits)
+        p.cnt = _splitk_counters(x.device, nt, kb) if nt else None
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
     cst = _attach_cstat(lib, p, out, M, Cout, Ho * Wo) if col_stats and out.is_contiguous() else None
@@ -942,11 +1023,10 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
     for t, c, nm in ((x, cs1, "cstat"), (x2, cs2, "cstat2")):
         if c is not None and not c.describes(t):
             raise ValueError(f"groupnorm: {nm} was produced for another tensor (address / size mismatch)")
-    cpg = (C1 + C2) // groups
-    single_launch = not (cpg & 1) and HW * cpg * 2 <= 48 * 1024           # the C side's one-workgroup-per-group condition
-    if (GN_CSTAT and not return_stats and not single_launch and cs1 is not None and cs1.hw == HW
+    if (GN_CSTAT and not return_stats and cs1 is not None and cs1.hw == HW
             and (x2 is None or (cs2 is not None and cs2.hw == HW))):
-        # statistics were left by the producers' epilogues: fold them (one small launch) and apply
+        # statistics were left by the producers' epilogues: fold them and apply — ONE launch while the fold is small
+        # (2-8 tiles per image: the 32x32 / 16x16 levels), a fold launch + an apply launch above
         stats = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
         with _Timed("groupnorm(stats+apply)", 0.0, 4.0 * x.numel() + (0 if x2 is None else 4.0 * x2.numel())):
             _check(lib.ief_groupnorm_cstat_f16(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
@@ -1056,12 +1136,16 @@ def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None, softm
 
 
 def attn_scores(q, k, heads, scale):
-    """PRE-softmax scores scale * q k^T as contiguous [B*heads, N, L] in q's dtype — the `sim` tensor MasaCtrl's editor
-    protocol hands to user editors (`/root/reference/masactrl/model/register.py:35`).  Generic-path only (fp32 MFMA)."""
-    if _is32(q):
-        return _attn_scores_f32(q, k, heads, scale, softmax=False)
-    s32 = _attn_scores_f32(to_f32(_dev16(q, "q")), to_f32(_dev16(k, "k")), heads, scale, softmax=False)
-    return to_f16(s32)
+    """-> (sim, attn): the PRE-softmax scores scale * q k^T and their row softmax, both contiguous [B*heads, N, L] in q's
+    dtype — the two tensors MasaCtrl's editor protocol hands to user editors
+    (`/root/reference/masactrl/model/register.py:35,44`).  Generic-path only: computed on the fp32 MFMA / fp32 softmax
+    whatever the model's storage dtype (any key count, e.g. 77)."""
+    half = not _is32(q)
+    if half:
+        q, k = to_f32(_dev16(q, "q")), to_f32(_dev16(k, "k"))
+    sim = _attn_scores_f32(q, k, heads, scale, softmax=False)
+    probs = softmax_rows_(sim.clone())
+    return (to_f16(sim), to_f16(probs)) if half else (sim, probs)
 
 
 def _attn_apply_f32(probs, v, heads, v_src=None, out=None):

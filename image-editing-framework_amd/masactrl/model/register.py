@@ -45,8 +45,7 @@ def _generic_forward(attn, editor, place_in_unet):
         is_cross = context is not None
         context = context if is_cross else x
         q, k, v = attn.to_q(x), attn.to_k(context), attn.to_v(context)
-        sim = hip.attn_scores(q.contiguous(), k.contiguous(), attn.heads, attn.scale)
-        probs = hip.softmax_rows_(sim.clone())
+        sim, probs = hip.attn_scores(q.contiguous(), k.contiguous(), attn.heads, attn.scale)
         out = editor(attn.head_to_batch_dim(q), attn.head_to_batch_dim(k), attn.head_to_batch_dim(v), sim, probs, is_cross,
                      place_in_unet, attn.heads, scale=attn.scale)
         return to_out(out.to(x.dtype).contiguous())

@@ -88,16 +88,22 @@ class NullTextOptimizer:
         saved = [t.clone() for t in (self.lat, self.param, self.m, self.v, self.p16, self.adam_step, self.eps_c)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        need = []
         with torch.cuda.stream(s):          # warm-up: allocator pools, packed adjoint weights
-            self._body_cond(), self._body_inner(), self._body_tail()
+            for body in (self._body_cond, self._body_inner, self._body_tail):
+                used0 = hip.counters_used()
+                body()
+                need.append(hip.counters_used() - used0)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        graphs = []
-        for body in (self._body_cond, self._body_inner, self._body_tail):
+        graphs, self._arenas = [], []
+        for body, n in zip((self._body_cond, self._body_inner, self._body_tail), need):
+            arena = hip.counter_arena(n, self.dev)      # this graph's own split-K arrival counters
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with arena, torch.cuda.graph(g):
                 body()
             graphs.append(g)
+            self._arenas.append(arena)
         for t, sv in zip((self.lat, self.param, self.m, self.v, self.p16, self.adam_step, self.eps_c), saved):
             t.copy_(sv)
         self._graphs = graphs

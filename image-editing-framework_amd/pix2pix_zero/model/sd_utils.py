@@ -75,14 +75,18 @@ class _Engine:
     def _capture(self, body):
         if not self.use_graph:
             return body
+        used0 = hip.counters_used()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             body()                                  # warm-up: allocator pools, packed adjoint weights
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # split-K launches combine inside the launch: the graph owns its arrival counters (kept alive with the loop)
+        arena = hip.counter_arena(hip.counters_used() - used0, self.lat.device)
+        self._arenas = getattr(self, "_arenas", []) + [arena]
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with arena, torch.cuda.graph(g):
             body()
         return g.replay
 

@@ -95,6 +95,13 @@ typedef struct IefGemmParams {
      * (ief_gemm_tile_bm(tile_hint) gives BM; the consumer is ief_groupnorm_cstat_f16).  No split-K, no GEGLU epilogue,
      * dense batch 1. */
     float* cstat_out;
+    /* split-K combined INSIDE the launch: cnt points at one zeroed int per output tile (ceil(M/BM) * ceil(N/BN)).  Each
+     * K-slice workgroup stores its fp32 slab tile, releases it at agent scope and draws a ticket from cnt[tile]; the
+     * workgroup that draws the last ticket acquires, sums the slabs IN SLAB ORDER (so the sum does not depend on who came
+     * last), applies the epilogue (and cstat_out, now allowed with splits > 1) and stores 0 back into cnt[tile]: the
+     * counters are zero again when the launch ends.  NULL: the slabs are summed by a second launch, as before.  Launches
+     * that may run concurrently must not share counters. */
+    int* cnt;
 } IefGemmParams;
 
 int ief_gemm_f16(const IefGemmParams* p, int batch, void* stream);

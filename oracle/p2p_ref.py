@@ -171,7 +171,7 @@ def ddim_inversion_loop(sd, cfg, cond_emb, latent, sched: DDIMRef, num_steps: Op
 def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps: int = 10,
                       epsilon: float = 1e-5, guidance_scale: float = 7.5,
                       num_outer: Optional[int] = None, added_cond=None, added_uncond=None, lr: float = 1e-2,
-                      restart: bool = False, lr_decay: float = 100.0):
+                      restart: bool = False, lr_decay: float = 100.0, grad_trace: Optional[list] = None):
     """`/root/reference/p2p/inversion/nti.py:9-45` with the oracle UNet as `model.unet`.
     `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`; the masactrl and pnp folders hold the same file, the
     p2p folder's copy uses lr = 0.5 (1 - i / 500), `p2p/inversion/nti.py:50,69`) is the same loop with lr = 5e-2 (:69), the embedding
@@ -203,6 +203,8 @@ def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps
             loss = F.mse_loss(rec, prev)
             opt.zero_grad()
             loss.backward()
+            if grad_trace is not None:      # (timestep index, inner step, d loss / d embedding) for tests that weigh elements
+                grad_trace.append((i, j, uncond.grad.detach().clone()))
             opt.step()
             if loss.item() < epsilon + i * 2e-5:
                 break

@@ -486,7 +486,8 @@ def test_sdxl_pipeline_host_surface():
 
 def test_producer_statistics_are_only_requested_where_they_are_valid():
     """host rule for `IefGemmParams.cstat_out` (GroupNorm statistics from the producer): only NHWC outputs of a level with
-    >= 1024 pixels per image, never with split-K or the GEGLU epilogue, and only when no M tile straddles two images"""
+    >= 256 pixels per image, never with the GEGLU epilogue, with split-K only when the slabs are combined inside the launch
+    (arrival counters present), and only when no M tile straddles two images"""
     lib = hip.load()
     assert [lib.ief_gemm_tile_bm(t) for t in range(1, 10)] == [128, 64, 64, 128, 64, 128, 128, 256, 128]
     assert lib.ief_gemm_tile_bm(0) == 0 and lib.ief_map_loss_blocks(4096, 40) == 16 and lib.ief_map_loss_blocks(256, 160) == 4
@@ -502,13 +503,18 @@ def test_producer_statistics_are_only_requested_where_they_are_valid():
     cs, out, ptr = ask(7, 1, 1, 4 * 4096, 320, 4096)
     assert cs.buf.shape == (4 * 4096 // 128, 320, 2) and (cs.bm, cs.hw) == (128, 4096) and ptr == cs.buf.data_ptr()
     assert cs.describes(out) and not cs.describes(torch.empty(4 * 4096, 320, dtype=torch.float16))
-    for bad in ((7, 2, 1, 16384, 320, 4096),        # split-K: the reducer writes the output
+    for bad in ((7, 2, 1, 16384, 320, 4096),        # split-K without counters: the reducer launch writes the output
                 (7, 1, 3, 16384, 320, 4096),        # GEGLU epilogue
-                (7, 1, 1, 4 * 256, 1280, 256),      # a small level: the single-launch GroupNorm is already one launch
+                (7, 1, 1, 4 * 64, 1280, 64),        # the 8x8 level: a 128-row tile covers two images
                 (8, 1, 1, 4 * 1600, 320, 1600),     # 40x40 latents: a 256-row tile would straddle two images
                 (7, 1, 1, 1000, 320, None)):        # not an NHWC activation
         cs, _, ptr = ask(*bad)
         assert cs is None and not ptr, bad
+    cs, _, _ = ask(7, 1, 1, 4 * 256, 1280, 256)       # the 16x16 level: two 128-row tiles per image
+    assert cs is not None and (cs.bm, cs.hw) == (128, 256)
+    p = hip.IefGemmParams()                         # split-K combined in the launch: the last arriver owns the tile
+    p.tile_hint, p.splits, p.flags, p.cnt = 7, 2, 1, 4096
+    assert hip._attach_cstat(lib, p, torch.empty(16384, 320, dtype=torch.float16), 16384, 320, 4096) is not None
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/masactrl"), reason="reference checkout not present")

