@@ -166,13 +166,24 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IefGemmF32Params p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = (K + XBK - 1) / XBK;
-    load_tile(0);
-    store_tile(0);
+    // split-K (grid.y): this workgroup's K tiles [kt0, kt0 + nk); the partial tile goes to an fp32 slab, a second launch sums
+    // the slabs in slab order and applies the epilogue (small-M levels would otherwise leave most of the chip idle)
+    const int nk_all = (K + XBK - 1) / XBK;
+    int kt0 = 0, nk = nk_all;
+    if (p.splits > 1) {
+        const int per = (nk_all + p.splits - 1) / p.splits;
+        kt0 = blockIdx.y * per;
+        nk = min(per, nk_all - kt0);
+        if (nk < 0) nk = 0;
+    }
+    if (nk > 0) {
+        load_tile(kt0 * XBK);
+        store_tile(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * XBK);
+        if (kt + 1 < nk) load_tile((kt0 + kt + 1) * XBK);
         const float* as = As + buf * XBM * XLD + (wm * 64 + li) * XLD + 4 * lh;
         const float* bs = Bs + buf * XBN * XLD + (wn * 32 * NT + li) * XLD + 4 * lh;
 #pragma unroll
@@ -192,6 +203,22 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IefGemmF32Params p
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
+    }
+    if (p.splits > 1) {       // raw partial sums
+        float* slab = p.ws + (long long)blockIdx.y * M * N;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * 32 * NT + b * 32 + li;
+                if (n >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M) slab[(long long)m * N + n] = acc[a][b][r];
+                }
+            }
+        return;
     }
     // ---- epilogue: (acc + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]) * out_scale, fp32
     const float* R = p.residual;
@@ -214,15 +241,40 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IefGemmF32Params p
         }
 }
 
+// out = (sum of the split-K slabs, in slab order, + bias + rowvec + residual) * out_scale
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const IefGemmF32Params p) {
+    const long long total = (long long)p.M * p.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+        float v = p.ws[i];
+        for (int s = 1; s < p.splits; ++s) v += p.ws[(long long)s * total + i];
+        if (p.bias) v += p.bias[n];
+        if (p.rowvec) v += p.rowvec[(long long)(m / p.rows_per_batch) * p.N + n];
+        if (p.residual) v += p.residual[(long long)m * p.ldr + n];
+        p.Out[(long long)m * p.ldo + n] = v * p.out_scale;
+    }
+}
+
 template <bool CONV, bool TRANSB, int NT>
 static int launch_igemm_f32(const IefGemmF32Params& p, hipStream_t st) {
     constexpr int XBN = 64 * NT;
     const int tiles = ((p.M + XBM - 1) / XBM) * ((p.N + XBN - 1) / XBN);
     const int z = p.heads > 0 ? p.batch * p.heads : 1;
-    hipLaunchKernelGGL((igemm_f32_kernel<CONV, TRANSB, NT>), dim3(tiles, 1, z), dim3(256), 0, st, p);
+    const int splits = p.splits > 1 ? p.splits : 1;
+    hipLaunchKernelGGL((igemm_f32_kernel<CONV, TRANSB, NT>), dim3(tiles, splits, z), dim3(256), 0, st, p);
     IEF_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long total = (long long)p.M * p.N;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3(grid), dim3(256), 0, st, p);
+        IEF_LAUNCH_CHECK();
+    }
     return IEF_OK;
 }
+
+// column-tile width the launcher picks for N output columns: 64 when that wastes less of the last tile than 128
+extern "C" int ief_gemm_f32_bn(int N) { return (N <= 64 || ((N % 128) != 0 && (N % 128) <= 64)) ? 64 : 128; }
 
 extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
     if (!pp || !pp->A || !pp->W || !pp->Out) return IEF_EINVAL;
@@ -230,6 +282,7 @@ extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return IEF_ESHAPE;
     if (p.rowvec && p.rows_per_batch <= 0) return IEF_ESHAPE;
     if (p.heads > 0 && p.batch <= 0) return IEF_ESHAPE;
+    if (p.splits > 1 && (!p.ws || p.heads > 0 || p.splits > 64)) return IEF_EINVAL;
     if (p.heads == 0 && (p.a_src || p.w_src)) return IEF_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (p.conv) {
@@ -239,20 +292,47 @@ extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
         if (p.K != 9 * (p.C1 + p.C2) + p.CE1 + p.CE2 || p.M != p.batch_images * p.Ho * p.Wo) return IEF_ESHAPE;
         if (p.stride != 1 && p.stride != 2) return IEF_ESHAPE;
         if (p.ups && ((p.H | p.Wd) & 1)) return IEF_ESHAPE;
-        return p.N <= 64 ? launch_igemm_f32<true, false, 1>(p, st) : launch_igemm_f32<true, false, 2>(p, st);
+        return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<true, false, 1>(p, st) : launch_igemm_f32<true, false, 2>(p, st);
     }
     p.a_scalar = ((p.lda & 3) || (p.K & 3)) ? 1 : 0;          // A rows not 16-byte chunked: element loads for A
     if (p.ldw & 3) return IEF_EALIGN;
     if (!p.transb && (p.K & 3)) return IEF_ESHAPE;             // W [N][K] rows are read in 16-byte chunks along K
     if (p.transb) {
         if (p.N & 3) return IEF_ESHAPE;
-        return p.N <= 64 ? launch_igemm_f32<false, true, 1>(p, st) : launch_igemm_f32<false, true, 2>(p, st);
+        return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<false, true, 1>(p, st) : launch_igemm_f32<false, true, 2>(p, st);
     }
-    return p.N <= 64 ? launch_igemm_f32<false, false, 1>(p, st) : launch_igemm_f32<false, false, 2>(p, st);
+    return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<false, false, 1>(p, st) : launch_igemm_f32<false, false, 2>(p, st);
 }
 
 // --------------------------------------------------------------------------------------------- attention maps
 // in-place softmax over rows of length L (fp32), one wave per row; three passes over a row that stays in L1/L2
+// rows of up to 64 * SMX floats stay in registers: one read, one write
+template <int SMX>
+__global__ __launch_bounds__(256) void softmax_rows_f32_reg_kernel(float* __restrict__ x, long long rows, int L) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = x + row * L;
+    const int lane = threadIdx.x & 63;
+    float v[SMX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SMX; ++i) {
+        const int k = lane + 64 * i;
+        v[i] = k < L ? r[k] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMX; ++i) { v[i] = expf(v[i] - m); s += v[i]; }      // exp(-inf) = 0 for the padding
+    const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < SMX; ++i) {
+        const int k = lane + 64 * i;
+        if (k < L) r[k] = v[i] * inv;
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* __restrict__ x, long long rows, int L) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -270,7 +350,12 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* __restrict
 extern "C" int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream) {
     if (!x) return IEF_EINVAL;
     if (rows <= 0 || L <= 0) return IEF_ESHAPE;
-    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, L);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 128) hipLaunchKernelGGL(softmax_rows_f32_reg_kernel<2>, grid, dim3(256), 0, st, x, rows, L);
+    else if (L <= 1024) hipLaunchKernelGGL(softmax_rows_f32_reg_kernel<16>, grid, dim3(256), 0, st, x, rows, L);
+    else if (L <= 4096) hipLaunchKernelGGL(softmax_rows_f32_reg_kernel<64>, grid, dim3(256), 0, st, x, rows, L);
+    else hipLaunchKernelGGL(softmax_rows_f32_kernel, grid, dim3(256), 0, st, x, rows, L);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
@@ -321,11 +406,86 @@ extern "C" int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* 
 }
 
 // --------------------------------------------------------------------------------------------- norms
-// GroupNorm (+ SiLU) over [B][HW][C1 (+ C2 concat)] fp32: one workgroup per (batch, group); mean first, then the centred
-// second moment (two-pass: no cancellation), then apply — three sweeps of a slab that stays in L2
-__global__ __launch_bounds__(256) void groupnorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
+// GroupNorm (+ SiLU) over [B][HW][C1 (+ C2 concat)] fp32.  KS workgroups per (batch, group): thread (py, j) keeps channel
+// pair j of the group (8-byte accesses, no index arithmetic in the loops); every workgroup streams the whole slab for the
+// mean and then for the centred second moment (two-pass: no cancellation; identical sums in all KS of them, so no
+// hand-off), and normalises every KS-th run of pixels.  cpg even (host-checked; odd cpg: the scalar kernel below).
+__global__ __launch_bounds__(512) void groupnorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
                                                             float* __restrict__ out, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int HW, int groups, float eps, int silu) {
+                                                            const float* __restrict__ beta, int HW, int groups, float eps, int silu,
+                                                            int PY, int KS) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    __shared__ float red[8];
+    __shared__ float bc;
+    const int C = C1 + C2, cpg = C / groups, cp2 = cpg >> 1;
+    const int nbg = gridDim.x / KS;
+    const int ks = blockIdx.x / nbg, id = blockIdx.x - ks * nbg;
+    const int b = id / groups, g = id - b * groups;
+    const int j = threadIdx.x % cp2, py = threadIdx.x / cp2;
+    const bool live = py < PY;
+    const int c = g * cpg + 2 * j;
+    const float* src = c < C1 ? x : x2;
+    const int cs = c < C1 ? C1 : C2, cc = c < C1 ? c : c - C1;
+    const float* base = src + (long long)b * HW * cs + cc;
+    const int nw = (blockDim.x + 63) >> 6;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < nw; ++w) t += red[w]; bc = t; }
+        __syncthreads();
+        return bc;
+    };
+    constexpr int GU = 8;
+    float s = 0.f;
+    if (live) {
+        for (int p0 = py; p0 < HW; p0 += PY * GU) {
+            f32x2 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) { const int p = p0 + u * PY; v[u] = p < HW ? *(const f32x2*)(base + (long long)p * cs) : (f32x2){0.f, 0.f}; }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) s += v[u][0] + v[u][1];
+        }
+    }
+    const float n = (float)cpg * (float)HW;
+    const float mean = block_sum(s) / n;
+    float q = 0.f;
+    if (live) {
+        for (int p0 = py; p0 < HW; p0 += PY * GU) {
+            f32x2 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) { const int p = p0 + u * PY; v[u] = p < HW ? *(const f32x2*)(base + (long long)p * cs) : (f32x2){mean, mean}; }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) { const float d0 = v[u][0] - mean, d1 = v[u][1] - mean; q += d0 * d0 + d1 * d1; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(q) / n + eps);
+    if (!live) return;
+    const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
+    const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+    float* ob = out + (long long)b * HW * C + c;
+    for (int p0 = py + ks * PY * GU; p0 < HW; p0 += PY * GU * KS) {
+        f32x2 v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) { const int p = p0 + u * PY; v[u] = p < HW ? *(const f32x2*)(base + (long long)p * cs) : (f32x2){0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int p = p0 + u * PY;
+            if (p < HW) {
+                float y0 = v[u][0] * sc0 + sh0, y1 = v[u][1] * sc1 + sh1;
+                if (silu) { y0 = silu_x(y0); y1 = silu_x(y1); }
+                *(f32x2*)(ob + (long long)p * C) = (f32x2){y0, y1};
+            }
+        }
+    }
+}
+
+// any cpg (odd included): one workgroup per (batch, group), element-wise indexing
+__global__ __launch_bounds__(256) void groupnorm_f32_scalar_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
+                                                                   int C2, float* __restrict__ out, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, int HW, int groups, float eps,
+                                                                   int silu) {
     __shared__ float red[4];
     __shared__ float bc;
     const int C = C1 + C2, cpg = C / groups;
@@ -351,8 +511,7 @@ __global__ __launch_bounds__(256) void groupnorm_f32_kernel(const float* __restr
     const float mean = block_sum(s) / (float)n;
     float q = 0.f;
     for (long long i = threadIdx.x; i < n; i += 256) { const float d = at(i) - mean; q += d * d; }
-    const float var = block_sum(q) / (float)n;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    const float rstd = 1.0f / sqrtf(block_sum(q) / (float)n + eps);
     for (long long i = threadIdx.x; i < n; i += 256) {
         const long long pix = i / cpg;
         const int c = c0 + (int)(i - pix * cpg);
@@ -365,8 +524,23 @@ extern "C" int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, i
                                       const float* beta, int B, int HW, int groups, float eps, int silu, void* stream) {
     if (!x || !out || !gamma || !beta || (C2 > 0 && !x2)) return IEF_EINVAL;
     if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups) return IEF_ESHAPE;
-    hipLaunchKernelGGL(groupnorm_f32_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, x2, C1, C2, out, gamma,
-                       beta, HW, groups, eps, silu);
+    const int cpg = (C1 + C2) / groups;
+    if ((cpg & 1) || (C1 & 1) || (cpg >> 1) > 256) {
+        hipLaunchKernelGGL(groupnorm_f32_scalar_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, x, x2, C1, C2, out,
+                           gamma, beta, HW, groups, eps, silu);
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
+    const int cp2 = cpg >> 1;
+    int PY = 512 / cp2;
+    if (PY > HW) PY = HW;
+    int threads = ((cp2 * PY + 63) / 64) * 64;
+    if (threads > 512) { PY -= 1; threads = ((cp2 * PY + 63) / 64) * 64; }
+    const int rounds = (HW + PY * 8 - 1) / (PY * 8);
+    int KS = 1;
+    while (KS * 2 <= rounds && B * groups * KS < 1024) KS *= 2;
+    hipLaunchKernelGGL(groupnorm_f32_kernel, dim3(B * groups * KS), dim3(threads), 0, (hipStream_t)stream, x, x2, C1, C2, out,
+                       gamma, beta, HW, groups, eps, silu, PY, KS);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

@@ -14,6 +14,13 @@
 #define GN_MAX_GROUPS 64
 #define GN_PART_FLOATS 4096   // LDS partials of the statistics pass: PY * C <= 4096
 
+#include <stdlib.h>
+// A/B switches read once from the environment (same-box comparisons of two forms of one kernel; not part of the ABI)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 // pixel splits per image for the statistics pass: enough blocks to cover the chip, at least 16 pixels each
 static inline int gn_splits_host(int HW) {
     int s = HW / 16;
@@ -134,10 +141,16 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict_
                                                        int C1, int C2, half_t* __restrict__ out,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ stats_out,
-                                                       int HW, int groups, float eps, int apply_silu, int PY) {
+                                                       int HW, int groups, float eps, int apply_silu, int PY, int KS) {
     const int C = C1 + C2, cpg = C / groups, cp2 = cpg >> 1;
+    // KS workgroups share one (batch, group): each streams the whole slab for the statistics (the same sums in the same
+    // order: identical mean / rstd in all of them, no hand-off) and normalises every KS-th run of pixels — the second,
+    // heavier pass (SiLU + stores) is split KS ways and 128 x KS workgroups fill the chip
+    // (the KS workgroups of a (batch, group) are gridDim.x / KS block ids apart: the same XCD, one L2 copy of the slab)
+    const int nbg = gridDim.x / KS;
+    const int ks = blockIdx.x / nbg;
     // 4 consecutive groups per XCD: id = xcd + 8k  ->  group = 4*xcd + k%4 (needs groups % 32 == 0, else linear)
-    const int id = blockIdx.x;
+    const int id = blockIdx.x - ks * nbg;
     int b, g;
     if ((groups & 31) == 0) {
         const int per_b = groups, local = id % per_b;
@@ -180,12 +193,12 @@ __global__ __launch_bounds__(512) void gn_fused_kernel(const half_t* __restrict_
     const float inv = 1.0f / ((float)cpg * (float)HW);
     const float mean = ts * inv;
     const float rstd = rsqrtf(fmaxf(tq * inv - mean * mean, 0.f) + eps);
-    if (threadIdx.x == 0) { stats_out[((long long)b * groups + g) * 2] = mean; stats_out[((long long)b * groups + g) * 2 + 1] = rstd; }
+    if (threadIdx.x == 0 && ks == 0) { stats_out[((long long)b * groups + g) * 2] = mean; stats_out[((long long)b * groups + g) * 2 + 1] = rstd; }
     if (!live) return;
     const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1];
     const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
     half_t* ob = out + (long long)b * HW * C + c;
-    for (int p0 = py; p0 < HW; p0 += PY * GU) {
+    for (int p0 = py + ks * PY * GU; p0 < HW; p0 += PY * GU * KS) {
         half2_t v[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
@@ -222,9 +235,14 @@ extern "C" int ief_groupnorm_silu_f16(const ief_half* x, const ief_half* x2, int
         if (PY > HW) PY = HW;
         int threads = ((cp2 * PY + 63) / 64) * 64;
         if (threads > 512) { PY -= 1; threads = ((cp2 * PY + 63) / 64) * 64; }
+        // workgroups per (batch, group): enough to put >= 2 workgroups on every CU, each keeping >= one full round of pixels
+        const int rounds = (HW + PY * 8 - 1) / (PY * 8);       // 8 pixels in flight per thread and round
+        static const int ks_max = env_int("IEF_GN_KS_MAX", 2);   // same-box A/B: 1 -> 7.45, 8 -> 7.42, 2 -> 7.39 ms per step
+        int KS = 1;
+        while (KS * 2 <= rounds && KS * 2 <= ks_max && B * groups * KS < 512) KS *= 2;
         // (mean, rstd) land where the three-launch path leaves them: after the split partials
-        hipLaunchKernelGGL(gn_fused_kernel, dim3(B * groups), dim3(threads), 0, st, x, x2, C1, C2, out, gamma, beta,
-                           partial + (long long)B * gn_splits_host(HW) * groups * 2, HW, groups, eps, apply_silu, PY);
+        hipLaunchKernelGGL(gn_fused_kernel, dim3(B * groups * KS), dim3(threads), 0, st, x, x2, C1, C2, out, gamma, beta,
+                           partial + (long long)B * gn_splits_host(HW) * groups * 2, HW, groups, eps, apply_silu, PY, KS);
         IEF_LAUNCH_CHECK();
         return IEF_OK;
     }
@@ -383,7 +401,8 @@ extern "C" int ief_groupnorm_cstat_f16(const ief_half* x, const ief_half* x2, in
         const int nt = nt1 > nt2 ? nt1 : nt2;
         int CW = unit * ((192 + unit - 1) / unit);            // ~192 channels per slice
         if (CW > C) CW = C;
-        if (unit <= 256 && CW <= GNS_MAXC && CW / 8 <= 256 && (long long)nt * CW * 8 <= 16 * 1024 && B <= 65535) {
+        static const int fused_ok = env_int("IEF_GN_CSTAT_FUSED", 1);
+        if (fused_ok && unit <= 256 && CW <= GNS_MAXC && CW / 8 <= 256 && (long long)nt * CW * 8 <= 16 * 1024 && B <= 65535) {
             const int PY = 256 / (CW / 8);
             int ppb = PY * 4;                                  // ~4 pixels per thread
             if (ppb > HW) ppb = HW;

@@ -91,6 +91,7 @@ class IefGemmF32Params(Structure):
         ("batch", c_int), ("heads", c_int),
         ("sAb", c_longlong), ("sAh", c_longlong), ("sWb", c_longlong), ("sWh", c_longlong), ("sOb", c_longlong), ("sOh", c_longlong),
         ("a_src", c_void_p), ("w_src", c_void_p), ("transb", c_int), ("a_scalar", c_int),
+        ("splits", c_int), ("ws", c_void_p),
     ]
 
 
@@ -108,7 +109,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn",
 ]
 
 
@@ -764,6 +765,21 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     return (out, cst) if col_stats else out
 
 
+def _splits_f32(lib, p, M, N, K, device):
+    """split-K for the fp32 GEMM when M x N alone gives too few 128-row tiles for the 256 CUs (the 16x16 / 8x8 levels):
+    aim at ~512 workgroups, every slice keeping >= 4 K tiles of 32"""
+    tiles = -(-M // 128) * -(-N // lib.ief_gemm_f32_bn(N))
+    nk = -(-K // 32)
+    if tiles >= 256 or nk < 8:
+        return None
+    splits = max(1, min(-(-512 // tiles), nk // 4, 16))
+    if splits <= 1:
+        return None
+    ws = torch.empty(splits * M * N, dtype=torch.float32, device=device)
+    p.splits, p.ws = splits, ws.data_ptr()
+    return ws
+
+
 def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, transb=False):
     """fp32 out[..., n] = (a . w[n] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale;
     transb: w is [K, N] (rows along K) instead of [N, K]"""
@@ -792,6 +808,7 @@ def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out
         p.residual, p.ldr = residual.data_ptr(), ldr
     p.M, p.N, p.K, p.lda, p.ldw, p.ldo = M, N, K, lda, w.stride(0), ldo
     p.out_scale, p.transb = out_scale, 1 if transb else 0
+    ws = _splits_f32(lib, p, M, N, K, a.device)     # noqa: F841  (keeps the slabs alive until the launch is queued)
     nbytes = 4.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))
     with _Timed(f"igemm_f32_kernel<false, {'true' if transb else 'false'}>", 2.0 * M * N * K, nbytes):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32")
@@ -850,6 +867,7 @@ def _conv3x3_f32(x, w, bias, x2, stride, upsample, rowvec, residual, out, extra,
     p.stride, p.ups, p.batch_images, p.pad_hi_only = stride, 1 if upsample else 0, B, 1 if pad_hi_only else 0
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.out_scale = 1.0
+    ws = _splits_f32(lib, p, M, Cout, K, x.device)  # noqa: F841
     nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * (2 if residual is not None else 1))
     with _Timed("igemm_f32_kernel<true, false>", 2.0 * M * Cout * K, nbytes):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (conv)")

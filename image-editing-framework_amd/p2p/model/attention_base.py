@@ -14,7 +14,9 @@ IN PLACE, and the returned tensor aliases the argument (:22).
 These Python bodies are what the GENERIC hook path executes (materialised maps, any user
 subclass).  For the classes defined in this package `register_attention_control` lowers the
 same arithmetic into the fused HIP attention kernels instead (see `register.py`,
-`lower_controller`); both paths are held to identical results by tests/test_gpu_p2p.py.
+`lower_controller`); both paths are held to the oracle and to each other by
+`tests/test_gpu_unet.py::test_p2p_controlled_forward_fused_generic_oracle` (every lowerable class) and, at full SD1.5 size,
+`tests/test_gpu_fullsize.py`.
 """
 import abc
 from typing import Dict, Optional, Tuple, Union

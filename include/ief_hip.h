@@ -249,8 +249,13 @@ typedef struct IefGemmF32Params {
     const int* w_src;
     int transb;
     int a_scalar;           /* set by the library: A rows are not 16-byte chunked */
+    /* split-K (not batched): K cut `splits` ways over grid.y, fp32 slabs ws[splits][M][N], summed in slab order by a second
+     * launch that applies the epilogue */
+    int splits;
+    float* ws;
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
+int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */
 int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
 /* P'[w] = c1[w] * sum_v P_src[v] M[v][w] + c2[w] * P_tgt[w] in place on maps [B*heads][N][L], L <= 96; MT fp32
  * [slots][96][96] (M transposed, zero padded), coef fp32 [slots][2][96]; edit_src / edit_slot as IefCrossParams */
