@@ -304,6 +304,156 @@ extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
     return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<false, false, 1>(p, st) : launch_igemm_f32<false, false, 2>(p, st);
 }
 
+// --------------------------------------------------------------------------------------------- fused attention, fp32
+// out[b] = softmax(scale * q[q_src[b]] k[k_src[b]]^T) v[v_src[b]] without materialising the maps (self-attention and
+// un-edited cross-attention of the reference-precision mode; the P2P cross edit and the generic controller path keep the
+// materialised pipeline below).  One workgroup = 128 queries of one (batch row, head), a wave = 32 of them; 32-key tiles.
+//   S^T = K Q^T on v_mfma_f32_32x32x2_f32: a lane owns one query COLUMN (16 keys of the tile in its registers, the other
+//   16 in lane + 32), so the running maximum / sum are in-lane plus one cross-half exchange, and the P registers are
+//   directly the B operand of O^T += V^T P^T (the k order of that product is whatever the accumulator layout gives; the
+//   V^T fragment is read from LDS in the matching order).  d is padded to 32-row tiles of O^T (d = 40: 64 rows).
+template <int D>
+__global__ __launch_bounds__(256) void attn_flash_f32_kernel(const IefAttnF32Params p) {
+    constexpr int DT = (D + 31) / 32;            // 32-row tiles of O^T
+    constexpr int KLD = D + 4;                   // K tile row stride (floats): rows start 4 banks apart mod 64 -> b128 reads conflict-free
+    constexpr int VLD = DT * 32 + 4;             // V tile row stride; columns D..DT*32 are zero
+    __shared__ __attribute__((aligned(16))) float smem_a[32 * KLD + 32 * VLD];
+    float* Ks = smem_a;
+    float* Vs = smem_a + 32 * KLD;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+    const int bq = p.q_src ? p.q_src[b] : b, bk = p.k_src ? p.k_src[b] : b, bv = p.v_src ? p.v_src[b] : b;
+    const float* Q = p.Q + (long long)bq * p.sQb + (long long)h * D;
+    const float* K = p.K + (long long)bk * p.sKb + (long long)h * D;
+    const float* V = p.V + (long long)bv * p.sVb + (long long)h * D;
+    float* O = p.Out + (long long)b * p.sOb + (long long)h * D;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int qi = q0 + li;
+    // this lane's share of its query: for every 8-deep d group the 4 values of its lane half
+    f32x4 qf[D / 8];
+#pragma unroll
+    for (int g = 0; g < D / 8; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qi < p.N) v = *(const f32x4*)(Q + (long long)qi * p.ldq + g * 8 + 4 * lh);
+        qf[g] = v;
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr int KCH = 32 * (D / 4);            // 16-byte chunks of one K (or V) tile
+    constexpr int NLD = (KCH + 255) / 256;
+    f32x4 rk[NLD], rv[NLD];
+    auto load_kv = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / (D / 4), ch = c - row * (D / 4);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+            if (c < KCH && k0 + row < p.L) {
+                a = *(const f32x4*)(K + (long long)(k0 + row) * p.ldk + ch * 4);
+                bb = *(const f32x4*)(V + (long long)(k0 + row) * p.ldv + ch * 4);
+            }
+            rk[i] = a; rv[i] = bb;
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            if (c < KCH) {
+                const int row = c / (D / 4), ch = c - row * (D / 4);
+                *(f32x4*)(Ks + row * KLD + ch * 4) = rk[i];
+                *(f32x4*)(Vs + row * VLD + ch * 4) = rv[i];
+            }
+        }
+    };
+    if (DT * 32 > D) {                            // zero the padding columns of the V tile once
+        for (int c = tid; c < 32 * (DT * 32 - D); c += 256) {
+            const int row = c / (DT * 32 - D), col = D + c - row * (DT * 32 - D);
+            Vs[row * VLD + col] = 0.f;
+        }
+    }
+    const int nt = (p.L + 31) / 32;
+    load_kv(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();                          // everybody is done with the previous tile
+        store_kv();
+        __syncthreads();
+        if (t + 1 < nt) load_kv((t + 1) * 32);
+        // ---- S^T tile: 32 keys x 32 queries
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            const f32x4 kf = *(const f32x4*)(Ks + li * KLD + g * 8 + 4 * lh);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s2], qf[g][s2], sacc, 0, 0, 0);
+        }
+        // ---- online softmax over the key rows of this tile (register r <-> key (r&3) + 8 (r>>2) + 4 lh)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sacc[r] = key < p.L ? sacc[r] * p.scale : -INFINITY;
+            mx = fmaxf(mx, sacc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = expf(sacc[r] - m_new); ls += sacc[r]; }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+        // ---- O^T += V^T P^T: step r multiplies keys {(r&3) + 8 (r>>2), + 4}: lane half lh supplies / reads its own key row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vrow = Vs + ((r & 3) + 8 * (r >> 2) + 4 * lh) * VLD + li;
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[tt * 32], sacc[r], o[tt], 0, 0, 0);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qi < p.N) {
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (d < D) O[(long long)qi * p.ldo + d] = o[tt][r] * inv;
+            }
+    }
+}
+
+extern "C" int ief_attn_flash_f32(const IefAttnF32Params* pp, void* stream) {
+    if (!pp || !pp->Q || !pp->K || !pp->V || !pp->Out) return IEF_EINVAL;
+    const IefAttnF32Params p = *pp;
+    if (p.B <= 0 || p.heads <= 0 || p.N <= 0 || p.L <= 0) return IEF_ESHAPE;
+    if ((p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.sQb & 3) || (p.sKb & 3) || (p.sVb & 3)) return IEF_EALIGN;
+    dim3 grid((p.N + 127) / 128, p.B * p.heads);
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.d) {
+        case 32: hipLaunchKernelGGL(attn_flash_f32_kernel<32>, grid, dim3(256), 0, st, p); break;
+        case 40: hipLaunchKernelGGL(attn_flash_f32_kernel<40>, grid, dim3(256), 0, st, p); break;
+        case 64: hipLaunchKernelGGL(attn_flash_f32_kernel<64>, grid, dim3(256), 0, st, p); break;
+        case 80: hipLaunchKernelGGL(attn_flash_f32_kernel<80>, grid, dim3(256), 0, st, p); break;
+        case 160: hipLaunchKernelGGL(attn_flash_f32_kernel<160>, grid, dim3(256), 0, st, p); break;
+        default: return IEF_ESHAPE;
+    }
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 // --------------------------------------------------------------------------------------------- attention maps
 // in-place softmax over rows of length L (fp32), one wave per row; three passes over a row that stays in L1/L2
 // rows of up to 64 * SMX floats stay in registers: one read, one write

@@ -95,6 +95,17 @@ class IefGemmF32Params(Structure):
     ]
 
 
+class IefAttnF32Params(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("Out", c_void_p),
+        ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int),
+        ("sQb", c_longlong), ("sKb", c_longlong), ("sVb", c_longlong), ("sOb", c_longlong),
+        ("scale", c_float),
+        ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p),
+    ]
+
+
 EXPORTS = [
     "ief_abi_version", "ief_target_arch", "ief_gemm_f16", "ief_conv3x3_f16", "ief_conv_in_f32",
     "ief_conv_out_f32", "ief_gn_splits", "ief_groupnorm_silu_f16", "ief_layernorm_f16", "ief_geglu_f16",
@@ -109,7 +120,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32",
 ]
 
 
@@ -180,6 +191,7 @@ def load():
     lib.ief_gather_rows_f16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]
     lib.ief_gemm_f32.argtypes = [POINTER(IefGemmF32Params), c_void_p]
     lib.ief_softmax_rows_f32.argtypes = [c_void_p, c_longlong, c_int, c_void_p]
+    lib.ief_attn_flash_f32.argtypes = [POINTER(IefAttnF32Params), c_void_p]
     lib.ief_p2p_cross_edit_f32.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
     lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_float, c_int, c_void_p]
@@ -1125,6 +1137,31 @@ def _batched32(p, t, heads, d, which):
     return t.stride(0), d, t.stride(1)
 
 
+FLASH_F32 = os.environ.get("IEF_FLASH_F32", "1") == "1"      # 0: always materialise the fp32 maps (A/B runs)
+
+
+def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None):
+    """fused fp32 attention (`ief_attn_flash_f32`): no map is written; None when the head dim has no instantiation"""
+    lib = load()
+    B, N, C = q.shape
+    L, d = k.shape[1], C // heads
+    if not FLASH_F32 or d not in (32, 40, 64, 80, 160):
+        return None
+    if out is None:
+        out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+    p = IefAttnF32Params()
+    p.Q, p.K, p.V, p.Out = _act32(q, "q").data_ptr(), _act32(k, "k").data_ptr(), _act32(v, "v").data_ptr(), _act32(out, "out").data_ptr()
+    p.B, p.heads, p.N, p.L, p.d, p.scale = B, heads, N, L, d, scale
+    p.sQb, _, p.ldq = _batched32(p, q, heads, d, "q")
+    p.sKb, _, p.ldk = _batched32(p, k, heads, d, "k")
+    p.sVb, _, p.ldv = _batched32(p, v, heads, d, "v")
+    p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
+    p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
+    with _Timed(f"attn_flash_f32_kernel<{d}>", 4.0 * B * heads * N * L * d, 4.0 * B * heads * d * (2 * N + 2 * L)):
+        _check(lib.ief_attn_flash_f32(byref(p), _stream()), "ief_attn_flash_f32")
+    return out
+
+
 def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None, softmax=True):
     """materialised maps softmax(scale q k^T) as contiguous fp32 [B*heads, N, L] (`register.py:43-47`): one batched
     launch of the fp32 GEMM over (batch row, head) + a row softmax (softmax=False: the scaled scores themselves)"""
@@ -1211,6 +1248,9 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     if _is32(q):
         if lse is not None:
             raise ValueError("attn_flash: lse output exists only on the fp16 path")
+        o = _attn_flash_f32(q, k, v, heads, scale, q_src, k_src, v_src, out)
+        if o is not None:
+            return o
         return _attn_apply_f32(_attn_scores_f32(q, k, heads, scale, q_src, k_src), v, heads, v_src, out)
     lib = load()
     if out is None:
@@ -1234,6 +1274,10 @@ def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None
     """Cross-attention (<= 96 keys) with the fused Prompt-to-Prompt map edit (see include/ief_hip.h).
     fp32 operands: materialised maps, `mt` must then be the fp32 table."""
     if _is32(q):
+        if edit_src is None:
+            o = _attn_flash_f32(q, k, v, heads, scale, out=out)
+            if o is not None:
+                return o
         probs = _attn_scores_f32(q, k, heads, scale)
         if edit_src is not None:
             p2p_cross_edit_(probs, q.shape[0], heads, edit_src, edit_slot, mt, coef)

@@ -39,7 +39,6 @@ def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32, precis
                                                        precision=precision)
     if sd_version in ("xl-base", "smallxl"):       # `StableDiffusionXLPipeline` branch of edit_syn.py:63-65
         from ief_amd.pipeline import StableDiffusionXLPipeline
-        if precision != "f16":
-            raise NotImplementedError("the reference-precision mode is built for the SD1.x / SD2.x pipelines")
-        return StableDiffusionXLPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device)
+        return StableDiffusionXLPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device,
+                                                         precision=precision)
     raise ValueError("please use the right sd_version")

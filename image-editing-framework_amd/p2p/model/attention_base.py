@@ -16,7 +16,7 @@ subclass).  For the classes defined in this package `register_attention_control`
 same arithmetic into the fused HIP attention kernels instead (see `register.py`,
 `lower_controller`); both paths are held to the oracle and to each other by
 `tests/test_gpu_unet.py::test_p2p_controlled_forward_fused_generic_oracle` (every lowerable class) and, at full SD1.5 size,
-`tests/test_gpu_fullsize.py`.
+`tests/test_gpu_zz_fullsize.py`.
 """
 import abc
 from typing import Dict, Optional, Tuple, Union

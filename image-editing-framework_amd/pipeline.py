@@ -113,7 +113,7 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
 
     @classmethod
     def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
-                        keep_state_dict: bool = False, **unused):
+                        keep_state_dict: bool = False, precision: str = "f16", **unused):
         from .unet import UNet2DConditionModel
         import dataclasses
         sched = scheduler if scheduler is not None else DDIMScheduler()
@@ -123,9 +123,9 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
             cfg, sd = _load_local_unet(model_key)
             if not cfg.addition_embed:
                 raise ValueError(f"{model_key}: unet/config.json is not an SDXL-family configuration")
-            vae = _load_local_vae(model_key, device)
+            vae = _load_local_vae(model_key, device, precision)
             tokenizer, tokenizer_2, enc1, enc2 = _load_local_text_xl(model_key, cfg)
-            unet = UNet2DConditionModel(cfg, sd, device=device)
+            unet = UNet2DConditionModel(cfg, sd, device=device, precision=precision)
             return cls(unet, tokenizer, enc1.to(device), vae, sched, cfg, sd if keep_state_dict else None,
                        text_encoder_2=enc2.to(device), tokenizer_2=tokenizer_2)
         if not model_key.startswith("synthetic:"):
@@ -144,8 +144,8 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         enc1 = SyntheticTextEncoder(cfg.cross_attention_dim - d2, seed=1).to(device)
         enc2 = SyntheticTextEncoder(d2, seed=2).to(device)
         vcfg = SD_VAE if parts[1] == "sdxl" else TINY_VAE
-        vae = AutoencoderKL(dataclasses.replace(vcfg, scaling_factor=0.13025), device=device)   # the SDXL VAE's factor
-        unet = UNet2DConditionModel(cfg, sd, device=device)
+        vae = AutoencoderKL(dataclasses.replace(vcfg, scaling_factor=0.13025), device=device, precision=precision)   # the SDXL VAE's factor
+        unet = UNet2DConditionModel(cfg, sd, device=device, precision=precision)
         return cls(unet, tokenizer, enc1, vae, sched, cfg, sd if keep_state_dict else None, text_encoder_2=enc2)
 
     def _hidden_and_pooled(self, texts):

@@ -256,6 +256,17 @@ typedef struct IefGemmF32Params {
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
 int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */
+/* fused fp32 attention (maps never written): out[b] = softmax(scale q[q_src[b]] k[k_src[b]]^T) v[v_src[b]]; q [B][N][heads*d]
+ * (row stride ldq, batch stride sQb; likewise k, v over L keys and out); d in {32, 40, 64, 80, 160}; *_src NULL = identity */
+typedef struct IefAttnF32Params {
+    const float* Q; const float* K; const float* V; float* Out;
+    int B, heads, N, L, d;
+    int ldq, ldk, ldv, ldo;
+    long long sQb, sKb, sVb, sOb;
+    float scale;
+    const int* q_src; const int* k_src; const int* v_src;
+} IefAttnF32Params;
+int ief_attn_flash_f32(const IefAttnF32Params* p, void* stream);
 int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
 /* P'[w] = c1[w] * sum_v P_src[v] M[v][w] + c2[w] * P_tgt[w] in place on maps [B*heads][N][L], L <= 96; MT fp32
  * [slots][96][96] (M transposed, zero padded), coef fp32 [slots][2][96]; edit_src / edit_slot as IefCrossParams */

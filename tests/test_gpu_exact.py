@@ -130,8 +130,18 @@ def _attn_ref(q, k, v, heads, scale, qs=None, ks=None, vs=None, hook=None):
     return (p @ vh).permute(0, 2, 1, 3).reshape(B, N, C).float(), p.float()
 
 
+def test_attention_f32_peaky_rows_force_the_rescale():
+    """one key per 32-key tile dominates, growing tile by tile: the running maximum moves at every tile of the fused kernel"""
+    B, heads, N, L, d = 1, 2, 160, 512, 64
+    q, k, v = f32(B, N, heads * d, seed=1), f32(B, L, heads * d, seed=2), f32(B, L, heads * d, seed=3)
+    for t in range(L // 32):
+        k[0, 32 * t + 7, :] = q[0, 5, :] * (0.5 + 0.25 * t)
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, d ** -0.5 * 4.0)
+    assert rel_err(out, _attn_ref(q, k, v, heads, d ** -0.5 * 4.0)[0]) < KTOL
+
+
 @pytest.mark.parametrize("B,heads,N,L,d", [(2, 8, 1024, 1024, 40), (4, 8, 256, 256, 80), (2, 2, 200, 144, 64),
-                                           (2, 4, 100, 77, 160), (1, 3, 96, 77, 32)])
+                                           (2, 4, 100, 77, 160), (1, 3, 96, 77, 32), (1, 2, 130, 33, 40)])
 def test_attention_f32_materialised(B, heads, N, L, d):
     """scores (batched fp32 GEMM over (batch row, head) on strided q | k | v views) + row softmax + P.V, with the batch-row
     indirection of P2P self-replace / MasaCtrl; maps also handed out as `attn_probs` (generic controller path)"""
@@ -140,9 +150,11 @@ def test_attention_f32_materialised(B, heads, N, L, d):
     qd, kd = dev(qkv), dev(kv)
     q, k, v = qkv[..., :C], kv[..., :C], kv[..., C:]
     scale = d ** -0.5
-    out = hip.attn_flash(qd[..., :C], kd[..., :C], kd[..., C:], heads, scale)
+    out = hip.attn_flash(qd[..., :C], kd[..., :C], kd[..., C:], heads, scale)          # fused kernel (maps never written)
     ref, refp = _attn_ref(q, k, v, heads, scale)
     assert out.dtype == torch.float32 and rel_err(out, ref) < KTOL
+    mat = hip._attn_apply_f32(hip._attn_scores_f32(qd[..., :C], kd[..., :C], heads, scale), kd[..., C:], heads)   # materialised
+    assert rel_err(mat, ref) < KTOL
     probs = hip.attn_probs(qd[..., :C], kd[..., :C], heads, scale)
     assert probs.shape == (B * heads, N, L) and probs.is_contiguous()
     assert (probs.cpu() - refp.reshape(B * heads, N, L)).abs().max().item() < 1e-6
@@ -292,6 +304,45 @@ def test_p2p_controlled_forward_exact(kind, step, small32):
     e_f, e_g, effect = rel_err(outs[True], ref), rel_err(outs[False], ref), rel_err(plain, ref)
     print(f"exact {kind} step {step}: fused {e_f:.3e} generic {e_g:.3e} (the edit moves eps by {effect:.3e})")
     assert e_f < 1e-4 and e_g < 1e-4 and effect > 100 * e_f
+
+
+def test_other_folders_and_families_in_exact_mode(tiny32):
+    """the dtype dispatch serves every method folder: MasaCtrl's mutual self-attention (K / V batch-row indirection of the
+    materialised fp32 attention) and the SDXL shape family (depth > 1 transformers, additional embedding) against the
+    oracle at fp32 accuracy"""
+    from ief_amd.masactrl.model.attention_control import MutualSelfAttentionControl
+    from ief_amd.masactrl.model.register import regiter_attention_editor_diffusers, unregister_attention_control as unreg
+    from ief_amd.pipeline import StableDiffusionXLPipeline
+    from oracle.masactrl_ref import MasaCtrlRef
+    pipe = tiny32
+    cfg = pipe.cfg
+    x1, ctx = _inputs(cfg, 4, seed=9)
+    x = torch.cat([x1[:1], 0.6 * x1[:1] + 0.8 * x1[1:2]] * 2)
+    c = MutualSelfAttentionControl(4, 10, total_steps=50)
+    regiter_attention_editor_diffusers(pipe, c)
+    c.cur_step = 6
+    got = pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
+    unreg(pipe, c)
+    nl = unet_ref.count_attention_layers(cfg)
+    r = MasaCtrlRef(step_idx=list(range(4, 50)), layer_idx=list(range(10, 16)), num_att_layers=nl, cur_step=6)
+    ref = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx, qkv_hook=r)
+    plain = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(501), ctx)
+    e, effect = rel_err(got, ref), rel_err(plain, ref)
+    print(f"exact MasaCtrl step 6: {e:.3e} (the control moves eps by {effect:.3e})")
+    assert e < 1e-4 and effect > 100 * e
+    xl = StableDiffusionXLPipeline.from_pretrained("synthetic:smallxl", keep_state_dict=True, precision="f32")
+    xc = xl.cfg
+    g = torch.Generator().manual_seed(2)
+    xs = torch.randn(2, 4, xc.sample_size, xc.sample_size, generator=g)
+    cs = torch.randn(2, 77, xc.cross_attention_dim, generator=g)
+    size = float(xc.sample_size * 8)
+    added = {"text_embeds": torch.randn(2, xc.pooled_text_dim, generator=g) * 0.5,
+             "time_ids": torch.tensor([[size, size, 0.0, 0.0, size, size]] * 2)}
+    got = xl.unet(xs.to(DEV), 301, encoder_hidden_states=cs.to(DEV), added_cond_kwargs={k: v.to(DEV) for k, v in added.items()})["sample"]
+    ref = unet_ref.unet_forward(xl._state_dict, xc, xs, 301, cs, added_cond_kwargs=added)
+    e = rel_err(got, ref)
+    print(f"exact smallxl forward: {e:.3e}")
+    assert e < 1e-4
 
 
 def test_full_edit_images_exact_within_1e3(tiny32):
