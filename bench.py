@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--exact-steps", type=int, default=5,
                     help="also time this many edit steps in the reference-precision mode (fp32 weights / activations on the "
                     "fp32-input MFMA, precision='f32'); N = 1 only; 0: skip")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one "
+                    "GPU, which RCCL refuses: rehearsals of the N > 1 paths on a one-GPU box)")
     ap.add_argument("--pie-images", type=int, default=8, help="synthetic PIE images timed per GPU for images_per_sec (0: skip)")
     ap.add_argument("--steps-1024", type=int, default=10, help="timed edit steps on 128x128 latents (0: skip)")
     return ap.parse_args()
@@ -178,12 +180,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device(f"cuda:{local}")
+    dev = torch.device(f"cuda:{local % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from ief_amd import hip
     from ief_amd.p2p.model.sd_utils import _encode_prompts

@@ -100,6 +100,21 @@ def test_cfg_split_two_ranks_one_edit(tmp_path):
     assert rec["rel_split_vs_full"] < 5e-3
 
 
+def test_bench_two_ranks_weak_and_cfg_split(tmp_path):
+    """`bench.py --gpus 2` under the driver's launch line, both ranks on this box's one GPU over gloo (RCCL refuses two ranks
+    per device): the weight broadcast, the barriers / max-over-ranks timing of the weak-scaling line, and `--split cfg`
+    (one edit on two ranks, strong scaling)"""
+    base = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    tail = ["--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "tiny", "--no-cpu-baseline", "--dist-backend", "gloo",
+            "--pie-images", "1", "--steps-1024", "0", "--in-flight", "", "--exact-steps", "0"]
+    out = run(base + ["--master-port", "29641", os.path.join(ROOT, "bench.py")] + tail, cwd=ROOT, timeout=600)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and rec["images_per_sec"] > 0
+    out = run(base + ["--master-port", "29643", os.path.join(ROOT, "bench.py")] + tail + ["--split", "cfg"], cwd=ROOT, timeout=600)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+
+
 def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
     """--invert_batch K inverts K images in one batched DDIM loop and --in_flight E steps E edits concurrently; images
     are independent, so the PNGs must match the per-image run."""

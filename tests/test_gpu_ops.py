@@ -634,9 +634,9 @@ def test_producer_column_statistics(kind, B, hw, cin, cout):
     assert torch.equal(again, stat)                     # fixed summation order
 
 
-@pytest.mark.parametrize("C1,C2,hw", [(320, 0, 64), (640, 320, 64), (1280, 640, 32)])
+@pytest.mark.parametrize("C1,C2,hw", [(320, 0, 64), (640, 320, 64), (1280, 640, 32), (640, 320, 16), (1280, 0, 16), (1280, 1280, 16)])
 def test_groupnorm_from_producer_statistics(C1, C2, hw, monkeypatch):
-    """the two-launch GroupNorm on the producers' statistics against F.group_norm, against the three-launch path, and bit
+    """GroupNorm on the producers' statistics (one launch at 2-8 tiles per image: the hw = 16 cases; fold + apply above) against F.group_norm, against the path without them, and bit
     reproducible; statistics handed over for the wrong tensor are refused"""
     B = 2
     mk = lambda c, seed: hip.conv3x3(dev(h16(B, hw, hw, 64, seed=seed)), dev(h16(c, 3, 3, 64, seed=seed + 1, scale=1 / 24.0)),

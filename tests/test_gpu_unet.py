@@ -16,9 +16,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from ief_amd import config, weights  # noqa: E402
+import ief_amd  # noqa: E402,F401
 from ief_amd.pipeline import StableDiffusionPipeline  # noqa: E402
-from ief_amd.p2p.model.attention_base import EmptyControl  # noqa: E402
+from ief_amd.p2p.model.attention_base import AttentionStore  # noqa: E402
+from ief_amd.p2p.model.ptp_utils import LocalBlend  # noqa: E402
 from ief_amd.p2p.model.attention_control import AttentionRefine, AttentionReplace, AttentionReweight  # noqa: E402
 from ief_amd.p2p.model import seq_aligner  # noqa: E402
 from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control  # noqa: E402
@@ -296,6 +297,56 @@ def test_masactrl_user_editor_takes_the_generic_path(tiny):
     e, effect = rel_err(got, ref), rel_err(plain, ref)
     print(f"masactrl user editor (generic path): {e:.3e} vs oracle, the editor moves eps by {effect:.3e}")
     assert e < FWD_TOL and effect > 4 * e
+
+
+def test_attention_store_and_local_blend_on_hip_maps(small):
+    """AttentionStore (`/root/reference/p2p/model/attention_base.py:57-91`) fed by the generic HIP path (`ief_attn_probs_f16`
+    maps handed to the Python controller), two steps, against the oracle's materialised fp32 maps; then LocalBlend
+    (`ptp_utils.py:20-32`) on the HIP-produced store against LocalBlend on the oracle's store.  The two-level net at 32x32
+    latents stores [32^2, 32^2, 16^2, 16^2] down and [16^2 x 3, 32^2 x 3] up: the slots LocalBlend indexes
+    (`down_cross[2:4] + up_cross[:3]`, :22) hold 16x16 maps exactly as in the 64x64-latent SD1.5 net."""
+    sd15 = small
+    cfg = small.cfg
+    x1, ctx = _inputs(cfg, 4, seed=7)
+    ctx = ctx * 10.0
+    x = torch.cat([x1[:1], 0.8 * x1[:1] + 0.6 * x1[1:2]] * 2)
+    st = AttentionStore(False)
+    register_attention_control(sd15, st)                 # not lowerable: generic path
+    assert sd15.unet._plan is None
+    # two controller steps on the SAME (latents, t): the store must accumulate two HIP-produced maps per slot and average
+    # them back to the oracle's single map (one ~17 s oracle pass instead of two)
+    for _ in range(2):
+        sd15.unet(x.to(DEV), 981, encoder_hidden_states=ctx.to(DEV))
+    rc = p2p_ref.P2PControlRef(mode="empty", num_prompts=2, store={})
+    rc.num_att_layers = unet_ref.count_attention_layers(cfg)
+    with torch.no_grad():
+        unet_ref.unet_forward(sd15._state_dict, cfg, x, torch.tensor(981), ctx, hook=rc)
+    ref_sum = {k: [m * 2 for m in v] for k, v in rc.store.items()}
+    assert st.cur_step == 2 and st.cur_att_layer == 0
+    unregister_attention_control(sd15, st)
+    avg = st.get_average_attention()
+    assert {k: len(v) for k, v in avg.items()} == {"down_cross": 4, "mid_cross": 1, "up_cross": 6,
+                                                   "down_self": 4, "mid_self": 1, "up_self": 6}
+    assert [m.shape[1] for m in avg["down_cross"]] == [1024, 1024, 256, 256] and [m.shape[1] for m in avg["up_cross"][:3]] == [256] * 3
+    worst = 0.0
+    for key, maps in avg.items():
+        for i, m in enumerate(maps):
+            r = ref_sum[key][i] / 2
+            assert m.shape == r.shape and m.shape[0] == 16            # cond half: 2 prompts x 8 heads
+            worst = max(worst, (m.float().cpu() - r).abs().max().item())
+    print(f"AttentionStore on HIP maps: max |avg map - oracle| = {worst:.2e}")
+    # fp16 maps in [0, 1] (peaky here: unit-variance embeddings): 2.4e-4 per stored value, 4.9e-4 when two are summed in
+    # fp16 (values up to 2), plus the kernel's own error on near-one-hot rows: measured 1.8e-3 (8.8e-4 at SD1.5 size)
+    assert worst < 4e-3
+    lb = LocalBlend(sd15.tokenizer, PROMPTS, [["house"], ["fall"]], device=DEV)
+    x_t = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(7))
+    got = lb(x_t.to(DEV), {k: [m.float() for m in v] for k, v in avg.items()}).cpu()
+    lb_ref = LocalBlend(sd15.tokenizer, PROMPTS, [["house"], ["fall"]], device=torch.device("cpu"))
+    want = lb_ref(x_t, {k: [m / 2 for m in v] for k, v in ref_sum.items()})
+    same = (got == want).float().mean().item()
+    blended = (want != x_t[:1]).any(1).float().mean().item()
+    print(f"LocalBlend on HIP maps: {same:.4f} of the elements identical to the oracle's (mask covers {blended:.2f} of the pixels)")
+    assert torch.equal(got[0], want[0]) and same > 0.995 and 0.0 < blended < 1.0
 
 
 def test_full_edit_images_vs_oracle(tiny):

@@ -2,18 +2,20 @@
 
   * the workload `bench.py` times: SD1.5 shapes, 64x64 latents, UNet batch 4 (2 prompts x CFG), AttentionRefine lowered
     into the fused kernels, at two points of the schedule (self-replace window open / closed);
-  * the controllers that only exist on the generic path (AttentionStore, LocalBlend) on HIP-produced maps at SD1.5
-    geometry (LocalBlend's indices into the store assume the 64x64-latent UNet: `/root/reference/p2p/model/ptp_utils.py:22`);
-  * plain forwards of the SD2.1 (96x96 latents, d = 64, context 1024) and SDXL (128x128 latents, depth-10 transformers,
-    additional embedding) shape families at FULL size.
+  * the SD2.1 shape family (96x96 latents, d = 64, context 1024) at FULL size with both Plug-and-Play injections active
+    (BASELINE.json configs[3]), the SDXL family (128x128 latents, depth-10 transformers, additional embedding) and the
+    SD1.5 net on 128x128 latents at FULL size.
+(AttentionStore / LocalBlend on HIP-produced maps: tests/test_gpu_unet.py, on the two-level net whose store has the same
+index structure.)
 
 Stated tolerance: max |eps - eps_oracle| <= 5e-3 * max |eps_oracle| for one forward of the fp16-storage path (measured
 1.7-2.6e-3, printed with -s); stored maps (fp16, accumulated in fp16 as the reference's `+=` does) within 2e-3 absolute.  The CPU oracle takes ~10-20 s per
 batch-4 forward on the GPU box's host cores.
 
 This module runs LAST (its name sorts last) and costs ~170 s, mostly CPU oracle time: every test first checks the suite's
-clock and skips itself when the session has already run longer than IEF_GPU_SUITE_BUDGET seconds (default 560; the whole
-`-m gpu` suite takes ~570 s on the GPU box), so a slow box ends with skips, not with a kill at the driver's time limit.
+clock and skips itself when the session has already run longer than IEF_GPU_SUITE_BUDGET seconds (default 540; on the GPU
+box the last of them starts at ~525 s and the whole `-m gpu` suite takes ~565 s), so a slow box ends with skips, not with a
+kill at a driver's time limit.
 """
 import gc
 import os
@@ -25,9 +27,7 @@ pytestmark = pytest.mark.gpu
 
 from ief_amd import config  # noqa: E402
 from ief_amd.pipeline import StableDiffusionPipeline  # noqa: E402
-from ief_amd.p2p.model.attention_base import AttentionStore  # noqa: E402
 from ief_amd.p2p.model.attention_control import AttentionRefine  # noqa: E402
-from ief_amd.p2p.model.ptp_utils import LocalBlend  # noqa: E402
 from ief_amd.p2p.model.register import register_attention_control, unregister_attention_control  # noqa: E402
 from oracle import p2p_ref, unet_ref  # noqa: E402
 
@@ -39,7 +39,7 @@ FWD_TOL = 5e-3
 @pytest.fixture(autouse=True)
 def _suite_budget():
     from conftest import suite_seconds
-    budget = float(os.environ.get("IEF_GPU_SUITE_BUDGET", "560"))
+    budget = float(os.environ.get("IEF_GPU_SUITE_BUDGET", "540"))
     if suite_seconds() > budget:
         pytest.skip(f"suite time budget ({budget:.0f} s) used up before this full-size oracle comparison")
 
@@ -104,67 +104,52 @@ def test_sd15_p2p_refine_step_b4_fused_vs_oracle(sd15, step):
     assert effect > 10 * e, "the control must change the output by far more than the kernel error"
 
 
-def test_sd15_attention_store_and_local_blend_on_hip_maps(sd15):
-    """AttentionStore (`attention_base.py:57-91`) fed by the generic HIP path (`ief_attn_probs_f16` maps handed to the
-    Python controller), two steps, against the oracle's materialised fp32 maps; then LocalBlend (`ptp_utils.py:20-32`) on
-    the HIP-produced store against LocalBlend on the oracle's store."""
+def test_sd15_1024px_forward_b1(sd15):
+    """the SD1.5-shaped net on 128x128 latents (1024x1024 px, north_star's second latent size): N = 16384 self-attention at
+    d = 40 inside the whole UNet"""
     cfg = config.SD15
-    x, ctx = _p2p_batch(cfg, seed=7)
-    st = AttentionStore(False)
-    register_attention_control(sd15, st)                 # not lowerable: generic path
-    assert sd15.unet._plan is None
-    # two controller steps on the SAME (latents, t): the store must accumulate two HIP-produced maps per slot and average
-    # them back to the oracle's single map (one ~17 s oracle pass instead of two)
-    for _ in range(2):
-        sd15.unet(x.to(DEV), 981, encoder_hidden_states=ctx.to(DEV))
-    rc = p2p_ref.P2PControlRef(mode="empty", num_prompts=2, store={})
-    rc.num_att_layers = 32
+    x, ctx = _inputs(cfg, 1, seed=17, hw=128)
+    ctx = ctx * 0.1
+    eps = sd15.unet(x.to(DEV), 481, encoder_hidden_states=ctx.to(DEV))["sample"]
     with torch.no_grad():
-        unet_ref.unet_forward(sd15._state_dict, cfg, x, torch.tensor(981), ctx, hook=rc)
-    ref_sum = {k: [m * 2 for m in v] for k, v in rc.store.items()}
-    assert st.cur_step == 2 and st.cur_att_layer == 0
-    unregister_attention_control(sd15, st)
-    avg = st.get_average_attention()
-    # SD1.5 at 64x64 latents: maps with N <= 1024 = the 32x32, 16x16 and 8x8 levels
-    assert {k: len(v) for k, v in avg.items()} == {"down_cross": 4, "mid_cross": 1, "up_cross": 6,
-                                                   "down_self": 4, "mid_self": 1, "up_self": 6}
-    worst = 0.0
-    for key, maps in avg.items():
-        for i, m in enumerate(maps):
-            r = ref_sum[key][i] / 2
-            assert m.shape == r.shape and m.shape[0] == 16            # cond half: 2 prompts x 8 heads
-            worst = max(worst, (m.float().cpu() - r).abs().max().item())
-    print(f"AttentionStore on HIP maps: max |avg map - oracle| = {worst:.2e}")
-    # fp16 maps in [0, 1]: 2.4e-4 per stored value, 4.9e-4 when two are summed in fp16 (values up to 2), halved again by the
-    # average, plus the kernel's own ~4e-4: measured 8.8e-4
-    assert worst < 2e-3
-    lb = LocalBlend(sd15.tokenizer, PROMPTS, [["house"], ["fall"]], device=DEV)
-    x_t = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(7))
-    got = lb(x_t.to(DEV), {k: [m.float() for m in v] for k, v in avg.items()}).cpu()
-    lb_ref = LocalBlend(sd15.tokenizer, PROMPTS, [["house"], ["fall"]], device=torch.device("cpu"))
-    want = lb_ref(x_t, {k: [m / 2 for m in v] for k, v in ref_sum.items()})
-    same = (got == want).float().mean().item()
-    blended = (want != x_t[:1]).any(1).float().mean().item()
-    print(f"LocalBlend on HIP maps: {same:.4f} of the elements identical to the oracle's (mask covers {blended:.2f} of the pixels)")
-    assert torch.equal(got[0], want[0]) and same > 0.995 and 0.0 < blended < 1.0
+        ref = unet_ref.unet_forward(sd15._state_dict, cfg, x, torch.tensor(481), ctx)
+    e = rel_err(eps, ref)
+    print(f"sd15 B=1 1024^2 (128x128 latents): rel err {e:.3e}")
+    assert e < FWD_TOL
 
 
-def test_sd21_full_size_forward_b1():
-    """SD2.1 shape family at 768x768 (BASELINE.json configs[3]): 96x96 latents -> N = 9216 self-attention at d = 64,
-    OpenCLIP context 1024, linear projections"""
+def test_sd21_full_size_pnp_injected_forward_b4():
+    """BASELINE.json configs[3]: Plug-and-Play on the SD2.1 shape family at 768x768 — 96x96 latents (N = 9216 self-attention
+    at d = 64), OpenCLIP context 1024, linear projections — one forward at the sampler's batch 4 with BOTH injections active
+    (self-attention Q / K of decoder blocks 4-11 and the conv feature of `up_blocks[1].resnets[1]` taken from the source
+    rows, `/root/reference/pnp/model/register.py:45-52,161-166`) against the oracle's hooks"""
+    from ief_amd.pnp.model.register import (register_attention_control_efficient, register_conv_control_efficient, register_time,
+                                            unregister_attention_control_efficient, unregister_conv_control_efficient)
+    from oracle import pnp_ref
     cfg = config.SD21
     pipe = StableDiffusionPipeline.from_pretrained("synthetic:sd21", keep_state_dict=True)
-    x, ctx = _inputs(cfg, 1, seed=11)
+    pipe.scheduler.set_timesteps(50)
+    x, ctx = _inputs(cfg, 4, seed=11)
     ctx = ctx * 0.1
-    eps = pipe.unet(x.to(DEV), 481, encoder_hidden_states=ctx.to(DEV))["sample"]
+    ts = pipe.scheduler.timesteps
+    t = int(ts[0])
+    register_attention_control_efficient(pipe, ts[:25])
+    register_conv_control_efficient(pipe, ts[:40])
+    try:
+        register_time(pipe, t)
+        got = pipe.unet(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
+    finally:
+        unregister_attention_control_efficient(pipe)
+        unregister_conv_control_efficient(pipe)
+    plain = pipe.unet(x.to(DEV), t, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
     with torch.no_grad():
-        ref = unet_ref.unet_forward(pipe._state_dict, cfg, x, torch.tensor(481), ctx)
-    e = rel_err(eps, ref)
-    print(f"sd21 B=1 768^2 (96x96 latents): rel err {e:.3e}")
+        ref = pnp_ref.pnp_forward(pipe._state_dict, cfg, x, t, ctx, True, True)
+    e, moved = rel_err(got, ref), rel_err(plain, ref)
+    print(f"sd21 B=4 768^2 (96x96 latents) PnP-injected forward: rel err {e:.3e}; the injection moves eps by {moved:.3e}")
     del pipe
     gc.collect()
     torch.cuda.empty_cache()
-    assert e < FWD_TOL
+    assert e < FWD_TOL and moved > 10 * e
 
 
 def test_sdxl_full_size_forward_b1():
@@ -186,18 +171,4 @@ def test_sdxl_full_size_forward_b1():
     del pipe
     gc.collect()
     torch.cuda.empty_cache()
-    assert e < FWD_TOL
-
-
-def test_sd15_1024px_forward_b1(sd15):
-    """the SD1.5-shaped net on 128x128 latents (1024x1024 px, north_star's second latent size): N = 16384 self-attention at
-    d = 40 inside the whole UNet"""
-    cfg = config.SD15
-    x, ctx = _inputs(cfg, 1, seed=17, hw=128)
-    ctx = ctx * 0.1
-    eps = sd15.unet(x.to(DEV), 481, encoder_hidden_states=ctx.to(DEV))["sample"]
-    with torch.no_grad():
-        ref = unet_ref.unet_forward(sd15._state_dict, cfg, x, torch.tensor(481), ctx)
-    e = rel_err(eps, ref)
-    print(f"sd15 B=1 1024^2 (128x128 latents): rel err {e:.3e}")
     assert e < FWD_TOL
