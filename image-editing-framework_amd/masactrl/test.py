@@ -21,7 +21,7 @@ _mod = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_mod)          # THIS folder's edit_real.py (p2p/ has one of the same name on sys.path)
 edit_one, pick = _mod.edit_one, _mod.pick
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
-from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
+from ief_amd.p2p.utils.save_image import PngWriter  # noqa: E402
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
 
@@ -54,6 +54,7 @@ def main(argv=None):
         for category in CATEGORIES:
             items += PIE(args.dataset_path, None, category=category).items
     mine = list(range(rank, len(items), world))
+    writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in mine:
@@ -63,9 +64,10 @@ def main(argv=None):
         if not args.no_save:
             out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
             os.makedirs(out_path, exist_ok=True)
-            original.save(os.path.join(out_path, "source.png"))
-            save_img(images[0], os.path.join(out_path, "inversion.png"))
-            save_img(images[1], os.path.join(out_path, "edit.png"))
+            writer.save_pil(original, os.path.join(out_path, "source.png"))
+            writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+            writer.save_img(images[1], os.path.join(out_path, "edit.png"))
+    writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

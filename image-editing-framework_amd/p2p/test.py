@@ -34,7 +34,7 @@ from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl
 from ief_amd.p2p.inversion.nti import NTI, NTI_XL
 from ief_amd.p2p.model.sd_utils import P2P, P2P_NTI, P2P_XL, P2P_XL_NTI
-from ief_amd.p2p.utils.save_image import save_img
+from ief_amd.p2p.utils.save_image import PngWriter
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
 
@@ -159,28 +159,20 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
 
-    # PNG encoding (zlib, ~30 ms per 512x512 image, three files per item) runs on host threads so the GPU loop never waits
-    # for it (`/root/reference/p2p/utils/save_image.py:6-14` writes synchronously between two edits)
-    from concurrent.futures import ThreadPoolExecutor
-    writers = ThreadPoolExecutor(max_workers=2)
-    pending = []
-
-    def write(image_path, original, images):
-        out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
-        os.makedirs(out_path, exist_ok=True)
-        original.save(os.path.join(out_path, "source.png"))
-        save_img(images[0], os.path.join(out_path, "inversion.png"))
-        save_img(images[1], os.path.join(out_path, "edit.png"))
+    writer = PngWriter()          # encodes / writes on host threads: the GPU loop never waits for a file
 
     def save(image_path, original, images):
-        if not args.no_save:
-            pending.append(writers.submit(write, image_path, original, images))
+        if args.no_save:
+            return
+        out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+        os.makedirs(out_path, exist_ok=True)
+        writer.save_pil(original, os.path.join(out_path, "source.png"))
+        writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+        writer.save_img(images[1], os.path.join(out_path, "edit.png"))
 
     run_items(pipe, editor, invertor, [items[i] for i in mine], size, device, args.inversion_type, args.invert_batch,
               args.in_flight, save)
-    for f in pending:
-        f.result()                # re-raises a writer's exception; the timing below includes the last files
-    writers.shutdown()
+    writer.close()                # the timing below includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

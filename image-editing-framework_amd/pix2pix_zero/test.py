@@ -22,7 +22,7 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
 from ief_amd.p2p.inversion.nti import NTI, NTI_XL_5e2 as NTI_XL  # noqa: E402  (this folder's copy: lr 5e-2)
-from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
+from ief_amd.p2p.utils.save_image import PngWriter  # noqa: E402
 from ief_amd.pix2pix_zero.model.sd_utils import P2P_Zero, P2P_Zero_NTI, P2P_Zero_XL, P2P_Zero_XL_NTI  # noqa: E402
 
 CATEGORIES = [0, 1, 2, 3, 4, 6, 7, 8, 9]
@@ -69,6 +69,7 @@ def main(argv=None):
             items += PIE(args.dataset_path, None, category=category).items
     mine = list(range(rank, len(items), world))
     bs = max(1, args.invert_batch)
+    writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c0 in range(0, len(mine), bs):
@@ -92,9 +93,10 @@ def main(argv=None):
             if not args.no_save:
                 out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
                 os.makedirs(out_path, exist_ok=True)
-                originals[j].save(os.path.join(out_path, "source.png"))
-                save_img(image_source, os.path.join(out_path, "inversion.png"))
-                save_img(image_edit, os.path.join(out_path, "edit.png"))
+                writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
+                writer.save_img(image_source, os.path.join(out_path, "inversion.png"))
+                writer.save_img(image_edit, os.path.join(out_path, "edit.png"))
+    writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

@@ -20,7 +20,7 @@ from _bootstrap import load_pipe, seed_everything  # noqa: E402
 
 from ief_amd.p2p.dataset.pie import PIE, SyntheticPIE  # noqa: E402
 from ief_amd.p2p.inversion.ddim import ddim_inversion, ddim_inversion_xl  # noqa: E402
-from ief_amd.p2p.utils.save_image import save_img  # noqa: E402
+from ief_amd.p2p.utils.save_image import PngWriter  # noqa: E402
 from ief_amd.p2p.inversion.nti import NTI, NTI_XL_5e2 as NTI_XL  # noqa: E402  (this folder's copy: lr 5e-2)
 from ief_amd.pnp.model.sd_utils import PnP, PnP_NTI, PnP_XL, PnP_XL_NTI  # noqa: E402
 
@@ -74,6 +74,7 @@ def main(argv=None):
         if xl:
             raise NotImplementedError("--in_flight on the SDXL family: run the reference's per-image order")
         bs = max(bs, E)
+    writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c0 in range(0, len(mine), bs):
@@ -94,9 +95,9 @@ def main(argv=None):
                     if not args.no_save:
                         out_path = os.path.join(args.exp_path, os.path.relpath(chunk[j][0].split(".")[0], root))
                         os.makedirs(out_path, exist_ok=True)
-                        originals[j].save(os.path.join(out_path, "source.png"))
-                        save_img(images[0], os.path.join(out_path, "inversion.png"))
-                        save_img(images[1], os.path.join(out_path, "edit.png"))
+                        writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
+                        writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+                        writer.save_img(images[1], os.path.join(out_path, "edit.png"))
             continue
         for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
             x_T = latents[-1][j:j + 1].clone()
@@ -113,9 +114,10 @@ def main(argv=None):
             if not args.no_save:
                 out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
                 os.makedirs(out_path, exist_ok=True)
-                originals[j].save(os.path.join(out_path, "source.png"))
-                save_img(images[0], os.path.join(out_path, "inversion.png"))
-                save_img(images[1], os.path.join(out_path, "edit.png"))
+                writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
+                writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+                writer.save_img(images[1], os.path.join(out_path, "edit.png"))
+    writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)
