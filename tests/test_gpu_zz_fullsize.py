@@ -13,9 +13,9 @@ Stated tolerance: max |eps - eps_oracle| <= 5e-3 * max |eps_oracle| for one forw
 batch-4 forward on the GPU box's host cores.
 
 This module runs LAST (its name sorts last) and costs ~170 s, mostly CPU oracle time: every test first checks the suite's
-clock and skips itself when the session has already run longer than IEF_GPU_SUITE_BUDGET seconds (default 540; on the GPU
-box the last of them starts at ~525 s and the whole `-m gpu` suite takes ~565 s), so a slow box ends with skips, not with a
-kill at a driver's time limit.
+clock and skips itself when the session has already run longer than IEF_GPU_SUITE_BUDGET seconds (default 1000: the round-end
+driver gives the GPU tier 1500 s, `GPUTEST_r01.json: run.timeout_s`; the whole `-m gpu` suite takes 560-620 s on the GPU box),
+so a pathologically slow box ends with skips, not with a kill at the driver's time limit.
 """
 import gc
 import os
@@ -39,7 +39,7 @@ FWD_TOL = 5e-3
 @pytest.fixture(autouse=True)
 def _suite_budget():
     from conftest import suite_seconds
-    budget = float(os.environ.get("IEF_GPU_SUITE_BUDGET", "540"))
+    budget = float(os.environ.get("IEF_GPU_SUITE_BUDGET", "1000"))
     if suite_seconds() > budget:
         pytest.skip(f"suite time budget ({budget:.0f} s) used up before this full-size oracle comparison")
 
