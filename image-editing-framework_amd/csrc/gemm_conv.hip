@@ -574,6 +574,325 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IefGemmParam
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with the input tile RESIDENT in LDS across the nine taps
+// ------------------------------------------------------------------------------------------
+// The implicit GEMM above re-stages the A operand once per tap: nine LDS-DMA passes over (nearly) the same pixels.
+// Measured on it: the K loop runs at the rate its LDS-DMA pieces can be issued and landed (36 one-KiB pieces per
+// 128x160x64 K tile; pointing them at one L1-hot page changes little, removing them takes a third off), so the
+// lever is FEWER PIECES PER FLOP, not a smarter pipeline.  Here a workgroup owns BM consecutive output pixels
+// m0 .. m0+BM-1 of the flattened [B*H*W] pixel axis and, per 64-channel block, stages the pixel range
+// m0-(W+1) .. m0+BM+W ("super-tile", BM + 2W + 2 rows of 128 B) ONCE; tap (ky, kx) of output row r is then super-tile
+// row r + ky*W + kx, and lanes whose tap falls outside the image (left / right / top / bottom edge) read a zero row
+// instead.  The loop nest is channel block (outer) x tap (inner); only the weight tile changes per tap.  With
+// BM = 256, BN = 80 a K tile costs 10 weight pieces + 5.4 input pieces instead of 20 + 16 for the same 2.6 MFLOP.
+// The M tile stays a contiguous range of pixels, so the epilogue, split-K slabs and GroupNorm column statistics
+// are exactly those of igemm_f16_kernel.
+//
+// Pipeline: weight tiles in a 4-slot ring, three steps ahead; the next channel block's super-tile (double buffered)
+// is fetched one piece per wave per step during taps 0..6 of the current block.  Each wave counts the LDS-DMA
+// instructions it issued in the last two steps and waits with vmcnt(that count): everything older — this step's
+// weight tile and, at tap 0, the whole super-tile — has then landed; the s_barrier publishes it to the other waves.
+template <int N>
+struct IntTag { static constexpr int value = N; };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le(int n) {   // n wave-uniform; waits until at most min(n, N) LDS-DMA are in flight
+    if constexpr (N == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (n >= N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+        else wait_vmcnt_le<N - 1>(n);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(const IefGemmParams p) {
+    constexpr int BK = 64;
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    constexpr int WMAX = 64;                                    // widest image row the super-tile is sized for
+    constexpr int NPA = (BM + 2 * WMAX + 2 + 7) / 8;            // super-tile pieces (8 rows x 128 B each) at that width
+    constexpr int PPW = (NPA + NW - 1) / NW;                    // super-tile pieces per wave
+    constexpr int ABUF = ((NPA + 1) / 2) * 2 * 1024;            // bytes per super-tile buffer
+    constexpr int NPB = BN / 8, BPW = (NPB + NW - 1) / NW;      // weight-tile pieces, per wave
+    constexpr int NSB = 5, BBUF = NPB * 1024;                   // weight ring
+    constexpr int BOFF = 2 * ABUF, ZOFF = BOFF + NSB * BBUF;    // ZOFF: 128 zero bytes, what an out-of-image tap reads
+    constexpr int LDS_BYTES = ZOFF + 128;
+    constexpr int LDS_N = BN + 4;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 64 == 0 && BN % 8 == 0, "tile");
+    static_assert(LDS_BYTES <= 160 * 1024 && 64 * LDS_N * 4 <= ABUF, "LDS");
+    __shared__ __attribute__((aligned(128))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    const int W = p.Wd, H = p.H;
+    const int Ctot = p.C1 + p.C2;
+    const char* __restrict__ zp = (const char*)p.zeros;
+
+    // channel blocks of this K slice
+    const int ncb = Ctot / BK;
+    int cb_lo = 0, cb_hi = ncb;
+    if (p.splits > 1) {
+        const int per = (ncb + p.splits - 1) / p.splits;
+        cb_lo = min(ncb, (int)blockIdx.y * per);
+        cb_hi = min(ncb, cb_lo + per);
+    }
+    const int nsteps = (cb_hi - cb_lo) * 9;
+
+    if (tid < 32) ((float*)(smem + ZOFF))[tid] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the first raw s_barrier publishes it
+
+    // ---- LDS images: rows of 128 B (64 channels); row r keeps 16-B chunk c in slot c ^ (r & 6).  That swizzle is free of
+    // bank conflicts for ds_read_b128 fragment reads of 16 CONSECUTIVE rows starting at ANY row (the tap shift moves the
+    // start), which (r >> 1) & 7 of igemm_f16_kernel is only for starts that are multiples of 4.  It is applied to the
+    // SOURCE address of the LDS-DMA (the LDS image of a wave-instruction is lane-linear): lane -> (row 8q + lane/8, slot
+    // lane%8) of piece q fetches chunk slot ^ (row & 6) = (lane & 7) ^ ((lane >> 3) & 6), the same for every piece.
+    const unsigned st_chunk = (unsigned)(((lane & 7) ^ ((lane >> 3) & 6)) * 16);
+    // LDS-DMA schedule, the same in every step so that the vmcnt counts are compile-time constants:
+    //   every wave      : weight piece `wave` of tile t+4; during taps 0..5 super-tile piece wave + NW*tap of the next block
+    //   waves < XB only : weight piece NW + wave; at tap 0 also super-tile piece wave + 6 NW
+    // (XB = NPB - NW = 2 waves; 6 NW + XB = 50 pieces >= the 49 a 64-pixel row needs).  What has no real source — a piece past
+    // the super-tile of a narrower image, a tile past the end of the K slice, the block after the last — is fetched from the
+    // zero page all the same: an L1-hot kilobyte costs less than a per-wave count.
+    constexpr int XB = NPB - NW;
+    static_assert(XB >= 0 && XB <= NW && BPW <= 2 && 6 * NW + XB >= NPA && (6 * NW + XB) * 1024 <= ABUF, "LDS-DMA schedule");
+    const bool xw = wave < XB;
+    const int a_ms0 = m0 - (W + 1) + 8 * wave + (lane >> 3);          // pixel fetched for super-tile piece wave + NW*j: + 8 NW j
+    // source of the NEXT channel block's super-tile (set per block)
+    const char* an_src = zp; unsigned an_cs = 0, an_c0 = 0; bool an_on = false;
+    auto set_next_block = [&](int cb, bool on) {
+        const bool first = cb * BK < p.C1;
+        an_src = (const char*)(first ? p.A : p.A2);
+        an_cs = (unsigned)(first ? p.C1 : p.C2);
+        an_c0 = (unsigned)(first ? cb * BK : cb * BK - p.C1);
+        an_on = on;
+    };
+    auto issue_a = [&](int j, int buf_off) {              // super-tile piece wave + NW j of the next block
+        const int ms = a_ms0 + 8 * NW * j;
+        const bool ok = an_on && (unsigned)ms < (unsigned)p.M;
+        const char* g = ok ? an_src + ((unsigned long long)((unsigned)ms * an_cs + an_c0) * 2ull + st_chunk) : zp;
+        glds16(g, (half_t*)(smem + buf_off + (wave + NW * j) * 1024));
+    };
+    // weight pieces: rows 8 wave + lane/8 (and 8 (NW + wave) + lane/8 for waves < XB) of the N tile
+    unsigned w_off[2];
+    bool w_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + 8 * (wave + NW * j) + (lane >> 3);
+        w_ok[j] = n < p.N;
+        w_off[j] = (unsigned)n * (unsigned)p.K * 2u + st_chunk;
+    }
+    auto issue_b = [&](int cb, int tap, bool on, int slot_off) {   // weight tile of (channel block, tap) into the ring slot at slot_off
+        const unsigned k0 = (unsigned)(tap * Ctot + cb * BK) * 2u;
+        const char* g0 = (w_ok[0] && on) ? (const char*)p.W + ((unsigned long long)w_off[0] + k0) : zp;
+        glds16(g0, (half_t*)(smem + BOFF + slot_off + wave * 1024));
+        if (xw) {
+            const char* g1 = (w_ok[1] && on) ? (const char*)p.W + ((unsigned long long)w_off[1] + k0) : zp;
+            glds16(g1, (half_t*)(smem + BOFF + slot_off + (NW + wave) * 1024));
+        }
+    };
+    // LDS-DMA instructions a wave issues in the step of tap `tap`
+    auto n_issued = [](int tap, bool x) constexpr -> int { return 1 + (x ? 1 : 0) + (tap < 6 ? 1 : 0) + (x && tap == 0 ? 1 : 0); };
+
+    // ---- fragment addressing
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_row[TM];
+    unsigned a_edge[TM];                 // bit 0: x == 0, 1: x == W-1, 2: y == 0, 3: y == H-1, 4: row past M
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wr * WM + i * 16 + fr, m = m0 + r;
+        const int x = m % W, y = (m / W) % H;
+        a_row[i] = r;
+        a_edge[i] = (x == 0 ? 1u : 0u) | (x == W - 1 ? 2u : 0u) | (y == 0 ? 4u : 0u) | (y == H - 1 ? 8u : 0u) | (m >= p.M ? 16u : 0u);
+    }
+    int b_off[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wc * WN + j * 16 + fr;
+        b_off[j] = BOFF + row * 128 + ((fq ^ (row & 6)) << 4);
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One K tile = two k-steps of 32 channels (16-B chunks fq and fq + 4 of a row: LDS addresses 64 B apart).
+    // Registers hold ONE set of fragments per k-step: a0/b0 (k-step 0) and a1/b1 (k-step 1).
+    half8 a0[TM], a1[TM], b0[TN], b1[TN];
+    auto a_addr = [&](int i, int abuf, int ky, int kx) -> int {
+        const unsigned tmask = 16u | (kx == 0 ? 1u : 0u) | (kx == 2 ? 2u : 0u) | (ky == 0 ? 4u : 0u) | (ky == 2 ? 8u : 0u);
+        const int sr = a_row[i] + ky * W + kx;
+        const int ad = abuf + sr * 128 + ((fq ^ (sr & 6)) << 4);
+        return (a_edge[i] & tmask) ? ZOFF : ad;
+    };
+    auto mma = [&](const half8 (&af)[TM], const half8 (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
+    // Step t = (channel block, tap).  Its k-step-0 fragments were read during step t-1; the step itself is
+    //     wait + barrier | LDS-DMA issues | read k-step 1 of t  || MFMAs of k-step 0 | read k-step 0 of t+1 || MFMAs of k-step 1
+    // so every fragment read has ten MFMAs' time to land.  LDS-DMA groups: group g = what a wave issues in step g = weight
+    // tile g+4 into ring slot (g+4) % 5 and, during taps 0..5, pieces of the next channel block's super-tile (prologue:
+    // g = -4 super-tile 0 + weight 0, g = -3 .. -1 weights 1 .. 3).  The wait of step t leaves groups t-1 and t-2 in flight:
+    // weight t+1 (group t-3) and, at tap 8, the next super-tile (groups up to tap 5) have landed.  The barrier publishes them
+    // and says every wave has finished the reads of step t-1: ring slot (t-1) % 5 = (t+4) % 5 and, at tap 0, the other
+    // super-tile buffer are free.
+    if (nsteps > 0) {
+        set_next_block(cb_lo, true);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) issue_a(j, 0);
+        if (xw) issue_a(6, 0);
+        issue_b(cb_lo, 0, true, 0);
+        issue_b(cb_lo, 1, true, BBUF);
+        issue_b(cb_lo, 2, true, 2 * BBUF);
+        issue_b(cb_lo, 3, true, 3 * BBUF);
+        if (xw) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = *(const half8*)(smem + a_addr(i, 0, 0, 0));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = *(const half8*)(smem + b_off[j]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    int bs_prev = 4 * BBUF, bs = 0, bs_next = BBUF;     // ring slots (byte offsets) of steps t-1 (= t+4), t, t+1
+    for (int cbi = 0; cbi < cb_hi - cb_lo; ++cbi) {
+        const int cb = cb_lo + cbi;
+        const int abuf = (cbi & 1) * ABUF, abuf_n = ABUF - abuf;
+        set_next_block(min(cb + 1, cb_hi - 1), cb + 1 < cb_hi);
+        const int steps_left = nsteps - cbi * 9;          // weight tile t+4 exists while tap + 4 < steps_left
+        auto one_step = [&](auto tap_tag) {
+            constexpr int tap = decltype(tap_tag)::value;
+            constexpr int ky = tap / 3, kx = tap - ky * 3;
+            {   // groups t-1 and t-2 stay in flight
+                constexpr int p1 = (tap + 8) % 9, p2 = (tap + 7) % 9;
+                if (xw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued(p1, true) + n_issued(p2, true)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued(p1, false) + n_issued(p2, false)) : "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");
+            if (tap < 6) {
+                issue_a(tap, abuf_n);
+                if (tap == 0 && xw) issue_a(6, abuf_n);
+            }
+            issue_b(cb + (tap + 4) / 9, (tap + 4) % 9, tap + 4 < steps_left, bs_prev);
+            __builtin_amdgcn_sched_barrier(0);
+            // k-step 1 of this step lands while k-step 0 is multiplied
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = *(const half8*)(smem + (a_addr(i, abuf, ky, kx) ^ 64));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = *(const half8*)(smem + bs + (b_off[j] ^ 64));
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            // k-step 0 of the next step (next tap, or tap 0 of the next channel block) lands while k-step 1 is multiplied
+            {
+                const int nky = tap == 8 ? 0 : (tap + 1) / 3, nkx = tap == 8 ? 0 : (tap + 1) % 3;
+                const int ab = tap == 8 ? abuf_n : abuf;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[i] = *(const half8*)(smem + a_addr(i, ab, nky, nkx));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b0[j] = *(const half8*)(smem + bs_next + b_off[j]);
+            }
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), said with the builtin: the compiler then knows nothing is pending at the loop head
+            __builtin_amdgcn_sched_barrier(0);
+            bs_prev = bs; bs = bs_next; bs_next = bs_next == (NSB - 1) * BBUF ? 0 : bs_next + BBUF;
+        };
+        one_step(IntTag<0>{}); one_step(IntTag<1>{}); one_step(IntTag<2>{});
+        one_step(IntTag<3>{}); one_step(IntTag<4>{}); one_step(IntTag<5>{});
+        one_step(IntTag<6>{}); one_step(IntTag<7>{}); one_step(IntTag<8>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // all fragment reads done, nothing in flight: the super-tile buffer becomes the epilogue's scratch
+
+    // ---------------- epilogue through LDS, 64 output rows per pass (as igemm_f16_kernel, without the linear-only parts)
+    constexpr int NPASS = BM / 64, CH = BN / 8;
+    float* stage = (float*)smem;
+    half_t* __restrict__ Out = p.Out;
+    float ccs = 0.f, ccq = 0.f;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if ((wr * WM) / 64 == pass) {
+            const int rb0 = wr * WM - pass * 64;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[(rb0 + i * 16 + fq * 4 + r) * LDS_N + wc * WN + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+        for (int c = tid; c < 64 * CH; c += NT) {
+            const int row = c / CH, nc = c - row * CH;
+            const int m = m0 + pass * 64 + row, n = n0 + nc * 8;
+            float* sp = stage + row * LDS_N + nc * 8;
+            if (m < p.M && n < p.N) {
+                const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+                if (p.splits > 1) {
+                    float* w = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
+                    *(f32x4*)w = s0;
+                    *(f32x4*)(w + 4) = s1;
+                    continue;
+                }
+                float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                if (p.bias) {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (p.rowvec) {
+                    const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n;
+                    const f32x4 b0 = *(const f32x4*)rv, b1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (p.residual) {
+                    const half8 rs = *(const half8*)(p.residual + (long long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                }
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
+                *(half8*)(Out + (long long)m * p.ldo + n) = o;
+                if (p.cstat_out) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sp[e] = (float)o[e];
+                }
+            } else if (p.cstat_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sp[e] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (p.cstat_out && p.splits <= 1) {   // column sums over this pass's rows, fixed order: deterministic
+            if (tid < BN) {
+                for (int r = 0; r < 64; ++r) {
+                    const float v = stage[r * LDS_N + tid];
+                    ccs += v;
+                    ccq += v * v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (p.cstat_out && p.splits <= 1 && tid < BN && n0 + tid < p.N) {
+        float* co = p.cstat_out + ((long long)(m0 / BM) * p.N + n0 + tid) * 2;
+        co[0] = ccs; co[1] = ccq;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool CONV>
 static int launch_ns(const IefGemmParams& p, int tiles, int splits, int batch, hipStream_t st) {
     constexpr int NT = 64 * WAVES_M * WAVES_N, RP = NT / 8;
@@ -609,9 +928,37 @@ static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     return IEF_OK;
 }
 
+static void launch_splitk_reducer(const IefGemmParams& p, hipStream_t st) {
+    const long long total = (long long)p.M * (p.N / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(grid), dim3(256), 0, st, p);
+}
+
+// tile 14: conv3x3_halo_kernel<256, 80>; plain 3x3 / stride 1 / pad 1 convolutions on rows of at most 64 pixels
+static int launch_conv_halo(IefGemmParams p, hipStream_t st) {
+    if (p.stride != 1 || p.ups || p.pad_hi_only || p.CE1 || p.CE2 || p.Wd > 64 || p.Wd < 2 || p.H < 2) return IEF_ESHAPE;
+    if ((p.C1 + p.C2) % 64) return IEF_ESHAPE;
+    const int ncb = (p.C1 + p.C2) / 64;
+    if (p.splits > ncb) return IEF_ESHAPE;
+    if (p.cstat_out && p.splits > 1) return IEF_EINVAL;
+    p.cnt = nullptr;                                   // split-K slabs are always summed by the reducer launch here
+    constexpr int BM = 256, BN = 80;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int splits = p.splits > 1 ? p.splits : 1;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1>), dim3(tiles, splits, 1), dim3(512), 0, st, p);
+    IEF_LAUNCH_CHECK();
+    if (splits > 1) {
+        launch_splitk_reducer(p, st);
+        IEF_LAUNCH_CHECK();
+    }
+    return IEF_OK;
+}
+
 // tile ids (IefGemmParams.tile_hint); the host binding picks one per layer shape
 //   1: 128x128 (2x2 waves)   2: 64x128 (2x2)    3: 64x64 (2x2)     4: 128x64 (2x2)
 //   5: 64x160 (2x2)          6: 128x160 (2x2)   7: 128x160 (4x2)   8: 256x128 (4x2)   9: 128x128 (4x2)
+//   14: conv3x3_halo_kernel 256x80 (8x1), convolutions only (launch_conv_halo)
 template <bool CONV>
 static int dispatch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     switch (p.tile_hint) {
@@ -636,7 +983,7 @@ extern "C" int ief_gemm_tile_bm(int tile_hint) {
     switch (tile_hint) {
         case 1: case 4: case 6: case 7: case 9: return 128;
         case 2: case 3: case 5: return 64;
-        case 8: return 256;
+        case 8: case 14: return 256;
         default: return 0;
     }
 }
@@ -646,6 +993,7 @@ extern "C" int ief_gemm_tile_bn(int tile_hint) {
         case 1: case 2: case 8: case 9: return 128;
         case 3: case 4: return 64;
         case 5: case 6: case 7: return 160;
+        case 14: return 80;
         default: return 0;
     }
 }
@@ -711,5 +1059,6 @@ extern "C" int ief_conv3x3_f16(const IefGemmParams* pp, void* stream) {
     const int emax = p.CE1 > p.CE2 ? p.CE1 : p.CE2;
     if (in_pix * cmax * 2 >= (1ll << 32) || (long long)p.M * emax * 2 >= (1ll << 32)) return IEF_ESHAPE;
     p.strideA = p.strideW = p.strideO = p.strideR = 0;
+    if (p.tile_hint == 14) return launch_conv_halo(p, (hipStream_t)stream);
     return dispatch_igemm<true>(p, 1, (hipStream_t)stream);
 }

@@ -59,10 +59,10 @@ CONVS = [  # (B, H, W, C1, C2, Cout, stride, ups, count)
 ATTN = [(4, 8, 4096, 40, 5), (4, 8, 1024, 80, 5), (4, 8, 256, 160, 5), (4, 8, 64, 160, 1)]
 
 
-def sweep(fn_of_plan, M, N, K, iters):
+def sweep(fn_of_plan, M, N, K, iters, conv=False):
     """(us, tile, splits, stages) sorted, over the tile family x split-K x LDS ring depth"""
     res = []
-    for t, s, st in hip.candidate_plans(M, N, K):
+    for t, s, st in hip.candidate_plans(M, N, K, conv=conv):
         try:
             res.append((timeit(lambda: fn_of_plan(t, s, st), iters), t, s, st))
         except RuntimeError:
@@ -103,7 +103,7 @@ def run_conv(iters, do_sweep=False):
         tot += us * n
         line = f"{us:8.1f} {2.0 * M * Cout * K / us / 1e6:7.1f} {us * n:8.1f}  {(B, H, W, C1, C2, Cout, s, ups)} {hip.pick_plan(M, Cout, K, conv=True)}"
         if do_sweep:
-            r = sweep(lambda t, sp, st: hip.conv3x3(x, w, bias, x2=x2, stride=s, upsample=ups, tile_hint=t, splits=sp, stages=st), M, Cout, K, iters)
+            r = sweep(lambda t, sp, st: hip.conv3x3(x, w, bias, x2=x2, stride=s, upsample=ups, tile_hint=t, splits=sp, stages=st), M, Cout, K, iters, conv=True)
             tot_best += r[0][0] * n
             line += "  best: " + " ".join(f"{u:.1f}us@t{t}s{sp}r{st}" for u, t, sp, st in r[:4])
         print(line, flush=True)

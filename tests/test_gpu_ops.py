@@ -115,6 +115,40 @@ def test_conv3x3(B, H, W, C1, C2, Cout, stride, ups):
     close(out, ref0 + res.float(), 2e-3, 1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,splits", [
+    (2, 16, 16, 128, 64, 320, 1), (2, 16, 16, 128, 64, 320, 3), (1, 64, 64, 64, 0, 160, 1), (4, 8, 8, 128, 0, 80, 2),
+    (3, 10, 12, 64, 64, 96, 1), (4, 64, 64, 320, 0, 320, 1), (4, 32, 32, 640, 0, 640, 2), (1, 5, 2, 64, 0, 8, 1),
+])
+def test_conv3x3_halo_tile(B, H, W, C1, C2, Cout, splits):
+    """conv3x3_halo_kernel (tile 14: the input tile stays in LDS across the nine taps): image edges, tiles spanning
+    several images (8x8), M / N tails, channel concat, split-K over channel blocks, the widest row it is sized for"""
+    x = h16(B, H, W, C1, seed=1)
+    x2 = h16(B, H, W, C2, seed=2) if C2 else None
+    w = h16(Cout, 3, 3, C1 + C2, seed=3, scale=(9 * (C1 + C2)) ** -0.5)
+    bias = f32(Cout, seed=4, scale=0.1)
+    rv = f32(B, Cout, seed=5)
+    ref0 = _conv_ref(x, w, bias, 1, False, x2, rv)
+    res = h16(*ref0.shape, seed=6)
+    out = hip.conv3x3(dev(x), dev(w), dev(bias), x2=None if x2 is None else dev(x2), rowvec=dev(rv), residual=dev(res),
+                      tile_hint=14, splits=splits, stages=4)
+    close(out, ref0 + res.float(), 2e-3, 1e-3)
+    # same sums as the implicit-GEMM kernel up to the fp32 summation order
+    out7 = hip.conv3x3(dev(x), dev(w), dev(bias), x2=None if x2 is None else dev(x2), rowvec=dev(rv), residual=dev(res),
+                       tile_hint=7, splits=1, stages=2)
+    close(out, out7.float().cpu(), 1e-3, 1e-3)
+
+
+def test_conv3x3_halo_tile_rejects_what_it_does_not_cover():
+    x, w = h16(1, 16, 16, 64, seed=1), h16(64, 3, 3, 64, seed=2, scale=0.05)
+    with pytest.raises(RuntimeError):
+        hip.conv3x3(dev(x), dev(w), stride=2, tile_hint=14, stages=4)
+    with pytest.raises(RuntimeError):
+        hip.conv3x3(dev(x), dev(w), upsample=True, tile_hint=14, stages=4)
+    xw = h16(1, 2, 128, 64, seed=3)
+    with pytest.raises(RuntimeError):
+        hip.conv3x3(dev(xw), dev(w), tile_hint=14, stages=4)
+
+
 def test_conv_in_out():
     B, H, W = 2, 24, 16
     x = f32(B, 4, H, W, seed=1)
