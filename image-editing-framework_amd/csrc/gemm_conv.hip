@@ -607,14 +607,17 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {   // n wave-uniform; wait
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// VAR (schedule switches kept for A/B; measured on the SD1.5 batch-4 shapes, same box, interleaved rounds — 64x64x320 conv in us):
+//   bit 0: waves NW/2.. issue their LDS-DMA group at the END of the step            off 33.8  on 33.2
+//   bit 1: one lgkmcnt(0) BEFORE each half's reads instead of after its MFMAs        off 33.8  on 32.7   (both: 33.1, best on the concat shapes)
+//   bit 2: sched_group_barrier pinning "all reads, then all MFMAs" inside a half     on 34.2-34.9: worse, the compiler's own interleave stays
+template <int BM, int BN, int WAVES_M, int WAVES_N, int VAR = 3>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(const IefGemmParams p) {
     constexpr int BK = 64;
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int WMAX = 64;                                    // widest image row the super-tile is sized for
     constexpr int NPA = (BM + 2 * WMAX + 2 + 7) / 8;            // super-tile pieces (8 rows x 128 B each) at that width
-    constexpr int PPW = (NPA + NW - 1) / NW;                    // super-tile pieces per wave
     constexpr int ABUF = ((NPA + 1) / 2) * 2 * 1024;            // bytes per super-tile buffer
     constexpr int NPB = BN / 8, BPW = (NPB + NW - 1) / NW;      // weight-tile pieces, per wave
     constexpr int NSB = 5, BBUF = NPB * 1024;                   // weight ring
@@ -663,6 +666,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     constexpr int XB = NPB - NW;
     static_assert(XB >= 0 && XB <= NW && BPW <= 2 && 6 * NW + XB >= NPA && (6 * NW + XB) * 1024 <= ABUF, "LDS-DMA schedule");
     const bool xw = wave < XB;
+    const bool late = (VAR & 1) && wave >= NW / 2;
     const int a_ms0 = m0 - (W + 1) + 8 * wave + (lane >> 3);          // pixel fetched for super-tile piece wave + NW*j: + 8 NW j
     // source of the NEXT channel block's super-tile (set per block)
     const char* an_src = zp; unsigned an_cs = 0, an_c0 = 0; bool an_on = false;
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
         for (int i = 0; i < TM; ++i) a0[i] = *(const half8*)(smem + a_addr(i, 0, 0, 0));
 #pragma unroll
         for (int j = 0; j < TN; ++j) b0[j] = *(const half8*)(smem + b_off[j]);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if constexpr (!(VAR & 2)) __builtin_amdgcn_s_waitcnt(0xC07F);
     }
     int bs_prev = 4 * BBUF, bs = 0, bs_next = BBUF;     // ring slots (byte offsets) of steps t-1 (= t+4), t, t+1
     for (int cbi = 0; cbi < cb_hi - cb_lo; ++cbi) {
@@ -781,21 +785,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued(p1, false) + n_issued(p2, false)) : "memory");
             }
             asm volatile("s_barrier" ::: "memory");
-            if (tap < 6) {
-                issue_a(tap, abuf_n);
-                if (tap == 0 && xw) issue_a(6, abuf_n);
-            }
-            issue_b(cb + (tap + 4) / 9, (tap + 4) % 9, tap + 4 < steps_left, bs_prev);
+            auto issue_group = [&]() {
+                if (tap < 6) {
+                    issue_a(tap, abuf_n);
+                    if (tap == 0 && xw) issue_a(6, abuf_n);
+                }
+                issue_b(cb + (tap + 4) / 9, (tap + 4) % 9, tap + 4 < steps_left, bs_prev);
+            };
+            // the two waves of a SIMD (w, w + NW/2) would otherwise both spend the head of the step issuing LDS-DMA with the
+            // matrix pipe idle: the second half of the workgroup issues its group at the END of the step instead
+            if (!late) issue_group();
             __builtin_amdgcn_sched_barrier(0);
-            // k-step 1 of this step lands while k-step 0 is multiplied
+            // each half: the fragments it multiplies are back (one lgkmcnt(0), said with the builtin so that the compiler
+            // does not add its own — it would put that after the new reads and wait for them too), then the other
+            // k-step's reads go out, then ten MFMAs run while they land
+            if constexpr (VAR & 2) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = *(const half8*)(smem + (a_addr(i, abuf, ky, kx) ^ 64));
+            for (int i = 0; i < TM; ++i) a1[i] = *(const half8*)(smem + (a_addr(i, abuf, ky, kx) ^ 64));    // k-step 1 of this step
 #pragma unroll
             for (int j = 0; j < TN; ++j) b1[j] = *(const half8*)(smem + bs + (b_off[j] ^ 64));
             mma(a0, b0);
+            if constexpr (VAR & 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // k-step 0 of the next step (next tap, or tap 0 of the next channel block) lands while k-step 1 is multiplied
-            {
+            if constexpr (VAR & 2) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // k-step 0 of the next step (next tap, or tap 0 of the next channel block)
                 const int nky = tap == 8 ? 0 : (tap + 1) / 3, nkx = tap == 8 ? 0 : (tap + 1) % 3;
                 const int ab = tap == 8 ? abuf_n : abuf;
 #pragma unroll
@@ -804,9 +826,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
                 for (int j = 0; j < TN; ++j) b0[j] = *(const half8*)(smem + bs_next + b_off[j]);
             }
             mma(a1, b1);
+            if constexpr (VAR & 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), said with the builtin: the compiler then knows nothing is pending at the loop head
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(VAR & 2)) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (late) issue_group();
             bs_prev = bs; bs = bs_next; bs_next = bs_next == (NSB - 1) * BBUF ? 0 : bs_next + BBUF;
         };
         one_step(IntTag<0>{}); one_step(IntTag<1>{}); one_step(IntTag<2>{});

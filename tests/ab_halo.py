@@ -22,10 +22,10 @@ for B, H, W, C1, C2, Cout, sps in SHAPES:
     M, K = B * H * W, 9 * (C1 + C2)
     t, sp, st = hip.pick_plan(M, Cout, K, conv=True)
     arms = [(f"t{t}s{sp}r{st}", lambda: hip.conv3x3(x, w, bias, x2=x2, tile_hint=t, splits=sp, stages=st))]
-    for s in sps:
-        arms.append((f"halo s{s}", (lambda s_: (lambda: hip.conv3x3(x, w, bias, x2=x2, tile_hint=14, splits=s_, stages=4)))(s)))
+    for s_ in sps:
+        arms.append((f"halo s{s_}", (lambda q: (lambda: hip.conv3x3(x, w, bias, x2=x2, tile_hint=14, splits=q, stages=4)))(s_)))
     res = {n: [] for n, _ in arms}
     for rnd in range(4):                      # interleaved rounds, one process (guide rule 24)
         for n, f in arms:
             res[n].append(timeit(f, iters))
-    print(f"{(B, H, W, C1, C2, Cout)}: " + " | ".join(f"{n}: min {min(v):6.1f} med {sorted(v)[len(v) // 2]:6.1f} us ({2.0 * M * Cout * K / min(v) / 1e6:5.0f} TF/s)" for n, v in res.items()), flush=True)
+    print(f"{(B, H, W, C1, C2, Cout)}: " + " | ".join(f"{n}: {min(v):6.1f}/{sorted(v)[len(v) // 2]:6.1f}" for n, v in res.items()), flush=True)
