@@ -611,10 +611,16 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {   // n wave-uniform; wait
 //   bit 0: waves NW/2.. issue their LDS-DMA group at the END of the step            off 33.8  on 33.2
 //   bit 1: one lgkmcnt(0) BEFORE each half's reads instead of after its MFMAs        off 33.8  on 32.7   (both: 33.1, best on the concat shapes)
 //   bit 2: sched_group_barrier pinning "all reads, then all MFMAs" inside a half     on 34.2-34.9: worse, the compiler's own interleave stays
-template <int BM, int BN, int WAVES_M, int WAVES_N, int VAR = 3>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(const IefGemmParams p) {
+//   NL: loader waves.  NL = 0: every wave issues its share of the LDS-DMA (the schedule below).  NL = 4: waves NW .. NW+3 do
+//   nothing but issue LDS-DMA and count it (they take the vmcnt waits), the NW compute waves only read fragments and
+//   multiply.  Measured on the 64x64x320 convolution (ablation builds, us): whole kernel 34.4, without the LDS-DMA
+//   instructions 26.6, without the fragment reads 29.2, without either 23.1 — an LDS-DMA instruction costs a COMPUTE wave
+//   ~180 cycles of its in-order stream (address VALU queued behind MFMAs, M0 write, issue), a wave that does nothing else
+//   ~25 (guide: ldsdma-fill).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NL = 0, int VAR = 3>
+__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_kernel(const IefGemmParams p) {
     constexpr int BK = 64;
-    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * (NW + NL);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int WMAX = 64;                                    // widest image row the super-tile is sized for
     constexpr int NPA = (BM + 2 * WMAX + 2 + 7) / 8;            // super-tile pieces (8 rows x 128 B each) at that width
@@ -622,7 +628,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     constexpr int NPB = BN / 8, BPW = (NPB + NW - 1) / NW;      // weight-tile pieces, per wave
     constexpr int NSB = 5, BBUF = NPB * 1024;                   // weight ring
     constexpr int BOFF = 2 * ABUF, ZOFF = BOFF + NSB * BBUF;    // ZOFF: 128 zero bytes, what an out-of-image tap reads
-    constexpr int LDS_BYTES = ZOFF + 128;
+    constexpr int DUMP = ZOFF + 128;                            // NL > 0: 1 KiB where the loaders' filler pieces land
+    constexpr int LDS_BYTES = ZOFF + 128 + (NL > 0 ? 1024 : 0);
     constexpr int LDS_N = BN + 4;
     static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 64 == 0 && BN % 8 == 0, "tile");
     static_assert(LDS_BYTES <= 160 * 1024 && 64 * LDS_N * 4 <= ABUF, "LDS");
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     // the super-tile of a narrower image, a tile past the end of the K slice, the block after the last — is fetched from the
     // zero page all the same: an L1-hot kilobyte costs less than a per-wave count.
     constexpr int XB = NPB - NW;
-    static_assert(XB >= 0 && XB <= NW && BPW <= 2 && 6 * NW + XB >= NPA && (6 * NW + XB) * 1024 <= ABUF, "LDS-DMA schedule");
+    static_assert(NL > 0 || (XB >= 0 && XB <= NW && BPW <= 2 && 6 * NW + XB >= NPA && (6 * NW + XB) * 1024 <= ABUF), "LDS-DMA schedule");
     const bool xw = wave < XB;
     const bool late = (VAR & 1) && wave >= NW / 2;
     const int a_ms0 = m0 - (W + 1) + 8 * wave + (lane >> 3);          // pixel fetched for super-tile piece wave + NW*j: + 8 NW j
@@ -704,6 +711,78 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     // LDS-DMA instructions a wave issues in the step of tap `tap`
     auto n_issued = [](int tap, bool x) constexpr -> int { return 1 + (x ? 1 : 0) + (tap < 6 ? 1 : 0) + (x && tap == 0 ? 1 : 0); };
 
+    if constexpr (NL > 0) {
+        if (wave >= NW) {
+            // ---------------- loader waves: loader l issues, per step, three weight pieces (l, l + NL, l + 2 NL of tile t+4) and,
+            // during taps 0..5, three super-tile pieces of the next block (9 tap + l, + NL, + 2 NL); a piece that does not exist is
+            // fetched from the zero page into a scratch kilobyte, so every loader issues the same count and the vmcnt waits
+            // are constants.
+            static_assert(3 * NL >= NPB && 6 * 9 >= NPA && 3 * NL >= 9, "loader schedule");
+            const int l = wave - NW;
+            const int ms_lane = m0 - (W + 1) + (lane >> 3);
+            const char* an_src = zp; unsigned an_cs = 0, an_c0 = 0; bool an_on = false;
+            auto set_next_block = [&](int cb, bool on) {
+                const bool first = cb * BK < p.C1;
+                an_src = (const char*)(first ? p.A : p.A2);
+                an_cs = (unsigned)(first ? p.C1 : p.C2);
+                an_c0 = (unsigned)(first ? cb * BK : cb * BK - p.C1);
+                an_on = on;
+            };
+            auto issue_a = [&](int q, bool exists, int buf_off) {     // super-tile piece q of the next block (q wave-uniform)
+                const int ms = ms_lane + 8 * q;
+                const bool ok = exists && an_on && (unsigned)ms < (unsigned)p.M;
+                const char* g = ok ? an_src + ((unsigned long long)((unsigned)ms * an_cs + an_c0) * 2ull + st_chunk) : zp;
+                glds16(g, (half_t*)(smem + (exists ? buf_off + q * 1024 : DUMP)));
+            };
+            const unsigned w_lane = (unsigned)(n0 + (lane >> 3)) * (unsigned)p.K * 2u + st_chunk;
+            auto issue_b = [&](int cb, int tap, bool on, int slot_off) {
+                const unsigned k0 = (unsigned)(tap * Ctot + cb * BK) * 2u;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int q = l + NL * j;
+                    const bool exists = q < NPB;
+                    const bool ok = exists && on && n0 + 8 * q + (lane >> 3) < p.N;
+                    const char* g = ok ? (const char*)p.W + ((unsigned long long)w_lane + (unsigned long long)((unsigned)(8 * q) * (unsigned)p.K * 2u) + k0) : zp;
+                    glds16(g, (half_t*)(smem + (exists ? BOFF + slot_off + q * 1024 : DUMP)));
+                }
+            };
+            auto n_issued = [](int tap) constexpr -> int { return 3 + (tap < 6 ? 3 : 0); };
+            if (nsteps > 0) {
+                set_next_block(cb_lo, true);
+                for (int q = l; q < ABUF / 1024; q += NL) issue_a(q, true, 0);
+                issue_b(cb_lo, 0, true, 0);
+                issue_b(cb_lo, 1, true, BBUF);
+                issue_b(cb_lo, 2, true, 2 * BBUF);
+                issue_b(cb_lo, 3, true, 3 * BBUF);
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+            }
+            int bs_prev = 4 * BBUF, bs = 0, bs_next = BBUF;
+            for (int cbi = 0; cbi < cb_hi - cb_lo; ++cbi) {
+                const int cb = cb_lo + cbi;
+                const int abuf_n = ABUF - (cbi & 1) * ABUF;
+                set_next_block(min(cb + 1, cb_hi - 1), cb + 1 < cb_hi);
+                const int steps_left = nsteps - cbi * 9;
+                auto one_step = [&](auto tap_tag) {
+                    constexpr int tap = decltype(tap_tag)::value;
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued((tap + 8) % 9) + n_issued((tap + 7) % 9)) : "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    if constexpr (tap < 6) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int k = l + NL * j, q = 9 * tap + k;
+                            issue_a(q, k < 9 && q < ABUF / 1024, abuf_n);
+                        }
+                    }
+                    issue_b(cb + (tap + 4) / 9, (tap + 4) % 9, tap + 4 < steps_left, bs_prev);
+                    bs_prev = bs; bs = bs_next; bs_next = bs_next == (NSB - 1) * BBUF ? 0 : bs_next + BBUF;
+                };
+                one_step(IntTag<0>{}); one_step(IntTag<1>{}); one_step(IntTag<2>{});
+                one_step(IntTag<3>{}); one_step(IntTag<4>{}); one_step(IntTag<5>{});
+                one_step(IntTag<6>{}); one_step(IntTag<7>{}); one_step(IntTag<8>{});
+            }
+        }
+    }
     // ---- fragment addressing
     const int fr = lane & 15, fq = lane >> 4;
     int a_row[TM];
@@ -753,16 +832,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     // weight t+1 (group t-3) and, at tap 8, the next super-tile (groups up to tap 5) have landed.  The barrier publishes them
     // and says every wave has finished the reads of step t-1: ring slot (t-1) % 5 = (t+4) % 5 and, at tap 0, the other
     // super-tile buffer are free.
-    if (nsteps > 0) {
-        set_next_block(cb_lo, true);
+    const bool computes = NL == 0 || wave < NW;
+    if (nsteps > 0 && computes) {
+        if constexpr (NL == 0) {
+            set_next_block(cb_lo, true);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) issue_a(j, 0);
-        if (xw) issue_a(6, 0);
-        issue_b(cb_lo, 0, true, 0);
-        issue_b(cb_lo, 1, true, BBUF);
-        issue_b(cb_lo, 2, true, 2 * BBUF);
-        issue_b(cb_lo, 3, true, 3 * BBUF);
-        if (xw) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            for (int j = 0; j < 6; ++j) issue_a(j, 0);
+            if (xw) issue_a(6, 0);
+            issue_b(cb_lo, 0, true, 0);
+            issue_b(cb_lo, 1, true, BBUF);
+            issue_b(cb_lo, 2, true, 2 * BBUF);
+            issue_b(cb_lo, 3, true, 3 * BBUF);
+            if (xw) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
         asm volatile("s_barrier" ::: "memory");
 #pragma unroll
         for (int i = 0; i < TM; ++i) a0[i] = *(const half8*)(smem + a_addr(i, 0, 0, 0));
@@ -771,21 +853,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
         if constexpr (!(VAR & 2)) __builtin_amdgcn_s_waitcnt(0xC07F);
     }
     int bs_prev = 4 * BBUF, bs = 0, bs_next = BBUF;     // ring slots (byte offsets) of steps t-1 (= t+4), t, t+1
-    for (int cbi = 0; cbi < cb_hi - cb_lo; ++cbi) {
+    for (int cbi = 0; computes && cbi < cb_hi - cb_lo; ++cbi) {
         const int cb = cb_lo + cbi;
         const int abuf = (cbi & 1) * ABUF, abuf_n = ABUF - abuf;
-        set_next_block(min(cb + 1, cb_hi - 1), cb + 1 < cb_hi);
+        if constexpr (NL == 0) set_next_block(min(cb + 1, cb_hi - 1), cb + 1 < cb_hi);
         const int steps_left = nsteps - cbi * 9;          // weight tile t+4 exists while tap + 4 < steps_left
         auto one_step = [&](auto tap_tag) {
             constexpr int tap = decltype(tap_tag)::value;
             constexpr int ky = tap / 3, kx = tap - ky * 3;
-            {   // groups t-1 and t-2 stay in flight
+            if constexpr (NL == 0) {   // groups t-1 and t-2 stay in flight
                 constexpr int p1 = (tap + 8) % 9, p2 = (tap + 7) % 9;
                 if (xw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued(p1, true) + n_issued(p2, true)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued(p1, false) + n_issued(p2, false)) : "memory");
             }
             asm volatile("s_barrier" ::: "memory");
             auto issue_group = [&]() {
+                if constexpr (NL > 0) return;
                 if (tap < 6) {
                     issue_a(tap, abuf_n);
                     if (tap == 0 && xw) issue_a(6, abuf_n);
@@ -975,7 +1058,8 @@ static int launch_conv_halo(IefGemmParams p, hipStream_t st) {
     constexpr int BM = 256, BN = 80;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int splits = p.splits > 1 ? p.splits : 1;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1>), dim3(tiles, splits, 1), dim3(512), 0, st, p);
+    if (p.tile_hint == 15) hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1, 4>), dim3(tiles, splits, 1), dim3(768), 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1, 0>), dim3(tiles, splits, 1), dim3(512), 0, st, p);
     IEF_LAUNCH_CHECK();
     if (splits > 1) {
         launch_splitk_reducer(p, st);
@@ -987,7 +1071,7 @@ static int launch_conv_halo(IefGemmParams p, hipStream_t st) {
 // tile ids (IefGemmParams.tile_hint); the host binding picks one per layer shape
 //   1: 128x128 (2x2 waves)   2: 64x128 (2x2)    3: 64x64 (2x2)     4: 128x64 (2x2)
 //   5: 64x160 (2x2)          6: 128x160 (2x2)   7: 128x160 (4x2)   8: 256x128 (4x2)   9: 128x128 (4x2)
-//   14: conv3x3_halo_kernel 256x80 (8x1), convolutions only (launch_conv_halo)
+//   14: conv3x3_halo_kernel 256x80 (8x1), convolutions only (launch_conv_halo); 15: the same with four loader waves
 template <bool CONV>
 static int dispatch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     switch (p.tile_hint) {
@@ -1012,7 +1096,7 @@ extern "C" int ief_gemm_tile_bm(int tile_hint) {
     switch (tile_hint) {
         case 1: case 4: case 6: case 7: case 9: return 128;
         case 2: case 3: case 5: return 64;
-        case 8: case 14: return 256;
+        case 8: case 14: case 15: return 256;
         default: return 0;
     }
 }
@@ -1022,7 +1106,7 @@ extern "C" int ief_gemm_tile_bn(int tile_hint) {
         case 1: case 2: case 8: case 9: return 128;
         case 3: case 4: return 64;
         case 5: case 6: case 7: return 160;
-        case 14: return 80;
+        case 14: case 15: return 80;
         default: return 0;
     }
 }
@@ -1088,6 +1172,6 @@ extern "C" int ief_conv3x3_f16(const IefGemmParams* pp, void* stream) {
     const int emax = p.CE1 > p.CE2 ? p.CE1 : p.CE2;
     if (in_pix * cmax * 2 >= (1ll << 32) || (long long)p.M * emax * 2 >= (1ll << 32)) return IEF_ESHAPE;
     p.strideA = p.strideW = p.strideO = p.strideR = 0;
-    if (p.tile_hint == 14) return launch_conv_halo(p, (hipStream_t)stream);
+    if (p.tile_hint == 14 || p.tile_hint == 15) return launch_conv_halo(p, (hipStream_t)stream);
     return dispatch_igemm<true>(p, 1, (hipStream_t)stream);
 }

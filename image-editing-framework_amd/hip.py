@@ -236,20 +236,20 @@ PROF_SHAPES = os.environ.get("IEF_PROF_SHAPES", "0") == "1"     # append MxNxK t
 # tile id -> (BM, BN, WAVES_M, WAVES_N), as in csrc/gemm_conv.hip
 _TILES = {1: (128, 128, 2, 2), 2: (64, 128, 2, 2), 3: (64, 64, 2, 2), 4: (128, 64, 2, 2), 5: (64, 160, 2, 2),
           6: (128, 160, 2, 2), 7: (128, 160, 4, 2), 8: (256, 128, 4, 2), 9: (128, 128, 4, 2),
-          14: (256, 80, 8, 1)}
-_HALO_TILE = 14     # conv3x3_halo_kernel (csrc/gemm_conv.hip): 3x3 / stride 1 / pad 1 convolutions only, rows of <= 64 pixels
+          14: (256, 80, 8, 1), 15: (256, 80, 8, 1)}
+_HALO_TILES = (14, 15)  # conv3x3_halo_kernel (csrc/gemm_conv.hip): 3x3 / stride 1 / pad 1 convolutions only, rows of <= 64 pixels; 15: + 4 loader waves
 
 
 def _kname(tile, conv, stages=2):
     bm, bn, wm, wn = _TILES[tile]
-    if tile == _HALO_TILE:
-        return f"conv3x3_halo_kernel<{bm}, {bn}, {wm}, {wn}>"
+    if tile in _HALO_TILES:
+        return f"conv3x3_halo_kernel<{bm}, {bn}, {wm}, {wn}, {4 if tile == 15 else 0}>"
     return f"igemm_f16_kernel<{bm}, {bn}, {wm}, {wn}, {stages or 2}, {'true' if conv else 'false'}>"
 
 
 def _ring_bytes(tile, stages):
     bm, bn, wm, wn = _TILES[tile]
-    if tile == _HALO_TILE:          # fixed LDS image (two super-tile buffers + a 4-slot weight ring); one "ring depth"
+    if tile in _HALO_TILES:         # fixed LDS image (two super-tile buffers + a 4-slot weight ring); one "ring depth"
         return 155776 if stages == 4 else 1 << 30
     rp = 64 * wm * wn // 8
     rows = -(-bm // rp) * rp + -(-bn // rp) * rp
@@ -484,7 +484,7 @@ def candidate_plans(M: int, N: int, K: int, conv: bool = False):
     nk = -(-K // 64)
     out = []
     for t, (bm, bn, _, _) in _TILES.items():
-        if t == _HALO_TILE and not conv:
+        if t in _HALO_TILES and not conv:
             continue
         for s in (1, 2, 4, 8, 16):
             blocks = -(-M // bm) * -(-N // bn) * s
@@ -769,7 +769,7 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
                                                                             pad_hi_only=pad_hi_only))
             del wc
         p.tile_hint, p.splits, p.stages = pick_plan(M, Cout, K, conv=True)
-        if p.tile_hint == _HALO_TILE and (stride != 1 or upsample or pad_hi_only or extra is not None or Wd > 64
+        if p.tile_hint in _HALO_TILES and (stride != 1 or upsample or pad_hi_only or extra is not None or Wd > 64
                                           or p.splits > (C1 + C2) // 64):
             # the table is keyed by (M, N, K) alone: a convolution of another geometry that shares the key
             p.tile_hint, p.splits, p.stages = heuristic_plan(M, Cout, K) + (2,)
@@ -779,7 +779,7 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
         ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)
         p.ws = ws.data_ptr()
         nt, kb = _tile_count(lib, p.tile_hint, M, Cout, p.splits)
-        p.cnt = _splitk_counters(x.device, nt, kb) if nt and p.tile_hint != _HALO_TILE else None
+        p.cnt = _splitk_counters(x.device, nt, kb) if nt and p.tile_hint not in _HALO_TILES else None
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.flags, p.zeros = 1, _zeros(x.device)
     cst = _attach_cstat(lib, p, out, M, Cout, Ho * Wo) if col_stats and out.is_contiguous() else None

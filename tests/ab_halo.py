@@ -23,7 +23,8 @@ for B, H, W, C1, C2, Cout, sps in SHAPES:
     t, sp, st = hip.pick_plan(M, Cout, K, conv=True)
     arms = [(f"t{t}s{sp}r{st}", lambda: hip.conv3x3(x, w, bias, x2=x2, tile_hint=t, splits=sp, stages=st))]
     for s_ in sps:
-        arms.append((f"halo s{s_}", (lambda q: (lambda: hip.conv3x3(x, w, bias, x2=x2, tile_hint=14, splits=q, stages=4)))(s_)))
+        for t_ in (14, 15):
+            arms.append((f"t{t_} s{s_}", (lambda q, tt: (lambda: hip.conv3x3(x, w, bias, x2=x2, tile_hint=tt, splits=q, stages=4)))(s_, t_)))
     res = {n: [] for n, _ in arms}
     for rnd in range(4):                      # interleaved rounds, one process (guide rule 24)
         for n, f in arms:

@@ -119,7 +119,8 @@ def test_conv3x3(B, H, W, C1, C2, Cout, stride, ups):
     (2, 16, 16, 128, 64, 320, 1), (2, 16, 16, 128, 64, 320, 3), (1, 64, 64, 64, 0, 160, 1), (4, 8, 8, 128, 0, 80, 2),
     (3, 10, 12, 64, 64, 96, 1), (4, 64, 64, 320, 0, 320, 1), (4, 32, 32, 640, 0, 640, 2), (1, 5, 2, 64, 0, 8, 1),
 ])
-def test_conv3x3_halo_tile(B, H, W, C1, C2, Cout, splits):
+@pytest.mark.parametrize("tile", [14, 15])
+def test_conv3x3_halo_tile(B, H, W, C1, C2, Cout, splits, tile):
     """conv3x3_halo_kernel (tile 14: the input tile stays in LDS across the nine taps): image edges, tiles spanning
     several images (8x8), M / N tails, channel concat, split-K over channel blocks, the widest row it is sized for"""
     x = h16(B, H, W, C1, seed=1)
@@ -130,7 +131,7 @@ def test_conv3x3_halo_tile(B, H, W, C1, C2, Cout, splits):
     ref0 = _conv_ref(x, w, bias, 1, False, x2, rv)
     res = h16(*ref0.shape, seed=6)
     out = hip.conv3x3(dev(x), dev(w), dev(bias), x2=None if x2 is None else dev(x2), rowvec=dev(rv), residual=dev(res),
-                      tile_hint=14, splits=splits, stages=4)
+                      tile_hint=tile, splits=splits, stages=4)
     close(out, ref0 + res.float(), 2e-3, 1e-3)
     # same sums as the implicit-GEMM kernel up to the fp32 summation order
     out7 = hip.conv3x3(dev(x), dev(w), dev(bias), x2=None if x2 is None else dev(x2), rowvec=dev(rv), residual=dev(res),
