@@ -41,11 +41,17 @@ __device__ __forceinline__ void glds16(const char* g, half_t* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool CONV>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const IefGemmParams p) {
+// NL > 0: NL extra LOADER waves stage both operands (all LDS-DMA issues, the address bookkeeping and the vmcnt waits are
+// theirs); the WAVES_M x WAVES_N compute waves only read fragments and multiply.  An LDS-DMA instruction costs a wave that
+// also multiplies ~180 cycles of its in-order stream and a wave that does nothing else ~25-60 (measured on the halo kernel
+// below, where the split took 8-12 % off).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NL, bool CONV>
+__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kernel(const IefGemmParams p) {
     constexpr int BK = 64;
-    constexpr int NT = 64 * WAVES_M * WAVES_N;      // threads
-    constexpr int RP = NT / 8;                      // tile rows staged per pass (8 lanes x 16 B = one 128-B row)
+    constexpr int NWC = WAVES_M * WAVES_N;          // compute waves
+    constexpr int NT = 64 * (NWC + NL);             // threads
+    constexpr int NST = NL > 0 ? 64 * NL : NT;      // threads that stage
+    constexpr int RP = NST / 8;                     // tile rows staged per pass (8 lanes x 16 B = one 128-B row)
     constexpr int NA = (BM + RP - 1) / RP, NB = (BN + RP - 1) / RP;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     constexpr int ROWS_A = NA * RP, ROWS_B = NB * RP;   // LDS rows incl. staging overshoot
@@ -61,6 +67,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases (m0) stay on the scalar unit
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const bool stages_ = NL == 0 || wave >= NWC;                 // this wave stages operands
+    const bool computes = NL == 0 || wave < NWC;                 // this wave multiplies
+    const int stid = NL > 0 ? tid - 64 * NWC : tid;              // index among the staging threads (negative: not one)
+    const int swave = NL > 0 ? wave - NWC : wave;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     const char* __restrict__ Wt = (const char*)(p.W + z * p.strideW);
     const char* __restrict__ zp = (const char*)p.zeros;
 
-    const int rbase = tid >> 3;   // row (+RP*i) this thread stages
+    const int rbase = (stid >> 3) & (RP - 1);   // row (+RP*i) this thread stages
     // the LDS slot (tid&7) of a lane is fixed by LDS-DMA; the swizzle is applied to the chunk FETCHED
     const unsigned kcb = (unsigned)(((tid & 7) ^ ((rbase >> 1) & 7)) * 16);   // byte offset of that chunk in the K row
 
@@ -166,8 +176,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     };
 
     auto stage_tile = [&](int buf, int kt) {
-        half_t* la = As + buf * ROWS_A * BK + (wave * 8) * BK;
-        half_t* lb = Bs + buf * ROWS_B * BK + (wave * 8) * BK;
+        if (!stages_) return;
+        half_t* la = As + buf * ROWS_A * BK + (swave * 8) * BK;
+        half_t* lb = Bs + buf * ROWS_B * BK + (swave * 8) * BK;
         const bool tz = ktail && kt == nk_all - 1 && tail_zero;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -252,11 +263,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
     // fragments they read (and waited for) before the barrier, then stage and read tile kt — so each SIMD always has one
     // wave on the matrix pipe while its partner issues DMA / LDS reads.  Same barriers, same slots, same sums.
     constexpr bool PINGPONG = (WAVES_M * WAVES_N == 8) && NS >= 3;
-    const bool late = PINGPONG && wave >= 4;
+    const bool late = PINGPONG && wave >= 4 && wave < NWC;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (kt_lo + s < nk) stage_tile(s, kt_lo + s);
-    if (!late) {
+    if (NL > 0 && !computes) {
+        // loader waves: their share of tile k has landed -> barrier -> refill the slot tile k-1 used
         for (int kt = kt_lo; kt < nk; kt += NS) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -266,6 +278,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_barrier" ::: "memory");
                     if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS, k + NS - 1);
+                }
+            }
+        }
+    } else if (!late) {
+        for (int kt = kt_lo; kt < nk; kt += NS) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k = kt + s;
+                if (k < nk) {
+                    if constexpr (NL == 0) {
+                        if (nk - 1 - k >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    asm volatile("s_barrier" ::: "memory");
+                    if constexpr (NL == 0) { if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS, k + NS - 1); }
                     read_frags(As + s * ROWS_A * BK, Bs + s * ROWS_B * BK);
                     mfma_frags();
                 }
@@ -277,11 +304,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_f16_kernel(const
             for (int s = 0; s < NS; ++s) {
                 const int k = kt + s;
                 if (k < nk) {
-                    if (nk - 1 - k >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 2)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if constexpr (NL == 0) {
+                        if (nk - 1 - k >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G * (NS - 2)) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                     asm volatile("s_barrier" ::: "memory");
                     if (k > kt_lo) mfma_frags();                                   // tile k-1, fragments already in registers
-                    if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS, k + NS - 1);
+                    if constexpr (NL == 0) { if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS, k + NS - 1); }
                     read_frags(As + s * ROWS_A * BK, Bs + s * ROWS_B * BK);         // tile k: landed (barrier above)
                 }
             }
@@ -1005,28 +1036,28 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool CONV>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NL, bool CONV>
 static int launch_ns(const IefGemmParams& p, int tiles, int splits, int batch, hipStream_t st) {
-    constexpr int NT = 64 * WAVES_M * WAVES_N, RP = NT / 8;
+    constexpr int NT = 64 * (WAVES_M * WAVES_N + NL), RP = (NL > 0 ? 64 * NL : NT) / 8;
     constexpr long long lds = 2ll * NS * (((BM + RP - 1) / RP) * RP + ((BN + RP - 1) / RP) * RP) * 64;
     if constexpr (lds > 160 * 1024) {
         return IEF_ESHAPE;   // this ring depth does not fit the 160 KiB LDS for this tile
     } else {
-        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, WAVES_M, WAVES_N, NS, CONV>), dim3(tiles, splits, batch), dim3(NT), 0,
+        hipLaunchKernelGGL((igemm_f16_kernel<BM, BN, WAVES_M, WAVES_N, NS, NL, CONV>), dim3(tiles, splits, batch), dim3(NT), 0,
                            st, p);
         return IEF_OK;
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NL, bool CONV>
 static int launch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int splits = p.splits > 1 ? p.splits : 1;
     int rc;
     switch (p.stages) {
-        case 3: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 3, CONV>(p, tiles, splits, batch, st); break;
-        case 4: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 4, CONV>(p, tiles, splits, batch, st); break;
-        default: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 2, CONV>(p, tiles, splits, batch, st); break;
+        case 3: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 3, NL, CONV>(p, tiles, splits, batch, st); break;
+        case 4: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 4, NL, CONV>(p, tiles, splits, batch, st); break;
+        default: rc = launch_ns<BM, BN, WAVES_M, WAVES_N, 2, NL, CONV>(p, tiles, splits, batch, st); break;
     }
     if (rc) return rc;
     IEF_LAUNCH_CHECK();
@@ -1071,41 +1102,49 @@ static int launch_conv_halo(IefGemmParams p, hipStream_t st) {
 // tile ids (IefGemmParams.tile_hint); the host binding picks one per layer shape
 //   1: 128x128 (2x2 waves)   2: 64x128 (2x2)    3: 64x64 (2x2)     4: 128x64 (2x2)
 //   5: 64x160 (2x2)          6: 128x160 (2x2)   7: 128x160 (4x2)   8: 256x128 (4x2)   9: 128x128 (4x2)
+//   with loader waves (NL): 16: 128x160 (4x2)+4   17: 128x128 (4x2)+4   18: 256x128 (4x2)+4   19: 64x160 (2x2)+2   20: 64x64 (2x2)+2
+//   21: 128x160 (2x2)+2
 //   14: conv3x3_halo_kernel 256x80 (8x1), convolutions only (launch_conv_halo); 15: the same with four loader waves
 template <bool CONV>
 static int dispatch_igemm(const IefGemmParams& p, int batch, hipStream_t st) {
     switch (p.tile_hint) {
-        case 1: return launch_igemm<128, 128, 2, 2, CONV>(p, batch, st);
-        case 2: return launch_igemm<64, 128, 2, 2, CONV>(p, batch, st);
-        case 3: return launch_igemm<64, 64, 2, 2, CONV>(p, batch, st);
-        case 4: return launch_igemm<128, 64, 2, 2, CONV>(p, batch, st);
-        case 5: return launch_igemm<64, 160, 2, 2, CONV>(p, batch, st);
-        case 6: return launch_igemm<128, 160, 2, 2, CONV>(p, batch, st);
-        case 7: return launch_igemm<128, 160, 4, 2, CONV>(p, batch, st);
-        case 8: return launch_igemm<256, 128, 4, 2, CONV>(p, batch, st);
-        case 9: return launch_igemm<128, 128, 4, 2, CONV>(p, batch, st);
+        case 1: return launch_igemm<128, 128, 2, 2, 0, CONV>(p, batch, st);
+        case 2: return launch_igemm<64, 128, 2, 2, 0, CONV>(p, batch, st);
+        case 3: return launch_igemm<64, 64, 2, 2, 0, CONV>(p, batch, st);
+        case 4: return launch_igemm<128, 64, 2, 2, 0, CONV>(p, batch, st);
+        case 5: return launch_igemm<64, 160, 2, 2, 0, CONV>(p, batch, st);
+        case 6: return launch_igemm<128, 160, 2, 2, 0, CONV>(p, batch, st);
+        case 7: return launch_igemm<128, 160, 4, 2, 0, CONV>(p, batch, st);
+        case 8: return launch_igemm<256, 128, 4, 2, 0, CONV>(p, batch, st);
+        case 9: return launch_igemm<128, 128, 4, 2, 0, CONV>(p, batch, st);
+        case 16: return launch_igemm<128, 160, 4, 2, 4, CONV>(p, batch, st);
+        case 17: return launch_igemm<128, 128, 4, 2, 4, CONV>(p, batch, st);
+        case 18: return launch_igemm<256, 128, 4, 2, 4, CONV>(p, batch, st);
+        case 19: return launch_igemm<64, 160, 2, 2, 2, CONV>(p, batch, st);
+        case 20: return launch_igemm<64, 64, 2, 2, 2, CONV>(p, batch, st);
+        case 21: return launch_igemm<128, 160, 2, 2, 2, CONV>(p, batch, st);
         default: break;
     }
     auto nblk = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
-    if (nblk(128, 128) >= 384) return launch_igemm<128, 128, 2, 2, CONV>(p, batch, st);
-    if (nblk(64, 128) >= 256) return launch_igemm<64, 128, 2, 2, CONV>(p, batch, st);
-    return launch_igemm<64, 64, 2, 2, CONV>(p, batch, st);
+    if (nblk(128, 128) >= 384) return launch_igemm<128, 128, 2, 2, 0, CONV>(p, batch, st);
+    if (nblk(64, 128) >= 256) return launch_igemm<64, 128, 2, 2, 0, CONV>(p, batch, st);
+    return launch_igemm<64, 64, 2, 2, 0, CONV>(p, batch, st);
 }
 
 extern "C" int ief_gemm_tile_bm(int tile_hint) {
     switch (tile_hint) {
-        case 1: case 4: case 6: case 7: case 9: return 128;
-        case 2: case 3: case 5: return 64;
-        case 8: case 14: case 15: return 256;
+        case 1: case 4: case 6: case 7: case 9: case 16: case 17: case 21: return 128;
+        case 2: case 3: case 5: case 19: case 20: return 64;
+        case 8: case 14: case 15: case 18: return 256;
         default: return 0;
     }
 }
 
 extern "C" int ief_gemm_tile_bn(int tile_hint) {
     switch (tile_hint) {
-        case 1: case 2: case 8: case 9: return 128;
-        case 3: case 4: return 64;
-        case 5: case 6: case 7: return 160;
+        case 1: case 2: case 8: case 9: case 17: case 18: return 128;
+        case 3: case 4: case 20: return 64;
+        case 5: case 6: case 7: case 16: case 19: case 21: return 160;
         case 14: case 15: return 80;
         default: return 0;
     }

@@ -236,7 +236,10 @@ PROF_SHAPES = os.environ.get("IEF_PROF_SHAPES", "0") == "1"     # append MxNxK t
 # tile id -> (BM, BN, WAVES_M, WAVES_N), as in csrc/gemm_conv.hip
 _TILES = {1: (128, 128, 2, 2), 2: (64, 128, 2, 2), 3: (64, 64, 2, 2), 4: (128, 64, 2, 2), 5: (64, 160, 2, 2),
           6: (128, 160, 2, 2), 7: (128, 160, 4, 2), 8: (256, 128, 4, 2), 9: (128, 128, 4, 2),
-          14: (256, 80, 8, 1), 15: (256, 80, 8, 1)}
+          14: (256, 80, 8, 1), 15: (256, 80, 8, 1),
+          16: (128, 160, 4, 2), 17: (128, 128, 4, 2), 18: (256, 128, 4, 2), 19: (64, 160, 2, 2), 20: (64, 64, 2, 2),
+          21: (128, 160, 2, 2)}
+_TILE_NL = {16: 4, 17: 4, 18: 4, 19: 2, 20: 2, 21: 2}   # loader waves of a tile (csrc/gemm_conv.hip, NL): they stage, the others multiply
 _HALO_TILES = (14, 15)  # conv3x3_halo_kernel (csrc/gemm_conv.hip): 3x3 / stride 1 / pad 1 convolutions only, rows of <= 64 pixels; 15: + 4 loader waves
 
 
@@ -244,14 +247,14 @@ def _kname(tile, conv, stages=2):
     bm, bn, wm, wn = _TILES[tile]
     if tile in _HALO_TILES:
         return f"conv3x3_halo_kernel<{bm}, {bn}, {wm}, {wn}, {4 if tile == 15 else 0}>"
-    return f"igemm_f16_kernel<{bm}, {bn}, {wm}, {wn}, {stages or 2}, {'true' if conv else 'false'}>"
+    return f"igemm_f16_kernel<{bm}, {bn}, {wm}, {wn}, {stages or 2}, {_TILE_NL.get(tile, 0)}, {'true' if conv else 'false'}>"
 
 
 def _ring_bytes(tile, stages):
     bm, bn, wm, wn = _TILES[tile]
     if tile in _HALO_TILES:         # fixed LDS image (two super-tile buffers + a 4-slot weight ring); one "ring depth"
         return 155776 if stages == 4 else 1 << 30
-    rp = 64 * wm * wn // 8
+    rp = 64 * (_TILE_NL.get(tile, 0) or wm * wn) // 8
     rows = -(-bm // rp) * rp + -(-bn // rp) * rp
     return 2 * stages * rows * 64
 

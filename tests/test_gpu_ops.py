@@ -602,7 +602,7 @@ def test_splitk_in_launch_column_statistics_and_captured_arena(monkeypatch):
     assert torch.equal(y2, ref) and hip.counters_used() == used
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17, 18, 19, 20, 21])
 @pytest.mark.parametrize("stages", [2, 3, 4])
 def test_gemm_every_tile_and_ring_depth(tile, stages):
     """every member of the tile family x LDS ring depth, K tails (72 = 64 + 8) and short K (fewer tiles than stages)"""
@@ -615,7 +615,8 @@ def test_gemm_every_tile_and_ring_depth(tile, stages):
         close(out, a.float() @ w.float().t() + bias, 2e-3, 1e-3)
 
 
-@pytest.mark.parametrize("tile,stages,splits", [(6, 3, 1), (7, 4, 2), (3, 4, 4), (1, 3, 2), (8, 3, 1)])
+@pytest.mark.parametrize("tile,stages,splits", [(6, 3, 1), (7, 4, 2), (3, 4, 4), (1, 3, 2), (8, 3, 1), (16, 3, 1), (16, 4, 2), (19, 2, 1),
+                                                 (17, 3, 2), (20, 4, 4), (21, 2, 1), (18, 3, 1)])
 def test_conv_ring_depths(tile, stages, splits):
     B, H, W, C1, C2, Cout = 2, 16, 16, 128, 64, 320
     x, x2 = h16(B, H, W, C1, seed=1), h16(B, H, W, C2, seed=2)
