@@ -73,7 +73,12 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kerne
     const int swave = NL > 0 ? wave - NWC : wave;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    // consecutive logical tiles run on one XCD and share its L2: walk N first (they share the A panel) where the activations are
+    // the larger operand, M first (they share the weight tile) where the weights are — the 16x16 / 8x8 levels, whose weights
+    // every XCD would otherwise fetch in full
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const bool m_first = p.N > p.M;
+    const int m0 = (m_first ? lid % tiles_m : lid / tiles_n) * BM, n0 = (m_first ? lid / tiles_m : lid % tiles_n) * BN;
     const long long z = blockIdx.z;
     const char* __restrict__ A = (const char*)(p.A + z * p.strideA);
     const char* __restrict__ Wt = (const char*)(p.W + z * p.strideW);
@@ -671,7 +676,12 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    // consecutive logical tiles run on one XCD and share its L2: walk N first (they share the A panel) where the activations are
+    // the larger operand, M first (they share the weight tile) where the weights are — the 16x16 / 8x8 levels, whose weights
+    // every XCD would otherwise fetch in full
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const bool m_first = p.N > p.M;
+    const int m0 = (m_first ? lid % tiles_m : lid / tiles_n) * BM, n0 = (m_first ? lid / tiles_m : lid % tiles_n) * BN;
     const int W = p.Wd, H = p.H;
     const int Ctot = p.C1 + p.C2;
     const char* __restrict__ zp = (const char*)p.zeros;

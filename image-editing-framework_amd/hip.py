@@ -298,6 +298,7 @@ class _Timed:
 # describes: nothing is attached to tensor objects, so a buffer re-written by any other launch cannot be paired with
 # statistics of its earlier contents unless the caller itself keeps passing the old object.
 GN_CSTAT = os.environ.get("IEF_GN_CSTAT", "1") == "1"
+HALO_HEURISTIC = os.environ.get("IEF_HALO_HEURISTIC", "1") == "1"   # untuned plain 3x3 convolutions take the halo kernel
 _CSTAT_MIN_HW = 256
 
 
@@ -772,6 +773,17 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
                                                                             pad_hi_only=pad_hi_only))
             del wc
         p.tile_hint, p.splits, p.stages = pick_plan(M, Cout, K, conv=True)
+        halo_ok = stride == 1 and not upsample and not pad_hi_only and extra is None and 2 <= Wd <= 64 and Hp >= 2
+        if halo_ok and HALO_HEURISTIC and f"conv|{M}|{Cout}|{K}" not in _plan_table():
+            # no measured plan for this shape: the halo kernel (256 x 80 tiles) beat the implicit GEMM on every plain 3x3
+            # convolution that was tuned; cut K (whole 64-channel blocks) until ~256 workgroups exist
+            tiles = -(-M // 256) * -(-Cout // 80)
+            ncb = (C1 + C2) // 64
+            sp = 1
+            while tiles * sp < 192 and sp * 2 <= ncb and sp < 16:
+                sp *= 2
+            if tiles * sp >= 96:
+                p.tile_hint, p.splits, p.stages = 15, sp, 4
         if p.tile_hint in _HALO_TILES and (stride != 1 or upsample or pad_hi_only or extra is not None or Wd > 64
                                           or p.splits > (C1 + C2) // 64):
             # the table is keyed by (M, N, K) alone: a convolution of another geometry that shares the key

@@ -21,7 +21,7 @@ if os.environ.get("IEF_TUNE_KEEP", "0") != "1":      # IEF_TUNE_KEEP=1: keep the
     hip._plans = {}
 hip.AUTOTUNE = True
 pipe, cfg = bench.build_pipe(cfg_name, dev, 0, 1)
-hw = cfg.sample_size
+hw = int(os.environ.get('IEF_TUNE_LATENT', cfg.sample_size))   # e.g. 128: the 1024x1024 shapes of bench.py --latent 128
 for B in (4, 2, 1):
     x = torch.randn(B, 4, hw, hw, device=dev)
     ctx = (torch.randn(B, 77, cfg.cross_attention_dim, device=dev) * 0.1)
@@ -33,7 +33,7 @@ for B in (4, 2, 1):
         pipe.unet(x, 501, encoder_hidden_states=ctx, added_cond_kwargs=added)
     torch.cuda.synchronize()
     print(f"B={B}: {len(hip._plan_table())} shapes tuned", flush=True)
-if cfg.addition_embed:          # the reverse pass is not built for the SDXL family yet: forward shapes only
+if cfg.addition_embed or os.environ.get('IEF_TUNE_FORWARD_ONLY') == '1':          # forward shapes only
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     hip.save_plans(out)
     sys.exit(0)
