@@ -668,7 +668,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     constexpr int LDS_BYTES = ZOFF + 128 + (NL > 0 ? 1024 : 0);
     constexpr int LDS_N = BN + 4;
     static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % 64 == 0 && BN % 8 == 0, "tile");
-    static_assert(LDS_BYTES <= 160 * 1024 && 64 * LDS_N * 4 <= ABUF, "LDS");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(128))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -969,80 +969,102 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // all fragment reads done, nothing in flight: the super-tile buffer becomes the epilogue's scratch
 
-    // ---------------- epilogue through LDS, 64 output rows per pass (as igemm_f16_kernel, without the linear-only parts)
-    constexpr int NPASS = BM / 64, CH = BN / 8;
+    // ---------------- epilogue: the whole BM x BN tile goes through LDS at once (fp32 [BM][BN+4] in the super-tile buffers).
+    // Every thread first issues the residual loads of all its output chunks, then adds bias + the image's time-embedding row +
+    // residual, rounds and stores 16 B per chunk; the GroupNorm column statistics (sum, sum of squares of the ROUNDED outputs
+    // per channel) are taken by NT / BN row groups in parallel and folded in group order: fixed order, bit-reproducible.
+    constexpr int CH = BN / 8, NIT = (BM * CH + NT - 1) / NT;
+    constexpr int NG = NT / BN, RPG = (BM + NG - 1) / NG;          // cstat: row groups, rows per group
+    static_assert(BM * LDS_N * 4 <= 2 * ABUF && NG * BN * 2 * 4 <= NSB * BBUF, "epilogue LDS");
     float* stage = (float*)smem;
+    float* part = (float*)(smem + BOFF);                            // [NG][BN][2]
     half_t* __restrict__ Out = p.Out;
-    float ccs = 0.f, ccq = 0.f;
-    for (int pass = 0; pass < NPASS; ++pass) {
-        if ((wr * WM) / 64 == pass) {
-            const int rb0 = wr * WM - pass * 64;
+    if (computes) {
+        const int rb0 = wr * WM;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        stage[(rb0 + i * 16 + fq * 4 + r) * LDS_N + wc * WN + j * 16 + fr] = acc[i][j][r];
-        }
-        __syncthreads();
-        for (int c = tid; c < 64 * CH; c += NT) {
-            const int row = c / CH, nc = c - row * CH;
-            const int m = m0 + pass * 64 + row, n = n0 + nc * 8;
-            float* sp = stage + row * LDS_N + nc * 8;
-            if (m < p.M && n < p.N) {
-                const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
-                if (p.splits > 1) {
-                    float* w = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
-                    *(f32x4*)w = s0;
-                    *(f32x4*)(w + 4) = s1;
-                    continue;
-                }
-                float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-                if (p.bias) {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+                for (int r = 0; r < 4; ++r)
+                    stage[(rb0 + i * 16 + fq * 4 + r) * LDS_N + wc * WN + j * 16 + fr] = acc[i][j][r];
+    }
+    half8 rs[NIT];
+    if (p.residual && p.splits <= 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (p.rowvec) {
-                    const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n;
-                    const f32x4 b0 = *(const f32x4*)rv, b1 = *(const f32x4*)(rv + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (p.residual) {
-                    const half8 rs = *(const half8*)(p.residual + (long long)m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
-                }
-                half8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
-                *(half8*)(Out + (long long)m * p.ldo + n) = o;
-                if (p.cstat_out) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sp[e] = (float)o[e];
-                }
-            } else if (p.cstat_out) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sp[e] = 0.f;
-            }
-        }
-        __syncthreads();
-        if (p.cstat_out && p.splits <= 1) {   // column sums over this pass's rows, fixed order: deterministic
-            if (tid < BN) {
-                for (int r = 0; r < 64; ++r) {
-                    const float v = stage[r * LDS_N + tid];
-                    ccs += v;
-                    ccq += v * v;
-                }
-            }
-            __syncthreads();
+        for (int k = 0; k < NIT; ++k) {
+            const int c = tid + k * NT, row = c / CH, nc = c - row * CH;
+            const int m = m0 + row, n = n0 + nc * 8;
+            rs[k] = (c < BM * CH && m < p.M && n < p.N) ? *(const half8*)(p.residual + (long long)m * p.ldr + n) : (half8){0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    if (p.cstat_out && p.splits <= 1 && tid < BN && n0 + tid < p.N) {
-        float* co = p.cstat_out + ((long long)(m0 / BM) * p.N + n0 + tid) * 2;
-        co[0] = ccs; co[1] = ccq;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int c = tid + k * NT;
+        if (c >= BM * CH) break;
+        const int row = c / CH, nc = c - row * CH;
+        const int m = m0 + row, n = n0 + nc * 8;
+        float* sp = stage + row * LDS_N + nc * 8;
+        if (m < p.M && n < p.N) {
+            const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+            if (p.splits > 1) {
+                float* w = p.ws + ((long long)blockIdx.y * p.M + m) * p.N + n;
+                *(f32x4*)w = s0;
+                *(f32x4*)(w + 4) = s1;
+                continue;
+            }
+            float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            if (p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (p.rowvec) {
+                const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n;
+                const f32x4 b0 = *(const f32x4*)rv, b1 = *(const f32x4*)(rv + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            if (p.residual) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rs[k][e];
+            }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.out_scale);
+            *(half8*)(Out + (long long)m * p.ldo + n) = o;
+            if (p.cstat_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sp[e] = (float)o[e];
+            }
+        } else if (p.cstat_out) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sp[e] = 0.f;
+        }
+    }
+    if (p.cstat_out && p.splits <= 1) {
+        __syncthreads();
+        if (tid < NG * BN) {
+            const int g = tid / BN, col = tid - g * BN;
+            float cs = 0.f, cq = 0.f;
+            const int r1 = min(BM, (g + 1) * RPG);
+            for (int r = g * RPG; r < r1; ++r) {
+                const float v = stage[r * LDS_N + col];
+                cs += v;
+                cq += v * v;
+            }
+            part[(g * BN + col) * 2] = cs;
+            part[(g * BN + col) * 2 + 1] = cq;
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float cs = 0.f, cq = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { cs += part[(g * BN + tid) * 2]; cq += part[(g * BN + tid) * 2 + 1]; }
+            float* co = p.cstat_out + ((long long)(m0 / BM) * p.N + n0 + tid) * 2;
+            co[0] = cs; co[1] = cq;
+        }
     }
 }
 
