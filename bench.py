@@ -392,6 +392,8 @@ def _family(kernel_name: str) -> str:
     if kernel_name.startswith("igemm_f16_kernel"):
         return ("igemm_f16_kernel<.., CONV=true> (3x3 implicit-GEMM convolution)" if kernel_name.rstrip(">").endswith("true")
                 else "igemm_f16_kernel<.., CONV=false> (linear / 1x1)")
+    if kernel_name.startswith("conv3x3_halo_kernel"):
+        return "conv3x3_halo_kernel<..> (3x3 convolution, input tile resident in LDS across the taps)"
     if kernel_name.startswith("attn_flash"):
         return kernel_name.split("<")[0] + "<..> (self-attention, all head dims)"
     return kernel_name

@@ -16,11 +16,14 @@ CASES = {
     "gemmsq": ("igemm_f16_kernel", "igemm_f16_kernel<.., CONV=false> (linear / 1x1)",
                "square projection with bias + residual, B=4 64x64 tokens, 320->320 (M=16384 N=320 K=320): the most frequent linear "
                "of the step (to_out / proj_out / to_q at the 64x64 level)", 2 * (16384 * 320 * 3 + 320 * 320)),
-    "conv64": ("igemm_f16_kernel", "igemm_f16_kernel<.., CONV=true> (3x3 implicit-GEMM convolution)",
+    "conv64": ("conv3x3_halo_kernel", "conv3x3_halo_kernel<..> (3x3 convolution, input tile resident in LDS across the taps)",
                "conv3x3 B=4 64x64 320->320 (M=16384 N=320 K=2880): the most frequent large convolution of the step",
                2 * (16384 * 320 * 2 + 320 * 2880)),
-    "conv32": ("igemm_f16_kernel", "-", "conv3x3 B=4 32x32 640->640 (M=4096 N=640 K=5760), split-K: the kernel alone; the reducer "
+    "conv32": ("conv3x3_halo_kernel", "-", "conv3x3 B=4 32x32 640->640 (M=4096 N=640 K=5760), split-K: the kernel alone; the reducer "
                "launch is listed beside it", 2 * (4096 * 640 * 2 + 640 * 5760)),
+    "conv64igemm": ("igemm_f16_kernel", "igemm_f16_kernel<.., CONV=true> (3x3 implicit-GEMM convolution)",
+                    "the same convolution on the implicit-GEMM kernel (tile 7), for comparison with the halo kernel",
+                    2 * (16384 * 320 * 2 + 320 * 2880)),
     "attn40": ("attn_flash", "attn_flash_sp_kernel<..> (self-attention, all head dims)",
                "B=4 heads=8 N=L=4096 d=40 (SD1.5 64x64 self-attention)", 2 * 4 * 8 * 4096 * 40 * 4),
 }

@@ -18,6 +18,8 @@ def family(name: str) -> str:
     if name.startswith("igemm_f16_kernel"):
         return ("igemm_f16_kernel<.., CONV=true> (3x3 implicit-GEMM convolution)" if name.rstrip(">").endswith("true")
                 else "igemm_f16_kernel<.., CONV=false> (linear / 1x1)")
+    if name.startswith("conv3x3_halo_kernel"):
+        return "conv3x3_halo_kernel<..> (3x3 convolution, input tile resident in LDS across the taps)"
     if name.startswith("attn_flash"):
         return name.split("<")[0] + "<..> (self-attention, all head dims)"
     return name

@@ -14,10 +14,10 @@ if what == "attn40":
 elif what == "conv64":
     x, w, b = h(4, 64, 64, 320), h(320, 3, 3, 320, scale=0.02), torch.randn(320, device=DEV)
     fn = lambda: hip.conv3x3(x, w, b)
-elif what in ("conv64t7", "conv64halo"):
+elif what in ("conv64t7", "conv64halo", "conv64igemm"):
     x, w, b = h(4, 64, 64, 320), h(320, 3, 3, 320, scale=0.02), torch.randn(320, device=DEV)
-    fn = (lambda: hip.conv3x3(x, w, b, tile_hint=7, splits=1, stages=3)) if what == "conv64t7" else \
-         (lambda: hip.conv3x3(x, w, b, tile_hint=14, splits=1, stages=4))
+    fn = (lambda: hip.conv3x3(x, w, b, tile_hint=7, splits=1, stages=3)) if what in ("conv64t7", "conv64igemm") else \
+         (lambda: hip.conv3x3(x, w, b, tile_hint=15, splits=1, stages=4))
 elif what == "conv32":
     x, w, b = h(4, 32, 32, 640), h(640, 3, 3, 640, scale=0.02), torch.randn(640, device=DEV)
     fn = lambda: hip.conv3x3(x, w, b)

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k512 -- python3 $RO
 echo "k512 rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k1024 -- python3 $ROOT/bench.py $HEAD --latent 128 --steps 10 --in-flight "" > $OUT/k1024.log 2>&1
 echo "k1024 rc=$?"
-for k in gemmsq conv64 conv32 attn40; do
+for k in gemmsq conv64 conv64igemm conv32 attn40; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${k}_fetch -- python3 $ROOT/tests/one_kernel.py $k > $OUT/pmc_${k}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${k}_write -- python3 $ROOT/tests/one_kernel.py $k > $OUT/pmc_${k}_write.log 2>&1
   echo "pmc $k rc=$?"
