@@ -25,9 +25,12 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     Cout = Cc;
     float* wl = smem_ci;                 // [K][Cc]
     float* xin = smem_ci + K * Cc;       // [CI_PIX][K]
-    for (int i = threadIdx.x; i < K * Cout; i += 256) {   // w is [3][3][Cin][Cfull]: k-major
-        const int k = i / Cout, c = i - k * Cout;
-        wl[k * Cc + c] = (float)w[(long long)k * Cfull + co0 + c];
+    for (int i = threadIdx.x; i < K * (Cout >> 3); i += 256) {   // w is [3][3][Cin][Cfull]: k-major; 8 halves per load (Cc % 8 == 0)
+        const int k = i / (Cout >> 3), c = (i - k * (Cout >> 3)) << 3;
+        const half8 v = *(const half8*)(w + (long long)k * Cfull + co0 + c);
+        float* d = wl + k * Cc + c;
+        *(f32x4*)d = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        *(f32x4*)(d + 4) = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
     }
     const long long total = (long long)B * H * Wd;
     const long long pix0 = (long long)blockIdx.x * CI_PIX;
@@ -86,10 +89,79 @@ extern "C" int ief_conv_in_f32(const float* x, const ief_half* w, const float* b
     return IEF_OK;
 }
 
-// 16 lanes per output pixel split the 9*C reduction (8-channel chunks round-robin), shuffle-reduce.
+// 16 lanes per output pixel split the 9*C reduction (8-channel chunks round-robin), shuffle-reduce.  A workgroup stages the
+// weights ([Cout][9][C] fp16, 23 KB for SD's 320 -> 4) in LDS once and walks CO_PPG pixels per 16-lane group; per pixel the
+// activation chunks of a whole tap ROW (3 taps x up to CO_CH chunks) are requested before the first is used — the earlier
+// form issued one dependent load per 8 channels, 27 memory round trips per pixel (49 us for 0.4 GFLOP) — and the products
+// run on v_dot2_f32_f16 (fp16 pairs, fp32 accumulation).
+typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+template <int CH>            // chunks of 8 channels per lane and tap: C <= 16 * 8 * CH
 __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        int B, int C, int H, int Wd, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) half_t wl[];          // [Cout][9][C]
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long long total = (long long)B * H * Wd;
+    const int C8 = C >> 3;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long pix = (long long)blockIdx.x * 16 + grp;
+    const bool live = pix < total;
+    const long long pc = live ? pix : 0;
+    const int b = (int)(pc / (H * Wd));
+    const int rem = (int)(pc - (long long)b * H * Wd);
+    const int oy = rem / Wd, ox = rem - oy * Wd;
+    // every activation chunk this lane needs (9 taps x CH chunks) is requested before the weights are staged
+    half8 v[9][CH];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
+        const half_t* xp = x + (((long long)b * H + (ok ? iy : 0)) * Wd + (ok ? ix : 0)) * C;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c8 = sub + 16 * j;
+            v[tap][j] = (ok && c8 < C8) ? *(const half8*)(xp + c8 * 8) : zero8;
+        }
+    }
+    const int nw8 = (Cout * 9 * C) >> 3;
+    for (int i = threadIdx.x; i < nw8; i += 256) ((half8*)wl)[i] = ((const half8*)w)[i];
+    __syncthreads();
+    float acc[COUT_MAX];
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c8 = sub + 16 * j;
+            if (c8 < C8) {
+#pragma unroll
+                for (int o = 0; o < COUT_MAX; ++o) {
+                    if (o < Cout) {
+                        const half8 wv = *(const half8*)(wl + ((o * 9 + tap) * C + c8 * 8));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[o] = __builtin_amdgcn_fdot2((h2_t){v[tap][j][2 * e], v[tap][j][2 * e + 1]},
+                                                            (h2_t){wv[2 * e], wv[2 * e + 1]}, acc[o], false);
+                    }
+                }
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+    }
+    if (live && sub == 0) {
+        for (int o = 0; o < Cout; ++o)
+            out[(((long long)b * Cout + o) * H + oy) * Wd + ox] = acc[o] + (bias ? bias[o] : 0.f);
+    }
+}
+
+// fallback for wide inputs (C > 512) or weight sets past the LDS budget: the plain loop, one chunk at a time
+__global__ __launch_bounds__(256) void conv_out_wide_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int B, int C, int H, int Wd, int Cout) {
     const int sub = threadIdx.x & 15;
     const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const long long total = (long long)B * H * Wd;
@@ -137,8 +209,17 @@ extern "C" int ief_conv_out_f32(const ief_half* x, const ief_half* w, const floa
     if (!x || !w || !out) return IEF_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || C <= 0 || (C & 7) || Cout <= 0 || Cout > COUT_MAX) return IEF_ESHAPE;
     const long long total = (long long)B * H * Wd;
-    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                       out, B, C, H, Wd, Cout);
+    const size_t lds = (size_t)Cout * 9 * C * sizeof(half_t);
+    const dim3 grid((unsigned)((total + 15) / 16));
+    if (C <= 128 && lds <= 48 * 1024)
+        hipLaunchKernelGGL(conv_out_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, out, B, C, H, Wd, Cout);
+    else if (C <= 256 && lds <= 48 * 1024)
+        hipLaunchKernelGGL(conv_out_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, out, B, C, H, Wd, Cout);
+    else if (C <= 384 && lds <= 48 * 1024)
+        hipLaunchKernelGGL(conv_out_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, out, B, C, H, Wd, Cout);
+    else
+        hipLaunchKernelGGL(conv_out_wide_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           out, B, C, H, Wd, Cout);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
