@@ -402,7 +402,8 @@ extern "C" int ief_groupnorm_cstat_f16(const ief_half* x, const ief_half* x2, in
         int CW = unit * ((192 + unit - 1) / unit);            // ~192 channels per slice
         if (CW > C) CW = C;
         static const int fused_ok = env_int("IEF_GN_CSTAT_FUSED", 1);
-        if (fused_ok && unit <= 256 && CW <= GNS_MAXC && CW / 8 <= 256 && (long long)nt * CW * 8 <= 16 * 1024 && B <= 65535) {
+        static const int fused_kb = env_int("IEF_GN_CSTAT_FUSED_KB", 16);
+        if (fused_ok && unit <= 256 && CW <= GNS_MAXC && CW / 8 <= 256 && (long long)nt * CW * 8 <= fused_kb * 1024 && B <= 65535) {
             const int PY = 256 / (CW / 8);
             int ppb = PY * 4;                                  // ~4 pixels per thread
             if (ppb > HW) ppb = HW;
