@@ -4,6 +4,6 @@ run() {
     | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$2', '$1', d['ms_per_step'], 'ms', d['value'], 'steps/s')"
 }
 for cfg in sd21 sdxl; do
-  IEF_HALO_HEURISTIC=0 IEF_PLAN_FILE=$(pwd)/gpurun_ab/tuned_plans_r02start.json run "round-start plans" $cfg
+  IEF_HALO_HEURISTIC=0 IEF_PLAN_FILE=$(pwd)/tests/plans/tuned_plans_r02start.json run "round-start plans" $cfg
   run "committed plans  " $cfg
 done

@@ -4,6 +4,6 @@ run() {
     | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', d['ms_per_step'])"
 }
 for i in 1 2 3; do
-  IEF_HALO_HEURISTIC=0 IEF_PLAN_FILE=$(pwd)/gpurun_ab/tuned_plans_r02start.json run "round-start plans"
+  IEF_HALO_HEURISTIC=0 IEF_PLAN_FILE=$(pwd)/tests/plans/tuned_plans_r02start.json run "round-start plans"
   run "committed plans  "
 done
