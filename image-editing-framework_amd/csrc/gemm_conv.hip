@@ -212,6 +212,26 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kerne
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The residual rows this thread will add in the epilogue are requested NOW: they do not depend on the product, and a
+    // K = C projection is otherwise a chain of memory round trips (first tile, each K tile, then the residual).  Only where it
+    // costs few registers (<= 4 chunks of 8 halves per thread).
+    constexpr int EP_ROWS = BM < 64 ? BM : 64, EP_CH = BN / 8, EP_NPASS = (BM + 63) / 64;
+    constexpr int EP_IPT = (EP_ROWS * EP_CH + NT - 1) / NT;                       // output chunks per thread and pass
+    constexpr bool RES_PREFETCH = EP_IPT * EP_NPASS <= 4;
+    half8 res_pf[RES_PREFETCH ? EP_IPT * EP_NPASS : 1];
+    const bool res_pf_on = RES_PREFETCH && p.residual && p.splits <= 1 && !(p.flags & 2);
+    if (res_pf_on) {
+#pragma unroll
+        for (int ps = 0; ps < EP_NPASS; ++ps)
+#pragma unroll
+            for (int k = 0; k < EP_IPT; ++k) {
+                const int c = tid + k * NT, row = c / EP_CH, nc = c - row * EP_CH;
+                const int m = m0 + ps * 64 + row, n = n0 + nc * 8;
+                res_pf[RES_PREFETCH ? ps * EP_IPT + k : 0] = (c < EP_ROWS * EP_CH && m < p.M && n < p.N)
+                    ? *(const half8*)(p.residual + z * p.strideR + (long long)m * p.ldr + n) : (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+    }
+
     if constexpr (CONV) {
         const int k0 = kt_lo * BK;
         if (k0 < 9 * Ctot) { it_tap = k0 / Ctot; it_c = k0 - it_tap * Ctot; }
@@ -336,6 +356,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kerne
     float* row_rs = row_mu + 64;
     half_t* __restrict__ Out = p.Out + z * p.strideO;
     float ccs = 0.f, ccq = 0.f;                      // cstat_out: thread tid < BN owns output column n0 + tid
+#pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         if (p.rstat_in && tid < 64) {
             const int m = m0 + pass * 64 + tid;
@@ -391,7 +412,10 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kerne
             __syncthreads();
             continue;
         }
-        for (int c = tid; c < PROWS * CH; c += NT) {
+#pragma unroll
+        for (int kq = 0; kq < EP_IPT; ++kq) {
+            const int c = tid + kq * NT;
+            if (c >= PROWS * CH) break;
             const int row = c / CH, nc = c - row * CH;
             const int m = m0 + pass * 64 + row, n = n0 + nc * 8;
             if (m < p.M && n < p.N) {
@@ -422,7 +446,12 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kerne
                     for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
                 }
                 if (p.residual) {
-                    const half8 rs = *(const half8*)(p.residual + z * p.strideR + (long long)m * p.ldr + n);
+                    half8 rs;
+                    if constexpr (RES_PREFETCH) {
+                        rs = res_pf_on ? res_pf[pass * EP_IPT + kq] : *(const half8*)(p.residual + z * p.strideR + (long long)m * p.ldr + n);
+                    } else {
+                        rs = *(const half8*)(p.residual + z * p.strideR + (long long)m * p.ldr + n);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
                 }
