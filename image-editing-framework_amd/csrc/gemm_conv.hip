@@ -682,8 +682,13 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {   // n wave-uniform; wait
 //   instructions 26.6, without the fragment reads 29.2, without either 23.1 — an LDS-DMA instruction costs a COMPUTE wave
 //   ~180 cycles of its in-order stream (address VALU queued behind MFMAs, M0 write, issue), a wave that does nothing else
 //   ~25 (guide: ldsdma-fill).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NL = 0, int VAR = 3>
+//   UPS: the nearest-2x upsample of Upsample2D fused in (the source has H/2 x W/2 pixels): tap (ky, kx) of output pixel (y, x) is
+//   source pixel ((y + ky - 1) >> 1, (x + kx - 1) >> 1); the super-tile is then the SOURCE pixel range the tile's rows touch
+//   ((rows / 2 + 2) source rows + 2 pixels: smaller than the plain form's) and the fragment row is computed per lane and tap
+//   instead of being a constant shift.  Loader-wave form only; the tile must lie inside one image (H W a multiple of BM).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NL = 0, int VAR = 3, bool UPS = false>
 __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_kernel(const IefGemmParams p) {
+    static_assert(!UPS || NL > 0, "the upsample form exists with loader waves only");
     constexpr int BK = 64;
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * (NW + NL);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
@@ -714,6 +719,12 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     const int W = p.Wd, H = p.H;
     const int Ctot = p.C1 + p.C2;
     const char* __restrict__ zp = (const char*)p.zeros;
+    // UPS: source geometry and the source pixel (flattened over the batch) that super-tile row 0 holds
+    const int Wi = W >> 1, Hi = H >> 1;
+    const int ups_img = m0 / (H * W), ups_y0 = (m0 - ups_img * H * W) / W;
+    const int ups_rel = ((ups_y0 - 1) >> 1) * Wi - 1;                  // relative to the image's first source pixel
+    const int src_pixels = UPS ? p.batch_images * Hi * Wi : p.M;       // pixels of a source tensor
+    const int st_row0 = UPS ? ups_img * Hi * Wi + ups_rel : m0 - (W + 1);
 
     // channel blocks of this K slice
     const int ncb = Ctot / BK;
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
             // are constants.
             static_assert(3 * NL >= NPB && 6 * 9 >= NPA && 3 * NL >= 9, "loader schedule");
             const int l = wave - NW;
-            const int ms_lane = m0 - (W + 1) + (lane >> 3);
+            const int ms_lane = st_row0 + (lane >> 3);
             const char* an_src = zp; unsigned an_cs = 0, an_c0 = 0; bool an_on = false;
             auto set_next_block = [&](int cb, bool on) {
                 const bool first = cb * BK < p.C1;
@@ -800,7 +811,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
             };
             auto issue_a = [&](int q, bool exists, int buf_off) {     // super-tile piece q of the next block (q wave-uniform)
                 const int ms = ms_lane + 8 * q;
-                const bool ok = exists && an_on && (unsigned)ms < (unsigned)p.M;
+                const bool ok = exists && an_on && (unsigned)ms < (unsigned)src_pixels;
                 const char* g = ok ? an_src + ((unsigned long long)((unsigned)ms * an_cs + an_c0) * 2ull + st_chunk) : zp;
                 glds16(g, (half_t*)(smem + (exists ? buf_off + q * 1024 : DUMP)));
             };
@@ -855,13 +866,13 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     }
     // ---- fragment addressing
     const int fr = lane & 15, fq = lane >> 4;
-    int a_row[TM];
+    int a_row[TM], a_x[TM], a_y[TM];
     unsigned a_edge[TM];                 // bit 0: x == 0, 1: x == W-1, 2: y == 0, 3: y == H-1, 4: row past M
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wr * WM + i * 16 + fr, m = m0 + r;
         const int x = m % W, y = (m / W) % H;
-        a_row[i] = r;
+        a_row[i] = r; a_x[i] = x; a_y[i] = y;
         a_edge[i] = (x == 0 ? 1u : 0u) | (x == W - 1 ? 2u : 0u) | (y == 0 ? 4u : 0u) | (y == H - 1 ? 8u : 0u) | (m >= p.M ? 16u : 0u);
     }
     int b_off[TN];
@@ -882,7 +893,9 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void conv3x3_halo_ke
     half8 a0[TM], a1[TM], b0[TN], b1[TN];
     auto a_addr = [&](int i, int abuf, int ky, int kx) -> int {
         const unsigned tmask = 16u | (kx == 0 ? 1u : 0u) | (kx == 2 ? 2u : 0u) | (ky == 0 ? 4u : 0u) | (ky == 2 ? 8u : 0u);
-        const int sr = a_row[i] + ky * W + kx;
+        int sr;
+        if constexpr (UPS) sr = ((a_y[i] + ky - 1) >> 1) * Wi + ((a_x[i] + kx - 1) >> 1) - ups_rel;
+        else sr = a_row[i] + ky * W + kx;
         const int ad = abuf + sr * 128 + ((fq ^ (sr & 6)) << 4);
         return (a_edge[i] & tmask) ? ZOFF : ad;
     };
@@ -1141,7 +1154,10 @@ static void launch_splitk_reducer(const IefGemmParams& p, hipStream_t st) {
 
 // tile 14: conv3x3_halo_kernel<256, 80>; plain 3x3 / stride 1 / pad 1 convolutions on rows of at most 64 pixels
 static int launch_conv_halo(IefGemmParams p, hipStream_t st) {
-    if (p.stride != 1 || p.ups || p.pad_hi_only || p.CE1 || p.CE2 || p.Wd > 64 || p.Wd < 2 || p.H < 2) return IEF_ESHAPE;
+    if (p.stride != 1 || p.pad_hi_only || p.CE1 || p.CE2 || p.Wd < 2 || p.H < 2) return IEF_ESHAPE;
+    if (p.ups) {   // fused nearest-2x upsample: loader-wave form, tiles inside one image, whole output rows per tile
+        if (p.tile_hint != 15 || p.Wd > 128 || (p.H * p.Wd) % 256 || 256 % p.Wd) return IEF_ESHAPE;
+    } else if (p.Wd > 64) return IEF_ESHAPE;
     if ((p.C1 + p.C2) % 64) return IEF_ESHAPE;
     const int ncb = (p.C1 + p.C2) / 64;
     if (p.splits > ncb) return IEF_ESHAPE;
@@ -1150,7 +1166,8 @@ static int launch_conv_halo(IefGemmParams p, hipStream_t st) {
     constexpr int BM = 256, BN = 80;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int splits = p.splits > 1 ? p.splits : 1;
-    if (p.tile_hint == 15) hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1, 4>), dim3(tiles, splits, 1), dim3(768), 0, st, p);
+    if (p.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1, 4, 3, true>), dim3(tiles, splits, 1), dim3(768), 0, st, p);
+    else if (p.tile_hint == 15) hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1, 4>), dim3(tiles, splits, 1), dim3(768), 0, st, p);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, 8, 1, 0>), dim3(tiles, splits, 1), dim3(512), 0, st, p);
     IEF_LAUNCH_CHECK();
     if (splits > 1) {

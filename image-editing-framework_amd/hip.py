@@ -476,9 +476,13 @@ def heuristic_plan(M: int, N: int, K: int):
     return tile, splits
 
 
-def pick_plan(M: int, N: int, K: int, conv: bool = False):
-    """(tile, splits, stages)"""
-    hit = _plan_table().get(f"{'conv' if conv else 'gemm'}|{M}|{N}|{K}")
+def pick_plan(M: int, N: int, K: int, conv: bool = False, variant: str = ""):
+    """(tile, splits, stages); `variant` ("|u": the convolution with the fused nearest-2x upsample) has its own table key
+    and falls back to the plain key of the same (M, N, K)"""
+    kind = "conv" if conv else "gemm"
+    hit = _plan_table().get(f"{kind}|{M}|{N}|{K}{variant}") if variant else None
+    if hit is None:
+        hit = _plan_table().get(f"{kind}|{M}|{N}|{K}")
     if hit is None:
         hit = heuristic_plan(M, N, K)
     return (hit[0], hit[1], hit[2] if len(hit) > 2 else 2)
@@ -533,7 +537,7 @@ def _cold_copies(w, iters=20, budget=320 << 20):
     return [w] + [w.clone() for _ in range(k - 1)]
 
 
-def autotune_plan(kind: str, M: int, N: int, K: int, run):
+def autotune_plan(kind: str, M: int, N: int, K: int, run, variant: str = ""):
     """time run(tile, splits, stages, i) for every candidate plan (hipGraph of 20 launches each, launch i using
     the i-th cache-cold weight copy); remember the best"""
     best = None
@@ -545,7 +549,7 @@ def autotune_plan(kind: str, M: int, N: int, K: int, run):
         if best is None or us < best[0]:
             best = (us, t, sp, st)
     if best is not None:
-        _plan_table()[f"{kind}|{M}|{N}|{K}"] = (best[1], best[2], best[3])
+        _plan_table()[f"{kind}|{M}|{N}|{K}{variant}"] = (best[1], best[2], best[3])
     return best
 
 
@@ -764,17 +768,20 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.out_scale = 1.0
     M, K = B * Ho * Wo, 9 * (C1 + C2) + CE1 + CE2
     if tile_hint == 0:
-        if AUTOTUNE and f"conv|{M}|{Cout}|{K}" not in _plan_table() and not _capturing() and _prof is None:
+        variant = "|u" if upsample else ""
+        if AUTOTUNE and f"conv|{M}|{Cout}|{K}{variant}" not in _plan_table() and not _capturing() and _prof is None:
             wc = _cold_copies(w)
             autotune_plan("conv", M, Cout, K, lambda t, sp, st, i: conv3x3(x, wc[i % len(wc)], bias, x2=x2, stride=stride,
                                                                             upsample=upsample, rowvec=rowvec,
                                                                             residual=residual, out=out, tile_hint=t,
                                                                             splits=sp, extra=extra, stages=st,
-                                                                            pad_hi_only=pad_hi_only))
+                                                                            pad_hi_only=pad_hi_only), variant=variant)
             del wc
-        p.tile_hint, p.splits, p.stages = pick_plan(M, Cout, K, conv=True)
-        halo_ok = stride == 1 and not upsample and not pad_hi_only and extra is None and 2 <= Wd <= 64 and Hp >= 2
-        if halo_ok and HALO_HEURISTIC and f"conv|{M}|{Cout}|{K}" not in _plan_table():
+        p.tile_hint, p.splits, p.stages = pick_plan(M, Cout, K, conv=True, variant=variant)
+        halo_ok = stride == 1 and not pad_hi_only and extra is None and Hp >= 2 and (
+            (not upsample and 2 <= Wd <= 64) or (upsample and Wd <= 128 and (H * Wd) % 256 == 0 and 256 % Wd == 0))
+        if halo_ok and HALO_HEURISTIC and f"conv|{M}|{Cout}|{K}{variant}" not in _plan_table() and (
+                not upsample or f"conv|{M}|{Cout}|{K}" not in _plan_table()):
             # no measured plan for this shape: the halo kernel (256 x 80 tiles) beat the implicit GEMM on every plain 3x3
             # convolution that was tuned; cut K (whole 64-channel blocks) until ~256 workgroups exist
             tiles = -(-M // 256) * -(-Cout // 80)
@@ -784,8 +791,7 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
                 sp *= 2
             if tiles * sp >= 96:
                 p.tile_hint, p.splits, p.stages = 15, sp, 4
-        if p.tile_hint in _HALO_TILES and (stride != 1 or upsample or pad_hi_only or extra is not None or Wd > 64
-                                          or p.splits > (C1 + C2) // 64):
+        if p.tile_hint in _HALO_TILES and (not halo_ok or (upsample and p.tile_hint != 15) or p.splits > (C1 + C2) // 64):
             # the table is keyed by (M, N, K) alone: a convolution of another geometry that shares the key
             p.tile_hint, p.splits, p.stages = heuristic_plan(M, Cout, K) + (2,)
     else:

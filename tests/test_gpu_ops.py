@@ -139,12 +139,28 @@ def test_conv3x3_halo_tile(B, H, W, C1, C2, Cout, splits, tile):
     close(out, out7.float().cpu(), 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize("B,Hs,Ws,C1,C2,Cout,splits", [(2, 8, 8, 128, 0, 160, 1), (1, 32, 32, 64, 64, 96, 2), (1, 64, 64, 64, 0, 80, 1),
+                                                        (3, 16, 8, 64, 0, 320, 1), (4, 32, 32, 128, 0, 80, 1)])
+def test_conv3x3_halo_tile_upsample(B, Hs, Ws, C1, C2, Cout, splits):
+    """Upsample2D on the halo kernel (tile 15): nearest-2x fused into the super-tile addressing; rows of up to 128 pixels"""
+    x = h16(B, Hs, Ws, C1, seed=1)
+    x2 = h16(B, Hs, Ws, C2, seed=2) if C2 else None
+    w = h16(Cout, 3, 3, C1 + C2, seed=3, scale=(9 * (C1 + C2)) ** -0.5)
+    bias, rv = f32(Cout, seed=4, scale=0.1), f32(B, Cout, seed=5)
+    ref = _conv_ref(x, w, bias, 1, True, x2, rv)
+    out = hip.conv3x3(dev(x), dev(w), dev(bias), x2=None if x2 is None else dev(x2), upsample=True, rowvec=dev(rv),
+                      tile_hint=15, splits=splits, stages=4)
+    close(out, ref, 2e-3, 1e-3)
+
+
 def test_conv3x3_halo_tile_rejects_what_it_does_not_cover():
     x, w = h16(1, 16, 16, 64, seed=1), h16(64, 3, 3, 64, seed=2, scale=0.05)
     with pytest.raises(RuntimeError):
         hip.conv3x3(dev(x), dev(w), stride=2, tile_hint=14, stages=4)
     with pytest.raises(RuntimeError):
         hip.conv3x3(dev(x), dev(w), upsample=True, tile_hint=14, stages=4)
+    with pytest.raises(RuntimeError):
+        hip.conv3x3(dev(h16(1, 6, 6, 64, seed=4)), dev(w), upsample=True, tile_hint=15, stages=4)   # 12 x 12 output: tiles would span images
     xw = h16(1, 2, 128, 64, seed=3)
     with pytest.raises(RuntimeError):
         hip.conv3x3(dev(xw), dev(w), tile_hint=14, stages=4)
