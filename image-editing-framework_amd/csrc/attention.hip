@@ -673,9 +673,9 @@ __global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams 
     constexpr float RESCALE_THR = 5.0f;
     float m_run = 0.f, l_run = 0.f;
     bool first = true;
-    f32x16 minit, s0, s1;
+    f32x16 minit, sa0, sa1, sb0, sb1;      // two score sets: the loop alternates them instead of copying "next" into "current"
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { minit[i] = 0.f; s0[i] = 0.f; s1[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { minit[i] = 0.f; sa0[i] = 0.f; sa1[i] = 0.f; sb0[i] = 0.f; sb1[i] = 0.f; }
     half8 pb[4] = {};
 
     const int k_lane = r * C::KS + 8 * h;
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams 
             }
     };
     // mask (last tile) + running-maximum maintenance for the scores in (s0, s1); touches o, pb when the maximum moves
-    auto settle_max = [&](int kv0) {
+    auto settle_max = [&](int kv0, f32x16& s0, f32x16& s1) {
         if (kv0 + 64 > p.L) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams 
             first = false;
         }
     };
-    auto exp_pack = [&](half8 (&out)[4]) {
+    auto exp_pack = [&](half8 (&out)[4], f32x16& s0, f32x16& s1) {
         float ls = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -774,20 +774,19 @@ __global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams 
     if (nt > 1) { load_tile(64); store_tile(1, 1); }
     if (nt > 2) load_tile(128);
     __syncthreads();
-    scores(Ks, s0, s1);
-    settle_max(0);
-    exp_pack(pb);
-    if (nt > 1) scores(Ks + KBUF, s0, s1);
+    scores(Ks, sa0, sa1);
+    settle_max(0, sa0, sa1);
+    exp_pack(pb, sa0, sa1);
+    if (nt > 1) scores(Ks + KBUF, sa0, sa1);
     if (nt > 2) { store_tile(0, 2); if (nt > 3) load_tile(192); }
     __syncthreads();
-    for (int j = 1; j < nt; ++j) {
-        settle_max(j * 64);
+    auto one_tile = [&](int j, f32x16& s0, f32x16& s1, f32x16& n0, f32x16& n1) {
+        settle_max(j * 64, s0, s1);
         // one basic block: MFMAs of tiles j-1 and j+1 beside the exp / pack of tile j
         half8 pn[4];
-        f32x16 n0, n1;
         pv(Vs + ((j - 1) & 3) * VBUF);
         scores(Ks + ((j + 1) & 1) * KBUF, n0, n1);         // tile j+1 (a stale slot when j+1 == nt: result unused)
-        exp_pack(pn);
+        exp_pack(pn, s0, s1);
         // interleave: per MFMA two fragment reads and a handful of VALU ops (the exp / pack stream) in its shadow
 #pragma unroll
         for (int g = 0; g < 8 + 2 * C::D16; ++g) {
@@ -803,12 +802,15 @@ __global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams 
             asm volatile("" : "+v"(tmp));
             pb[kk] = __builtin_bit_cast(half8, tmp);
         }
-        s0 = n0; s1 = n1;
         if (j + 2 < nt) {
             store_tile(j & 1, (j + 2) & 3);
             if (j + 3 < nt) load_tile((j + 3) * 64);
         }
         __syncthreads();
+    };
+    for (int j = 1; j < nt; j += 2) {          // two tiles per trip: the score sets swap roles, no register copies
+        one_tile(j, sa0, sa1, sb0, sb1);
+        if (j + 1 < nt) one_tile(j + 1, sb0, sb1, sa0, sa1);
     }
     pv(Vs + ((nt - 1) & 3) * VBUF);
 
