@@ -596,9 +596,11 @@ __global__ __launch_bounds__(512) void attn_flash_pp_kernel(const IefAttnParams 
 // for 8 of its 32 cycles).  The running maximum is checked BEFORE that block; when it moves, O, the packed P(j-1) and
 // the pending scores are corrected first.  K is double-, V quadruple-buffered (V(j-1) .. V(j+2) are live).
 template <int D>
-__global__ __launch_bounds__(256) void attn_flash_sp_kernel(const IefAttnParams p) {
+__global__ __launch_bounds__(256, (D > 32 && D <= 48) ? 3 : 1) void attn_flash_sp_kernel(const IefAttnParams p) {
     using C = AttnCfg<D>;
-    constexpr int VRS = D <= 32 ? 32 : (D <= 96 ? 96 : 160);
+    // d = 40: 128-B V rows (the transposing reads are then 2-way conflicted, LDS is not what bounds the kernel) bring a workgroup
+    // to 46 KB and, with 166 registers, three workgroups onto a CU instead of two
+    constexpr int VRS = D <= 32 ? 32 : (D <= 48 ? 64 : (D <= 96 ? 96 : 160));
     constexpr int NCH = (64 * C::CPR + 255) / 256;
     constexpr int KBUF = 64 * C::KS, VBUF = 64 * VRS;
     __shared__ __attribute__((aligned(16))) half_t Ks[2 * KBUF];
