@@ -60,9 +60,9 @@ typedef struct IefGemmParams {
     int tile_hint;            /* 0 auto; otherwise a tile id (BM x BN, waves): 1: 128x128, 2: 64x128, 3: 64x64, 4: 128x64,
                                * 5: 64x160, 6: 128x160 (2x2), 7: 128x160 (4x2), 8: 256x128, 9: 128x128 (4x2); 16-21: 7, 9, 8, 5, 3, 6
                                * with 4 / 4 / 4 / 2 / 2 / 2 LOADER waves (extra waves that stage the operands, the others only
-                               * multiply); conv3x3 only: 14 / 15 = the halo kernel (256x80; 3x3, stride 1, pad 1, no upsample,
-                               * no fused 1x1 range, rows of <= 64 pixels; the input tile stays in LDS across the nine taps),
-                               * 15 with four loader waves.  ief_gemm_tile_bm / _bn give BM / BN of an id. */
+                               * multiply); conv3x3 only: 14 / 15 = the halo kernel (256x80; 3x3, stride 1, pad 1, no fused 1x1
+                               * range, rows of <= 64 pixels; the input tile stays in LDS across the nine taps), 15 with four
+                               * loader waves; 15 also takes ups = 1 (rows of <= 128 pixels, H*Wd a multiple of 256, Wd | 256).  ief_gemm_tile_bm / _bn give BM / BN of an id. */
     /* conv only: extra K range appended after the 9 taps, read at the OUTPUT pixel itself
      * (a fused 1x1 convolution over up to two more NHWC sources, e.g. ResnetBlock2D.conv_shortcut
      * over the un-concatenated [x | skip]); W rows are then [9*(C1+C2) + CE1 + CE2] long.
