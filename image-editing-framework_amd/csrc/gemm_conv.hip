@@ -184,15 +184,22 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_f16_kerne
         if (!stages_) return;
         half_t* la = As + buf * ROWS_A * BK + (swave * 8) * BK;
         half_t* lb = Bs + buf * ROWS_B * BK + (swave * 8) * BK;
-        const bool tz = ktail && kt == nk_all - 1 && tail_zero;
+        if (ktail && kt == nk_all - 1) {   // wave-uniform and never taken on the UNet's shapes (K % 64 == 0): keeps the per-lane
+            if (tail_zero) {               // zero-page select out of every other K tile
+#pragma unroll
+                for (int i = 0; i < NA; ++i) pa[i] = zp;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) pw[i] = zp;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            glds16(tz ? zp : pa[i], la + RP * i * BK);
+            glds16(pa[i], la + RP * i * BK);
             pa[i] += sa[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            glds16(tz ? zp : pw[i], lb + RP * i * BK);
+            glds16(pw[i], lb + RP * i * BK);
             pw[i] += sw[i];
         }
         if constexpr (CONV) {   // advance the iterator by one K tile; rebuild the pointers at tap / source boundaries
