@@ -276,6 +276,22 @@ static int launch_igemm_f32(const IefGemmF32Params& p, hipStream_t st) {
 // column-tile width the launcher picks for N output columns: 64 when that wastes less of the last tile than 128
 extern "C" int ief_gemm_f32_bn(int N) { return (N <= 64 || ((N % 128) != 0 && (N % 128) <= 64)) ? 64 : 128; }
 
+int ief_gemm_x3_dispatch(const IefGemmF32Params& p, hipStream_t st);      // split_x3.hip
+
+static int launch_x3(const IefGemmF32Params& p, hipStream_t st) {
+    if (!(p.sa > 0.f) || !(p.sb > 0.f)) return IEF_EINVAL;
+    const int rc = ief_gemm_x3_dispatch(p, st);
+    if (rc != IEF_OK) return rc;
+    if (p.splits > 1) {
+        const long long total = (long long)p.M * p.N;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3(grid), dim3(256), 0, st, p);
+        IEF_LAUNCH_CHECK();
+    }
+    return IEF_OK;
+}
+
 extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
     if (!pp || !pp->A || !pp->W || !pp->Out) return IEF_EINVAL;
     IefGemmF32Params p = *pp;
@@ -292,13 +308,15 @@ extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
         if (p.K != 9 * (p.C1 + p.C2) + p.CE1 + p.CE2 || p.M != p.batch_images * p.Ho * p.Wo) return IEF_ESHAPE;
         if (p.stride != 1 && p.stride != 2) return IEF_ESHAPE;
         if (p.ups && ((p.H | p.Wd) & 1)) return IEF_ESHAPE;
+        if (p.x3) return launch_x3(p, st);
         return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<true, false, 1>(p, st) : launch_igemm_f32<true, false, 2>(p, st);
     }
     p.a_scalar = ((p.lda & 3) || (p.K & 3)) ? 1 : 0;          // A rows not 16-byte chunked: element loads for A
     if (p.ldw & 3) return IEF_EALIGN;
     if (!p.transb && (p.K & 3)) return IEF_ESHAPE;             // W [N][K] rows are read in 16-byte chunks along K
+    if (p.transb && (p.N & 3)) return IEF_ESHAPE;
+    if (p.x3) return launch_x3(p, st);
     if (p.transb) {
-        if (p.N & 3) return IEF_ESHAPE;
         return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<false, true, 1>(p, st) : launch_igemm_f32<false, true, 2>(p, st);
     }
     return ief_gemm_f32_bn(p.N) == 64 ? launch_igemm_f32<false, false, 1>(p, st) : launch_igemm_f32<false, false, 2>(p, st);

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_longlo
 import torch
 
 # IEF_HIP_LIB / IEF_PLAN_FILE: A/B two builds of the library (and their tuned tables) on one GPU box
-ABI_VERSION = 2   # include/ief_hip.h IEF_ABI_VERSION
+ABI_VERSION = 3   # include/ief_hip.h IEF_ABI_VERSION
 _LIB_PATH = os.environ.get("IEF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libief_hip.so")
 _lib = None
 
@@ -92,6 +92,7 @@ class IefGemmF32Params(Structure):
         ("sAb", c_longlong), ("sAh", c_longlong), ("sWb", c_longlong), ("sWh", c_longlong), ("sOb", c_longlong), ("sOh", c_longlong),
         ("a_src", c_void_p), ("w_src", c_void_p), ("transb", c_int), ("a_scalar", c_int),
         ("splits", c_int), ("ws", c_void_p),
+        ("x3", c_int), ("sa", c_float), ("sb", c_float),
     ]
 
 
@@ -570,6 +571,40 @@ def _dev16(t, name):
     return t
 
 
+# How the contractions of the fp32-storage modes run (csrc/exact_f32.hip, csrc/split_x3.hip):
+#   "f32"  the fp32-input MFMA (bitwise an fp32 fma chain; precision="f32")
+#   "x3"   split operands: hi + lo fp16 halves of every fp32 element, three fp16 MFMAs per product (precision="f16x3")
+# A model sets it for the duration of its own calls (`with hip.f32_contraction(mode)`): one Python thread drives the
+# library, and a captured graph keeps the kernels that were chosen while it was recorded.
+_F32_CONTRACT = "f32"
+X3_SCALE_ACT, X3_SCALE_W, X3_SCALE_PROB = 16.0, 256.0, 16384.0      # powers of two: fp16(s x) keeps hi and lo normal
+
+
+class f32_contraction:
+    def __init__(self, mode: str):
+        if mode not in ("f32", "x3"):
+            raise ValueError('f32_contraction: mode must be "f32" or "x3"')
+        self.mode = mode
+
+    def __enter__(self):
+        global _F32_CONTRACT
+        self.saved, _F32_CONTRACT = _F32_CONTRACT, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _F32_CONTRACT
+        _F32_CONTRACT = self.saved
+        return False
+
+
+def _set_x3(p, sa, sb) -> str:
+    """fill the split-operand fields of an IefGemmF32Params from the current mode; returns the kernel family's name"""
+    if _F32_CONTRACT == "x3":
+        p.x3, p.sa, p.sb = 1, sa, sb
+        return "igemm_x3_kernel"
+    return "igemm_f32_kernel"
+
+
 def _is32(t) -> bool:
     """True for the fp32 activations / weights of the reference-precision mode (`csrc/exact_f32.hip`)"""
     return isinstance(t, torch.Tensor) and t.dtype == torch.float32
@@ -854,8 +889,9 @@ def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out
     p.M, p.N, p.K, p.lda, p.ldw, p.ldo = M, N, K, lda, w.stride(0), ldo
     p.out_scale, p.transb = out_scale, 1 if transb else 0
     ws = _splits_f32(lib, p, M, N, K, a.device)     # noqa: F841  (keeps the slabs alive until the launch is queued)
+    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_ACT if transb else X3_SCALE_W)        # transb: activation x activation
     nbytes = 4.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))
-    with _Timed(f"igemm_f32_kernel<false, {'true' if transb else 'false'}>", 2.0 * M * N * K, nbytes):
+    with _Timed(f"{kn}<false, {'true' if transb else 'false'}>" + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K, nbytes):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32")
     return out
 
@@ -913,8 +949,9 @@ def _conv3x3_f32(x, w, bias, x2, stride, upsample, rowvec, residual, out, extra,
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.out_scale = 1.0
     ws = _splits_f32(lib, p, M, Cout, K, x.device)  # noqa: F841
+    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_W)
     nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * (2 if residual is not None else 1))
-    with _Timed("igemm_f32_kernel<true, false>", 2.0 * M * Cout * K, nbytes):
+    with _Timed(f"{kn}<true, false>" + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (conv)")
     return out
 
@@ -1215,7 +1252,8 @@ def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None, softm
     p.sOb, p.sOh, p.ldo = heads * N * L, N * L, L
     p.batch, p.heads, p.out_scale = B, heads, scale
     p.a_src, p.w_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src"))
-    with _Timed(f"igemm_f32_kernel<scores {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
+    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_ACT)
+    with _Timed(f"{kn}<scores {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention scores)")
     if softmax:
         with _Timed("softmax_rows_f32_kernel", 0.0, 8.0 * out.numel()):
@@ -1257,7 +1295,8 @@ def _attn_apply_f32(probs, v, heads, v_src=None, out=None):
     p.sOb, p.sOh, p.ldo = _batched32(p, _act32(out, "out"), heads, d, "out")
     p.batch, p.heads, p.out_scale, p.transb = B, heads, 1.0, 1
     p.w_src = _ptr(_devi32(v_src, "v_src"))
-    with _Timed(f"igemm_f32_kernel<apply {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
+    kn = _set_x3(p, X3_SCALE_PROB, X3_SCALE_ACT)         # maps are <= 1: a large scale keeps the lo halves of small entries normal
+    with _Timed(f"{kn}<apply {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention apply)")
     return out
 

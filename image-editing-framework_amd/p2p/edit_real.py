@@ -27,7 +27,7 @@ parser.add_argument("--target_prompt", type=str, default="a whie horse in the fi
 parser.add_argument("--source_image", type=str, default="./test.jpg")
 parser.add_argument("--inversion_type", type=str, default="null-text")
 # not a reference flag: "f32" = the reference's own precision (fp32 weights / activations; ddim inversion only)
-parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32"])
+parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32", "f16x3"])
 
 
 def edit_latent(pipe, editor, x_T, source_prompt, target_prompt, edit_type, device, extra=None, num_inference_steps=50,

@@ -24,7 +24,7 @@ parser.add_argument("--source_prompt", type=str, default="a photo of a house on 
 parser.add_argument("--target_prompt", type=str, default="a photo of a house on a mountain at fall")
 # not a reference flag: "f32" = the reference's own precision (it loads the pipeline in fp32, edit_syn.py:38) on the fp32-MFMA
 # kernels; "f16" (default) = fp16 storage with fp32 accumulation
-parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32"])
+parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32", "f16x3"])
 
 
 def main(argv=None):

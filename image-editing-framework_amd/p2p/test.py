@@ -120,7 +120,7 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=0, help="use N generated images instead of ./PIE")
     ap.add_argument("--no_save", action="store_true")
     ap.add_argument("--invert_batch", type=int, default=1, help="images inverted per batched DDIM loop")
-    ap.add_argument("--precision", type=str, default="f16", choices=["f16", "f32"],
+    ap.add_argument("--precision", type=str, default="f16", choices=["f16", "f32", "f16x3"],
                     help="f32: the reference's own precision on the fp32-MFMA kernels (ddim inversion only)")
     ap.add_argument("--in_flight", type=int, default=1,
                     help="independent images stepped concurrently on one GPU (null-text optimisations and edits)")

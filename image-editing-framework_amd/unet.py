@@ -497,12 +497,16 @@ class TimestepEmbedding(nn.Module):
 class UNet2DConditionModel(nn.Module):
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", precision: str = "f16"):
         """precision: "f16" — fp16 storage, fp32 accumulation (the fast path); "f32" — the reference's precision
-        (`/root/reference/p2p/edit_syn.py:38`): fp32 weights and activations on the fp32-input MFMA kernels"""
+        (`/root/reference/p2p/edit_syn.py:38`): fp32 weights and activations on the fp32-input MFMA kernels; "f16x3" — fp32
+        weights and activations, every contraction on split fp16 operands (hi + lo halves, three fp16 MFMAs per product,
+        `csrc/split_x3.hip`): ~21 operand bits at a third of the fp16 matrix rate"""
         super().__init__()
         global _PACK
-        if precision not in ("f16", "f32"):
-            raise ValueError('precision must be "f16" or "f32"')
-        saved, _PACK = _PACK, (torch.float32 if precision == "f32" else torch.float16)
+        if precision not in ("f16", "f32", "f16x3"):
+            raise ValueError('precision must be "f16", "f32" or "f16x3"')
+        self.precision = precision
+        self.contract = "x3" if precision == "f16x3" else "f32"       # hip.f32_contraction mode of this model's calls
+        saved, _PACK = _PACK, (torch.float16 if precision == "f16" else torch.float32)
         try:
             self._build(cfg, state_dict, device)
         finally:
@@ -621,6 +625,20 @@ class UNet2DConditionModel(nn.Module):
         return out
 
     def aug_embedding(self, added_cond_kwargs):
+        with hip.f32_contraction(self.contract):
+            return self._aug_embedding(added_cond_kwargs)
+
+    def time_rows(self, timesteps_f32, aug=None):
+        with hip.f32_contraction(self.contract):
+            return self._time_rows(timesteps_f32, aug)
+
+    def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None,
+                added_cond_kwargs=None, return_dict=True, temb_row=None, taps=None, **kw):
+        with hip.f32_contraction(self.contract):
+            return self._forward(sample, timestep, encoder_hidden_states, cross_attention_kwargs, added_cond_kwargs,
+                                 return_dict, temb_row, taps, **kw)
+
+    def _aug_embedding(self, added_cond_kwargs):
         """SDXL: fp16 [B, time_embed_dim] = add_embedding(cat([text_embeds, sinusoids of the 6 time ids])) — constant over
         the steps of one edit (`/root/reference/pix2pix-zero/model/sd_utils.py:408-421` builds the kwargs)"""
         if not self.cfg.addition_embed:
@@ -633,7 +651,7 @@ class UNet2DConditionModel(nn.Module):
         tim = self.add_time_proj(ids.reshape(-1).contiguous()).reshape(B, -1)
         return self.add_embedding(torch.cat([self._act(te), tim], dim=-1).contiguous())
 
-    def time_rows(self, timesteps_f32, aug=None):
+    def _time_rows(self, timesteps_f32, aug=None):
         """fp32 [T, sum Cout]: time_emb_proj(silu(time_embedding(time_proj(t)))) for every resnet at once.
         aug (fp16 [B, time_embed_dim], `aug_embedding`): rows become [T * B, sum Cout], step-major."""
         emb = self.time_embedding(self.time_proj(timesteps_f32))
@@ -652,8 +670,8 @@ class UNet2DConditionModel(nn.Module):
         return self._temb_table
 
     # ------------------------------------------------------------------ forward
-    def forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None,
-                added_cond_kwargs=None, return_dict=True, temb_row=None, taps=None, **kw):
+    def _forward(self, sample, timestep=None, encoder_hidden_states=None, cross_attention_kwargs=None,
+                 added_cond_kwargs=None, return_dict=True, temb_row=None, taps=None, **kw):
         """sample fp32/fp16 NCHW [B,4,H,W]; timestep scalar / 0-d tensor; ctx [B,77,Cc] -> eps fp32 NCHW.
 
         `temb_row` (fp32 [1, width]) short-circuits the time embedding for the captured-graph loop."""

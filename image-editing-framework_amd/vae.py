@@ -175,12 +175,15 @@ class _MidAttention:
 class AutoencoderKL:
     def __init__(self, cfg: VAEConfig = SD_VAE, state_dict=None, device="cuda:0", seed: int = 2, precision: str = "f16"):
         global _PACK
-        saved, _PACK = _PACK, (torch.float32 if precision == "f32" else torch.float16)
+        if precision not in ("f16", "f32", "f16x3"):
+            raise ValueError('precision must be "f16", "f32" or "f16x3"')
+        saved, _PACK = _PACK, (torch.float16 if precision == "f16" else torch.float32)
         try:
             self._build(cfg, state_dict, device, seed)
         finally:
             _PACK = saved
         self.precision = precision
+        self.contract = "x3" if precision == "f16x3" else "f32"       # hip.f32_contraction mode (as unet.py)
 
     def _build(self, cfg, state_dict, device, seed):
         hip.load()
@@ -239,6 +242,15 @@ class AutoencoderKL:
     # ------------------------------------------------------------------ encode / decode
     @torch.no_grad()
     def encode(self, image):
+        with hip.f32_contraction(self.contract):
+            return self._encode(image)
+
+    @torch.no_grad()
+    def decode(self, z):
+        with hip.f32_contraction(self.contract):
+            return self._decode(z)
+
+    def _encode(self, image):
         """image fp32 NCHW [B,3,H,W] in [-1,1] -> {'latent_dist': dist}, dist.mean [B,4,H/8,W/8] fp32"""
         x = image.to(self.device, torch.float32).contiguous()
         G, eps = self.cfg.norm_num_groups, self.cfg.eps
@@ -255,8 +267,7 @@ class AutoencoderKL:
         moments = hip.pointwise_f32(moments, self.quant[0], self.quant[1])
         return {"latent_dist": _Dist(moments)}
 
-    @torch.no_grad()
-    def decode(self, z):
+    def _decode(self, z):
         """z fp32 NCHW [B,4,h,w] -> {'sample': fp32 NCHW [B,3,8h,8w]}"""
         z = z.to(self.device, torch.float32).contiguous()
         G, eps = self.cfg.norm_num_groups, self.cfg.eps

@@ -28,7 +28,7 @@ typedef uint16_t ief_half;
 extern "C" {
 #endif
 
-#define IEF_ABI_VERSION 2
+#define IEF_ABI_VERSION 3
 int ief_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char* ief_target_arch(void);
@@ -258,6 +258,12 @@ typedef struct IefGemmF32Params {
      * launch that applies the epilogue */
     int splits;
     float* ws;
+    /* ABI 3: split-operand contraction (csrc/split_x3.hip).  x3 != 0: every fp32 operand element is split into two fp16
+     * numbers (hi + lo of sa * a, of sb * w; sa, sb powers of two) while its tile is staged, the product runs on three
+     * fp16 MFMAs per k-step (Ah Bh + Al Bh + Ah Bl, fp32 accumulate) and is divided by sa * sb; same operators, operands,
+     * outputs and error codes as x3 == 0 (the fp32-input MFMA); |sa * a|, |sb * w| must stay below 1.3e5 */
+    int x3;
+    float sa, sb;
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
 int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */

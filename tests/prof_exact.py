@@ -1,4 +1,5 @@
-"""per-kernel time of ONE eager edit step in the reference-precision mode (HIP events per launch)"""
+"""per-kernel time of ONE eager edit step in an fp32-storage mode (HIP events per launch):
+    python tests/prof_exact.py [sd15] [f32 | f16x3]"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,8 +7,9 @@ import bench
 from ief_amd import hip
 from ief_amd.p2p.model.sd_utils import _encode_prompts
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "sd15"
+precision = sys.argv[2] if len(sys.argv) > 2 else "f32"
 dev = torch.device("cuda:0")
-pipe, cfg = bench.build_pipe(cfgname, dev, 0, 1, precision="f32")
+pipe, cfg = bench.build_pipe(cfgname, dev, 0, 1, precision=precision)
 pipe.scheduler.set_timesteps(50)
 with torch.no_grad():
     u, c = _encode_prompts(pipe, bench.PROMPTS)
