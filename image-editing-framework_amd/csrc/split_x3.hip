@@ -6,26 +6,40 @@
 //      hi = fp16(s x),   lo = fp16(s x - hi)            (s = a power of two, exact)
 // so that s x = hi + lo up to 2^-22 |s x| (round-to-nearest twice), and a product of two such operands is
 //      A B = (Ah Bh + Al Bh + Ah Bl) / (sa sb)   +   Al Bl / (sa sb)   <- dropped, 2^-22 relative
-// three `v_mfma_f32_32x32x16_f16` into ONE fp32 accumulator (products of two fp16 numbers are exact in fp32, so the MFMA
+// three `v_mfma_f32_16x16x32_f16` into ONE fp32 accumulator (products of two fp16 numbers are exact in fp32, so the MFMA
 // adds exact terms with fp32 rounding, as the fp32 MFMA does).  ~21 operand bits at 1/3 of the fp16 rate instead of 24 bits
-// at 1/16.  The scales keep `lo` out of the fp16 subnormal range (|lo| <= 2^-11 |hi|: with s x >= 2^-3 it is a normal
-// number) whatever the MFMA does with subnormal inputs; the host picks them per call (activations 2^4: exact up to 4096,
-// weights 2^8, softmax maps 2^14), the epilogue divides them out.  |s x| >= 65504 saturates `hi` (clamped), `lo` then carries the
-// excess up to another 65504.
+// at 1/16; measured against fp64 the results are as close as the fp32 MFMA's (tests/test_gpu_x3.py).  The scales keep `lo`
+// out of the fp16 subnormal range for elements of ordinary size (|lo| <= 2^-11 |hi|: a normal number once |s x| >= 2^-3;
+// smaller elements keep an absolute resolution of 2^-25 / s — gfx950's MFMA does not flush fp16 subnormals); the host
+// picks them per call (activations 2^4, weights 2^8, softmax maps 2^14), the epilogue divides them out.  `hi` is clamped to
+// +-65504, `lo` then carries the excess: elements up to 1.3e5 / s stay finite.
 //
-//   igemm_x3_kernel<CONV, TRANSB, NT>   same operator set, parameter struct and tile grid as igemm_f32_kernel
-//                                       (linear / 1x1 / 3x3 implicit GEMM with concat sources, nearest-2x, stride 2, fused
-//                                       1x1 shortcut sources, the two batched attention products, split-K slabs)
-//   attn_flash_x3_kernel<D>             fused attention without materialised maps: S^T = K Q^T and O^T += V^T P^T on split
-//                                       operands, softmax in fp32 registers
+//   igemm_x3_kernel<WM, WN, TM, TN, CONV, TRANSB>
+//       the operator set and parameter struct of igemm_f32_kernel (linear / 1x1 / 3x3 implicit GEMM with concat sources,
+//       nearest-2x, stride 2, fused 1x1 shortcut sources, the two batched attention products, split-K slabs).
+//       Tile (16 WM TM) x (16 WN TN) x 32, WM x WN waves, each TM x TN MFMA blocks of 16 x 16.  The MFMA's A operand is the
+//       WEIGHT block, its B operand the activation block: a lane then owns one output row m and four consecutive columns
+//       n — one 16-byte store (and 16-byte bias / residual loads) per block.  Operand tiles are fetched TWO K tiles ahead
+//       into registers (two register sets), split and written to a double-buffered LDS image one tile ahead; LDS rows of
+//       48 halves (96 B): conflict-free ds_read_b128 fragments of the 16x16x32 layout and ds_write_b64 staging.
+//   attn_flash_x3_kernel<D>             fused attention without materialised maps (below)
 #include "ief_common.h"
 #include "ief_params.h"
 
-#define YBM 128
 #define YBK 32
-#define YLD 40          // halves per LDS row (80 B): b128 fragment reads and b64 staging writes are conflict-free
+#define YLD 48          // halves per LDS row: 32 of the K tile + 16 of padding (96 B)
+
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
 
 struct RowCoordY { int b, oy, ox, ok; };
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload(rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
 
 // s x -> (hi, lo) for four consecutive k
 __device__ __forceinline__ void split4(const f32x4 v, const float s, half4& hi, half4& lo) {
@@ -38,20 +52,24 @@ __device__ __forceinline__ void split4(const f32x4 v, const float s, half4& hi, 
     lo = __builtin_convertvector(r, half4);
 }
 
-template <bool CONV, bool TRANSB, int NT>
-__global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IefGemmF32Params p) {
-    constexpr int YBN = 64 * NT;
-    constexpr int ROWS = YBM + YBN;
+template <int WM, int WN, int TM, int TN, bool CONV, bool TRANSB, bool SLOW>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3_kernel(const IefGemmF32Params p) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
+    constexpr int ROWS = BM + BN;
+    constexpr int NA = (BM * 8 + NTH - 1) / NTH;            // 16-byte chunks of the A tile per thread
+    constexpr int NB = (BN * 8 + NTH - 1) / NTH;
+    constexpr bool A_EXACT = (BM * 8) % NTH == 0, B_EXACT = (BN * 8) % NTH == 0;
     // per buffer: [A hi][A lo][B hi][B lo], rows of YLD halves
     __shared__ __attribute__((aligned(16))) half_t smem_y[2 * 2 * ROWS * YLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int ntn = (p.N + YBN - 1) / YBN;
-    const int ntiles = ((p.M + YBM - 1) / YBM) * ntn;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int ntiles = ((p.M + BM - 1) / BM) * ntn;
     const int bid = xcd_remap(blockIdx.x, ntiles);
     const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int m0 = tm * YBM, n0 = tn * YBN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const float* A = p.A;
     const float* W = p.W;
     float* Out = p.Out;
@@ -64,14 +82,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IefGemmF32Params
     }
     const int M = p.M, N = p.N, K = p.K;
     const float sa = p.sa, sb = p.sb;
-    // ---- loader assignment: A tile = 128 rows x 8 chunks of 4 floats; thread -> 4 rows (32 apart), one chunk column
-    const int a_kc = tid & 7, a_r0 = tid >> 3;
-    RowCoordY rc[4];
+    // ---- loader assignment: chunk c = tid + NTH i of a tile = (row c >> 3, 4 floats at k = 4 (c & 7))
+    const int kc4 = (tid & 7) * 4, r0 = tid >> 3;
+    constexpr int RSTEP = NTH / 8;
+    RowCoordY rc[NA];
     if (CONV) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + a_r0 + 32 * i;
-            rc[i].ok = m < M;
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + r0 + RSTEP * i;
+            rc[i].ok = m < M && (A_EXACT || r0 + RSTEP * i < BM);
             const int mm = rc[i].ok ? m : 0;
             const int hw = p.Ho * p.Wo;
             rc[i].b = mm / hw;
@@ -84,24 +103,73 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IefGemmF32Params
     const int pad_lo = p.pad_hi_only ? 0 : 1;
     const int Hs = p.ups ? (p.H >> 1) : p.H, Ws = p.ups ? (p.Wd >> 1) : p.Wd;   // dims of the stored source
 
-    f32x4 ra[4], rb[2 * NT];
-    auto load_tile = [&](int k0) {
-        const int kk = k0 + a_kc * 4;
-        if (CONV) {
+    // split-K (grid.y): this workgroup's K tiles [kt0, kt0 + nk); the partial tile goes to an fp32 slab, a second launch sums
+    // the slabs in slab order and applies the epilogue
+    const int nk_all = (K + YBK - 1) / YBK;
+    int kt0 = 0, nk = nk_all;
+    if (p.splits > 1) {
+        const int per = (nk_all + p.splits - 1) / p.splits;
+        kt0 = blockIdx.y * per;
+        nk = min(per, nk_all - kt0);
+        if (nk < 0) nk = 0;
+    }
+    const int kend = min(K, (kt0 + nk) * YBK);       // loads past this workgroup's K range read zeros
+    // Every operand is read through a buffer descriptor (wave-uniform: kernel arguments and blockIdx only) with a per-lane
+    // byte offset: an element outside the tensor, the K range or the image (3x3 padding) is a lane whose offset is pushed
+    // past the descriptor's size and reads zeros -- no branch around any load, so the loads of a tile issue back to back and
+    // stay in flight under the MFMAs of two K tiles.
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const rsrc_t rA = make_rsrc(A, p.bytesA), rW = make_rsrc(W, p.bytesW);
+    const rsrc_t rA2 = make_rsrc(p.A2, p.bytesA2), rE1 = make_rsrc(p.E1, p.bytesE1), rE2 = make_rsrc(p.E2, p.bytesE2);
+    // SLOW instantiations hold the general loaders (a convolution whose channel counts are not multiples of 32: a K tile then
+    // straddles taps / sources; A rows that are not 16-byte chunked) -- kept out of the fast kernels, whose K loop is then one
+    // basic block: the compiler counts the outstanding loads exactly (branches inside the loop made it wait for vmcnt(0))
+    // running decode of the next K tile to load (tiles are requested in order): tap, first channel inside the tap
+    int l_tap = 0, l_ch = 0;
+
+    auto load_tile = [&](int k0, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+        const int kk = k0 + kc4;
+        if (CONV && !SLOW) {
+            // uniform decode of the tile: mode 1 = 3x3 tap (ky, kx) of source 1 / 2, mode 2 = 1x1 extra source 1 / 2
+            rsrc_t rs = rA;
+            int cs = p.C1, chs = l_ch, ky = 0, kx = 0;
+            const bool tapm = l_tap < 9;
+            if (tapm) {
+                ky = (l_tap * 11) >> 5; kx = l_tap - 3 * ky;
+                if (l_ch >= p.C1) { rs = rA2; cs = p.C2; chs = l_ch - p.C1; }
+            } else if (l_ch < p.CE1) { rs = rE1; cs = p.CE1; }
+            else { rs = rE2; cs = p.CE2; chs = l_ch - p.CE1; }
+            // no branch below: uniform selects, bitwise predicates
+            const int kin = k0 < kend ? 1 : 0;
+            const int st = tapm ? p.stride : 1, dy = tapm ? ky - pad_lo : 0, dx = tapm ? kx - pad_lo : 0;
+            const unsigned Hc = tapm ? p.H : p.Ho, Wc = tapm ? p.Wd : p.Wo;       // bounds of the image the tap samples
+            const int sh = (tapm && p.ups) ? 1 : 0;
+            const int hs = tapm ? Hs : p.Ho, ws = tapm ? Ws : p.Wo;               // dims of the stored source
+            const int cb = chs + kc4;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int iy = rc[i].oy * st + dy, ix = rc[i].ox * st + dx;
+                const int ok = rc[i].ok & kin & ((unsigned)iy < Hc ? 1 : 0) & ((unsigned)ix < Wc ? 1 : 0);
+                const unsigned off = (unsigned)((((rc[i].b * hs + (iy >> sh)) * ws + (ix >> sh)) * cs + cb) * 4);
+                ra[i] = bload(rs, ok ? off : OOB);
+            }
+            l_ch += YBK;                       // advance the decode by one K tile
+            if (l_tap < 9 && l_ch >= Ct) { l_ch -= Ct; ++l_tap; }
+        } else if (CONV) {               // SLOW
             const float* src = nullptr;
             int cs = 0, chs = 0, ky = 0, kx = 0, mode = 0;       // mode 0: zero, 1: 3x3 tap, 2: 1x1 extra source
-            if (kk < K9) {
+            if (kk < K9 && kk < kend) {
                 const int tap = kk / Ct, ch = kk - tap * Ct;
                 ky = tap / 3; kx = tap - 3 * ky;
                 if (ch < p.C1) { src = p.A; cs = p.C1; chs = ch; } else { src = p.A2; cs = p.C2; chs = ch - p.C1; }
                 mode = 1;
-            } else if (kk < K) {
+            } else if (kk < kend) {
                 const int ch2 = kk - K9;
                 if (ch2 < p.CE1) { src = p.E1; cs = p.CE1; chs = ch2; } else { src = p.E2; cs = p.CE2; chs = ch2 - p.CE1; }
                 mode = 2;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (rc[i].ok && mode == 1) {
                     int iy = rc[i].oy * p.stride + ky - pad_lo, ix = rc[i].ox * p.stride + kx - pad_lo;
@@ -114,70 +182,75 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IefGemmF32Params
                 }
                 ra[i] = v;
             }
-        } else {
+        } else if (!SLOW) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + a_r0 + 32 * i;
+            for (int i = 0; i < NA; ++i) {
+                const int ml = r0 + RSTEP * i, m = m0 + ml;
+                const bool ok = (m < M) & (kk < kend) & (A_EXACT || ml < BM);
+                ra[i] = bload(rA, ok ? (unsigned)((m * p.lda + kk) * 4) : OOB);
+            }
+        } else {                        // rows of 77 keys: neither the row stride nor K is a multiple of 4 floats
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + r0 + RSTEP * i;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < M && kk < K) {
+                if (m < M && kk < kend && (A_EXACT || r0 + RSTEP * i < BM)) {
                     const float* ap = A + (long long)m * p.lda + kk;
-                    if (!p.a_scalar) v = *(const f32x4*)ap;
-                    else {                      // rows of 77 keys: neither the row stride nor K is a multiple of 4 floats
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (kk + j < K) v[j] = ap[j];
-                    }
+                    for (int j = 0; j < 4; ++j) if (kk + j < K) v[j] = ap[j];
                 }
                 ra[i] = v;
             }
         }
-        if (!TRANSB) {                  // W [N][K]: rows n0 + a_r0 + 32 i
+        if (!TRANSB) {                  // W [N][K]: rows n0 + r0 + RSTEP i
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) {
-                const int n = n0 + a_r0 + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < N && kk < K) v = *(const f32x4*)(W + (long long)n * p.ldw + kk);
-                rb[i] = v;
+            for (int i = 0; i < NB; ++i) {
+                const int nl = r0 + RSTEP * i, n = n0 + nl;
+                const bool ok = (n < N) & (kk < kend) & (B_EXACT || nl < BN);
+                rb[i] = bload(rW, ok ? (unsigned)((n * p.ldw + kk) * 4) : OOB);
             }
-        } else {                        // W [K][N]: thread -> k row (tid & 31), chunk columns (tid >> 5) + 8 i of 4 n each
-            const int kr = k0 + (tid & 31);
+        } else {                        // W [K][N]: chunk c = tid + NTH i -> k row c & 31, 4 columns at 4 (c >> 5)
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) {
-                const int n = n0 + ((tid >> 5) + 8 * i) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kr < K && n < N) v = *(const f32x4*)(W + (long long)kr * p.ldw + n);   // N % 4 == 0 (host-checked)
-                rb[i] = v;
+            for (int i = 0; i < NB; ++i) {
+                const int c = tid + NTH * i;
+                const int kr = k0 + (c & 31), nl = (c >> 5) * 4, n = n0 + nl;
+                const bool ok = (kr < kend) & (n < N) & (B_EXACT || nl < BN);     // N % 4 == 0 (host-checked)
+                rb[i] = bload(rW, ok ? (unsigned)((kr * p.ldw + n) * 4) : OOB);
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
         half_t* ah = smem_y + buf * (2 * ROWS * YLD);
-        half_t* al = ah + YBM * YLD;
-        half_t* bh = al + YBM * YLD;
-        half_t* bl = bh + YBN * YLD;
+        half_t* al = ah + BM * YLD;
+        half_t* bh = al + BM * YLD;
+        half_t* bl = bh + BN * YLD;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
+            if (!A_EXACT && r0 + RSTEP * i >= BM) continue;
             half4 h, l;
             split4(ra[i], sa, h, l);
-            const int off = (a_r0 + 32 * i) * YLD + a_kc * 4;
+            const int off = (r0 + RSTEP * i) * YLD + kc4;
             *(half4*)(ah + off) = h;
             *(half4*)(al + off) = l;
         }
         if (!TRANSB) {
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) {
+            for (int i = 0; i < NB; ++i) {
+                if (!B_EXACT && r0 + RSTEP * i >= BN) continue;
                 half4 h, l;
                 split4(rb[i], sb, h, l);
-                const int off = (a_r0 + 32 * i) * YLD + a_kc * 4;
+                const int off = (r0 + RSTEP * i) * YLD + kc4;
                 *(half4*)(bh + off) = h;
                 *(half4*)(bl + off) = l;
             }
         } else {
-            const int kr = tid & 31;
 #pragma unroll
-            for (int i = 0; i < 2 * NT; ++i) {
+            for (int i = 0; i < NB; ++i) {
+                const int c = tid + NTH * i;
+                const int kr = c & 31, nl = (c >> 5) * 4;
+                if (!B_EXACT && nl >= BN) continue;
                 half4 h, l;
                 split4(rb[i], sb, h, l);
-                const int nl = ((tid >> 5) + 8 * i) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bh[(nl + j) * YLD + kr] = h[j];
@@ -187,114 +260,156 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IefGemmF32Params
         }
     };
 
-    f32x16 acc[2][NT];
+    f32x4 acc[TN][TM];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int a = 0; a < TM; ++a) acc[b][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // split-K (grid.y): this workgroup's K tiles [kt0, kt0 + nk); the partial tile goes to an fp32 slab, a second launch sums
-    // the slabs in slab order and applies the epilogue
-    const int nk_all = (K + YBK - 1) / YBK;
-    int kt0 = 0, nk = nk_all;
-    if (p.splits > 1) {
-        const int per = (nk_all + p.splits - 1) / p.splits;
-        kt0 = blockIdx.y * per;
-        nk = min(per, nk_all - kt0);
-        if (nk < 0) nk = 0;
-    }
-    if (nk > 0) {
-        load_tile(kt0 * YBK);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt0 + kt + 1) * YBK);
-        const half_t* ah = smem_y + buf * (2 * ROWS * YLD) + (wm * 64 + li) * YLD + 8 * lh;
-        const half_t* al = ah + YBM * YLD;
-        const half_t* bh = smem_y + buf * (2 * ROWS * YLD) + 2 * YBM * YLD + (wn * 32 * NT + li) * YLD + 8 * lh;
-        const half_t* bl = bh + YBN * YLD;
+    auto mma_tile = [&](int buf) {
+        const half_t* ah = smem_y + buf * (2 * ROWS * YLD) + (wm * TM * 16 + lr) * YLD + 8 * lg;
+        const half_t* al = ah + BM * YLD;
+        const half_t* bh = smem_y + buf * (2 * ROWS * YLD) + 2 * BM * YLD + (wn * TN * 16 + lr) * YLD + 8 * lg;
+        const half_t* bl = bh + BN * YLD;
+        half8_t fah[TM], fal[TM];
 #pragma unroll
-        for (int ks = 0; ks < YBK / 16; ++ks) {
-            half8 fah[2], fal[2], fbh[NT], fbl[NT];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                fah[a] = *(const half8*)(ah + a * 32 * YLD + ks * 16);
-                fal[a] = *(const half8*)(al + a * 32 * YLD + ks * 16);
-            }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                fbh[b] = *(const half8*)(bh + b * 32 * YLD + ks * 16);
-                fbl[b] = *(const half8*)(bl + b * 32 * YLD + ks * 16);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[b], acc[a][b], 0, 0, 0);
-                }
+        for (int a = 0; a < TM; ++a) {
+            fah[a] = *(const half8_t*)(ah + a * 16 * YLD);
+            fal[a] = *(const half8_t*)(al + a * 16 * YLD);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const half8_t fbh = *(const half8_t*)(bh + b * 16 * YLD);
+            const half8_t fbl = *(const half8_t*)(bl + b * 16 * YLD);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl, fah[a], acc[b][a], 0, 0, 0);
+                acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh, fal[a], acc[b][a], 0, 0, 0);
+                acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh, fah[a], acc[b][a], 0, 0, 0);
+            }
+        }
+    };
+
+    if (CONV && !SLOW) {                     // decode of this workgroup's first K tile
+        const int k0 = kt0 * YBK;
+        if (k0 < K9) { l_tap = k0 / Ct; l_ch = k0 - l_tap * Ct; } else { l_tap = 9; l_ch = k0 - K9; }
+    }
+    // register set s holds tile t with (t & 1) == s; LDS buffer (t & 1) holds tile t
+    f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    // tiles past the K range load zeros and multiply zeros: no branch in the loop (an odd tile count costs one idle pass)
+    load_tile(kt0 * YBK, ra0, rb0);
+    load_tile((kt0 + 1) * YBK, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        load_tile((kt0 + kt + 2) * YBK, ra0, rb0);
+        mma_tile(0);
+        store_tile(1, ra1, rb1);
+        __syncthreads();
+        load_tile((kt0 + kt + 3) * YBK, ra1, rb1);
+        mma_tile(1);
+        store_tile(0, ra0, rb0);
         __syncthreads();
     }
     const float inv = 1.0f / (sa * sb);
-    if (p.splits > 1) {       // raw partial sums (already in output units)
+    // lane: output row m (lane & 15 of the block), columns n .. n + 3 (4 (lane >> 4) of the block)
+    const bool vec = p.vec_out != 0;
+    if (p.splits > 1) {       // raw partial sums (already in output units); ws rows are N floats, N % 4 == 0 whenever vec
         float* slab = p.ws + (long long)blockIdx.y * M * N;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < TM; ++a) {
+            const int m = m0 + (wm * TM + a) * 16 + lr;
+            if (m >= M) continue;
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int n = n0 + wn * 32 * NT + b * 32 + li;
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + (wn * TN + b) * 16 + 4 * lg;
                 if (n >= N) continue;
+                const f32x4 v = acc[b][a] * inv;
+                if ((N & 3) == 0) *(f32x4*)(slab + (long long)m * N + n) = v;
+                else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < M) slab[(long long)m * N + n] = acc[a][b][r] * inv;
+                    for (int j = 0; j < 4; ++j) if (n + j < N) slab[(long long)m * N + n + j] = v[j];
                 }
             }
+        }
         return;
     }
     // ---- epilogue: (acc + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]) * out_scale, fp32
     const float* R = p.residual;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a) {
+        const int m = m0 + (wm * TM + a) * 16 + lr;
+        if (m >= M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (long long)(m / p.rows_per_batch) * N : nullptr;
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-            const int n = n0 + wn * 32 * NT + b * 32 + li;
+        for (int b = 0; b < TN; ++b) {
+            const int n = n0 + (wn * TN + b) * 16 + 4 * lg;
             if (n >= N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
+            f32x4 v = acc[b][a] * inv;
+            if (vec) {
+                if (p.bias) v += *(const f32x4*)(p.bias + n);
+                if (rv) v += *(const f32x4*)(rv + n);
+                if (R) v += *(const f32x4*)(R + (long long)m * p.ldr + n);
+                *(f32x4*)(Out + (long long)m * p.ldo + n) = v * p.out_scale;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= M) continue;
-                float v = acc[a][b][r] * inv + bv;
-                if (p.rowvec) v += p.rowvec[(long long)(m / p.rows_per_batch) * N + n];
-                if (R) v += R[(long long)m * p.ldr + n];
-                Out[(long long)m * p.ldo + n] = v * p.out_scale;
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= N) break;
+                    float s = v[j];
+                    if (p.bias) s += p.bias[n + j];
+                    if (rv) s += rv[n + j];
+                    if (R) s += R[(long long)m * p.ldr + n + j];
+                    Out[(long long)m * p.ldo + n + j] = s * p.out_scale;
+                }
             }
         }
+    }
 }
 
-template <bool CONV, bool TRANSB, int NT>
+// column-tile width for N output columns: 80 where it divides N (every SD width is a multiple of 320), else 64
+extern "C" int ief_gemm_x3_bn(int N) { return (N % 80 == 0) ? 80 : 64; }
+extern "C" int ief_gemm_x3_bm(void) { return 128; }
+
+template <int WM, int WN, int TM, int TN, bool CONV, bool TRANSB, bool SLOW>
 static int launch_igemm_x3(const IefGemmF32Params& p, hipStream_t st) {
-    constexpr int YBN = 64 * NT;
-    const int tiles = ((p.M + YBM - 1) / YBM) * ((p.N + YBN - 1) / YBN);
+    constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int z = p.heads > 0 ? p.batch * p.heads : 1;
     const int splits = p.splits > 1 ? p.splits : 1;
-    hipLaunchKernelGGL((igemm_x3_kernel<CONV, TRANSB, NT>), dim3(tiles, splits, z), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_x3_kernel<WM, WN, TM, TN, CONV, TRANSB, SLOW>), dim3(tiles, splits, z), dim3(64 * WM * WN), 0, st, p);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
 
 // called by ief_gemm_f32 (exact_f32.hip) after its argument checks when p.x3 != 0; the split-K reducer launch is the caller's
-int ief_gemm_x3_dispatch(const IefGemmF32Params& p, hipStream_t st) {
-    const bool wide = ief_gemm_f32_bn(p.N) != 64;
-    if (p.conv) return wide ? launch_igemm_x3<true, false, 2>(p, st) : launch_igemm_x3<true, false, 1>(p, st);
-    if (p.transb) return wide ? launch_igemm_x3<false, true, 2>(p, st) : launch_igemm_x3<false, true, 1>(p, st);
-    return wide ? launch_igemm_x3<false, false, 2>(p, st) : launch_igemm_x3<false, false, 1>(p, st);
+int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
+    IefGemmF32Params p = pin;
+    // 16-byte epilogue accesses need 16-byte aligned rows of every operand the epilogue touches
+    const bool al = ((p.N & 3) == 0) && ((p.ldo & 3) == 0) && (((uintptr_t)p.Out & 15) == 0) &&
+                    (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.rowvec || ((uintptr_t)p.rowvec & 15) == 0) &&
+                    (!p.residual || (((uintptr_t)p.residual & 15) == 0 && (p.ldr & 3) == 0)) &&
+                    (p.heads == 0 || (((p.sOb | p.sOh) & 3) == 0));
+    p.vec_out = al ? 1 : 0;
+    // descriptor sizes (bytes reachable from each operand's base; batched: from the (batch row, head) base)
+    const unsigned long long lim = 0xFFFFFFF0ull;
+    unsigned long long bA, bW, bA2 = 0, bE1 = 0, bE2 = 0;
+    if (p.conv) {
+        const unsigned long long px = (unsigned long long)p.batch_images * (p.ups ? (p.H >> 1) * (p.Wd >> 1) : p.H * p.Wd);
+        bA = px * p.C1 * 4; bA2 = px * p.C2 * 4;
+        bE1 = (unsigned long long)p.M * p.CE1 * 4; bE2 = (unsigned long long)p.M * p.CE2 * 4;
+        p.al32 = ((p.C1 | p.C2 | p.CE1 | p.CE2) & 31) == 0 ? 1 : 0;
+    } else {
+        bA = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 4;
+        p.al32 = 0;
+    }
+    bW = p.transb ? ((unsigned long long)(p.K - 1) * p.ldw + p.N) * 4 : ((unsigned long long)(p.N - 1) * p.ldw + p.K) * 4;
+    if (bA >= lim || bW >= lim || bA2 >= lim || bE1 >= lim || bE2 >= lim) return IEF_ESHAPE;      // 32-bit buffer offsets
+    p.bytesA = (unsigned)bA; p.bytesW = (unsigned)bW; p.bytesA2 = (unsigned)bA2; p.bytesE1 = (unsigned)bE1; p.bytesE2 = (unsigned)bE2;
+    const bool n80 = ief_gemm_x3_bn(p.N) == 80;
+#define X3_GO(CONV_, TRANSB_, SLOW_) (n80 ? launch_igemm_x3<4, 1, 2, 5, CONV_, TRANSB_, SLOW_>(p, st) \
+                                          : launch_igemm_x3<2, 2, 4, 2, CONV_, TRANSB_, SLOW_>(p, st))
+    if (p.conv) return p.al32 ? X3_GO(true, false, false) : X3_GO(true, false, true);
+    if (p.transb) return p.a_scalar ? X3_GO(false, true, true) : X3_GO(false, true, false);
+    return p.a_scalar ? X3_GO(false, false, true) : X3_GO(false, false, false);
+#undef X3_GO
 }

@@ -92,7 +92,9 @@ class IefGemmF32Params(Structure):
         ("sAb", c_longlong), ("sAh", c_longlong), ("sWb", c_longlong), ("sWh", c_longlong), ("sOb", c_longlong), ("sOh", c_longlong),
         ("a_src", c_void_p), ("w_src", c_void_p), ("transb", c_int), ("a_scalar", c_int),
         ("splits", c_int), ("ws", c_void_p),
-        ("x3", c_int), ("sa", c_float), ("sb", c_float),
+        ("x3", c_int), ("sa", c_float), ("sb", c_float), ("vec_out", c_int), ("al32", c_int),
+        ("bytesA", ctypes.c_uint), ("bytesW", ctypes.c_uint), ("bytesA2", ctypes.c_uint), ("bytesE1", ctypes.c_uint),
+        ("bytesE2", ctypes.c_uint),
     ]
 
 
@@ -121,7 +123,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm",
 ]
 
 
@@ -848,9 +850,10 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
 def _splits_f32(lib, p, M, N, K, device):
     """split-K for the fp32 GEMM when M x N alone gives too few 128-row tiles for the 256 CUs (the 16x16 / 8x8 levels):
     aim at ~512 workgroups, every slice keeping >= 4 K tiles of 32"""
-    tiles = -(-M // 128) * -(-N // lib.ief_gemm_f32_bn(N))
+    x3 = _F32_CONTRACT == "x3"
+    tiles = -(-M // 128) * -(-N // (lib.ief_gemm_x3_bn(N) if x3 else lib.ief_gemm_f32_bn(N)))
     nk = -(-K // 32)
-    if tiles >= 256 or nk < 8:
+    if tiles >= (384 if x3 else 256) or nk < 8:       # x3 tiles: two workgroups per CU
         return None
     splits = max(1, min(-(-512 // tiles), nk // 4, 16))
     if splits <= 1:

@@ -264,8 +264,14 @@ typedef struct IefGemmF32Params {
      * outputs and error codes as x3 == 0 (the fp32-input MFMA); |sa * a|, |sb * w| must stay below 1.3e5 */
     int x3;
     float sa, sb;
+    /* set by the library (x3): every epilogue operand allows 16-byte accesses; conv channel counts are all multiples of
+     * 32; bytes reachable from A / W / A2 / E1 / E2 (buffer descriptor sizes: each must stay below 4 GiB) */
+    int vec_out, al32;
+    unsigned bytesA, bytesW, bytesA2, bytesE1, bytesE2;
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
+int ief_gemm_x3_bn(int N);    /* x3 != 0: output-tile width (80 or 64) for N columns; ief_gemm_x3_bm(): its row count (128) */
+int ief_gemm_x3_bm(void);
 int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */
 /* fused fp32 attention (maps never written): out[b] = softmax(scale q[q_src[b]] k[k_src[b]]^T) v[v_src[b]]; q [B][N][heads*d]
  * (row stride ldq, batch stride sQb; likewise k, v over L keys and out); d in {32, 40, 64, 80, 160}; *_src NULL = identity */

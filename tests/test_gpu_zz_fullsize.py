@@ -172,3 +172,59 @@ def test_sdxl_full_size_forward_b1():
     gc.collect()
     torch.cuda.empty_cache()
     assert e < FWD_TOL
+
+
+# ------------------------------------------------------------------------------------------- the reference's unit of work
+EDIT50 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sd15_edit50.npz")
+# image bound: north_star's "edited images within 1e-3 max-abs of reference" for the modes that compute at the reference's
+# precision; the fp16-storage path is held to what it measures (printed), not to 1e-3
+EDIT50_BOUNDS = {"f32": dict(lat=2e-4, img=1e-3, u8=1), "f16x3": dict(lat=2e-4, img=1e-3, u8=1), "f16": dict(lat=5e-2, img=6e-2, u8=16)}
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "f16"])
+def test_sd15_edit50_vs_oracle_fixture(precision):
+    """ONE FULL 50-step Prompt-to-Prompt edit at SD1.5 size (`/root/reference/p2p/model/sd_utils.py:24-65`: 512x512, UNet
+    batch 4, CLI default prompts, AttentionRefine 0.8 / 0.4, guidance 7.5, seed 8888) in the captured step graph, against
+    the trajectory `oracle.p2p_ref.edit_loop` computed on the CPU in fp32 (fixture G13, `tests/golden/make_golden_edit50.py`,
+    ~25 CPU-minutes: not recomputable inside the GPU suite): latents after 10 / 25 / 50 steps, then the VAE-decoded images
+    (centre crop at full resolution + the whole image average-pooled 8x8) in [0, 1] and as uint8."""
+    import numpy as np
+    from ief_amd.denoise import acquire
+    from ief_amd.p2p.model.sd_utils import _encode_prompts
+    g = np.load(EDIT50)
+    pipe = StableDiffusionPipeline.from_pretrained("synthetic:sd15", precision=precision)
+    cfg = config.SD15
+    n = int(g["steps"])
+    pipe.scheduler.set_timesteps(n)
+    with torch.no_grad():
+        u, c = _encode_prompts(pipe, PROMPTS)
+    context = torch.cat([u, c]).float()
+    probe, sums = torch.from_numpy(g["context_probe"]), g["context_sums"]
+    assert torch.allclose(context[:, :8, :16].cpu(), probe, rtol=0, atol=1e-6), "the regenerated context is not the fixture's"
+    assert abs(context.double().sum().item() - sums[0]) < 1e-2 and abs(context.double().abs().sum().item() - sums[1]) < 1e-2
+    x_T = torch.from_numpy(g["x_T"])
+    assert torch.equal(x_T, torch.randn(1, 4, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(8888)))
+    ctl = AttentionRefine(PROMPTS, pipe.tokenizer, n, 0.8, 0.4, device=DEV)
+    register_attention_control(pipe, ctl)
+    assert pipe.unet._plan is not None and pipe.unet._plan.kind == "p2p"
+    loop = acquire(pipe, context.to(DEV), 2, (cfg.sample_size, cfg.sample_size), 7.5)
+    assert loop.use_graph
+    lat, traj = loop.run(x_T.to(DEV).expand(2, -1, -1, -1), keep_all=True)
+    loop.release()
+    assert ctl.cur_step == n and ctl.cur_att_layer == 0
+    unregister_attention_control(pipe, ctl)
+    b = EDIT50_BOUNDS[precision]
+    errs = {k: rel_err(traj[k], torch.from_numpy(g[f"lat_{k}"])) for k in (10, 25, 50)}
+    dec = pipe.vae.decode(lat / pipe.vae.config.scaling_factor)["sample"].float().cpu()
+    a = int(g["crop_origin"])
+    to01 = lambda t: (t / 2 + 0.5).clamp(0, 1)
+    d_crop = (to01(dec[:, :, a:a + 64, a:a + 64]) - to01(torch.from_numpy(g["img_crop"]))).abs().max().item()
+    d_pool = (torch.nn.functional.avg_pool2d(dec, 8) - torch.from_numpy(g["img_pool8"])).abs().max().item() / 2
+    u8 = p2p_ref.latent_to_uint8(dec)[:, a:a + 64, a:a + 64].astype(int) - g["img_u8_crop"].astype(int)
+    print(f"sd15 50-step edit, precision={precision}: latents rel err after 10 / 25 / 50 steps "
+          f"{errs[10]:.3e} / {errs[25]:.3e} / {errs[50]:.3e}; decoded images in [0,1]: crop max |diff| {d_crop:.3e}, "
+          f"8x8-pooled whole image {d_pool:.3e}; uint8 crop: max diff {abs(u8).max()}, identical {(u8 == 0).mean():.4f}")
+    del pipe, loop
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert max(errs.values()) < b["lat"] and d_crop <= b["img"] and d_pool <= b["img"] and abs(u8).max() <= b["u8"]
