@@ -285,6 +285,7 @@ extern "C" int ief_struct_size(int which) {
         case 3: return (int)sizeof(IefAttnBwdParams);
         case 4: return (int)sizeof(IefMapLossParams);
         case 5: return (int)sizeof(IefGemmF32Params);
+        case 6: return (int)sizeof(IefAttnF32Params);
         default: return -1;
     }
 }

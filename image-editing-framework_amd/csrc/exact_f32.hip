@@ -453,6 +453,8 @@ __global__ __launch_bounds__(256) void attn_flash_f32_kernel(const IefAttnF32Par
     }
 }
 
+int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st);      // split_x3.hip
+
 extern "C" int ief_attn_flash_f32(const IefAttnF32Params* pp, void* stream) {
     if (!pp || !pp->Q || !pp->K || !pp->V || !pp->Out) return IEF_EINVAL;
     const IefAttnF32Params p = *pp;
@@ -460,6 +462,7 @@ extern "C" int ief_attn_flash_f32(const IefAttnF32Params* pp, void* stream) {
     if ((p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.sQb & 3) || (p.sKb & 3) || (p.sVb & 3)) return IEF_EALIGN;
     dim3 grid((p.N + 127) / 128, p.B * p.heads);
     hipStream_t st = (hipStream_t)stream;
+    if (p.x3) return ief_attn_flash_x3_dispatch(p, st);
     switch (p.d) {
         case 32: hipLaunchKernelGGL(attn_flash_f32_kernel<32>, grid, dim3(256), 0, st, p); break;
         case 40: hipLaunchKernelGGL(attn_flash_f32_kernel<40>, grid, dim3(256), 0, st, p); break;

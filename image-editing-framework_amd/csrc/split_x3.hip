@@ -413,3 +413,196 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
     return p.a_scalar ? X3_GO(false, false, true) : X3_GO(false, false, false);
 #undef X3_GO
 }
+
+// --------------------------------------------------------------------------------------------- fused attention, split operands
+// out[b] = softmax(scale * q[q_src[b]] k[k_src[b]]^T) v[v_src[b]] without materialising the maps, both products on split
+// operands (same role as attn_flash_f32_kernel, same parameter struct).  One workgroup = 128 queries of one (batch row, head),
+// a wave = 32 of them; 32-key tiles.
+//   S^T = K Q^T on v_mfma_f32_32x32x16_f16 (A = K tile hi / lo from LDS, B = this lane's query hi / lo in registers for the
+//   whole kernel): a lane owns one query COLUMN, 16 keys of the tile in its registers, the other 16 in lane + 32 -- running
+//   maximum / sum in-lane plus one cross-half exchange, in fp32 (exp2 of log2e-scaled scores).
+//   O^T += V^T P^T: the P registers of k-step s (registers 8s .. 8s+7, split into hi / lo with scale 2^14: P <= 1) are
+//   directly the B operand; its k order is key 16 s + 8 (j >> 2) + 4 h + (j & 3) for element j of lane half h, so the V^T
+//   fragment (A operand, row = head-dim index) is two 8-byte reads of a V tile kept TRANSPOSED in LDS ([d][key], hi and lo).
+// K and V tiles are fetched one tile ahead into registers through buffer descriptors (keys past L read zeros and are masked
+// to -inf), split once per workgroup and written to LDS (K rows of 16 DG + 8 halves, V^T rows of 36 halves: conflict-free
+// fragment reads).  Head dims are padded to 16 for the scores (d = 40: 48) and to 32 for O^T (d = 40: 64).
+template <int D>
+__global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(const IefAttnF32Params p) {
+    constexpr int DG = (D + 15) / 16;            // 16-deep groups of the score product
+    constexpr int DT = (D + 31) / 32;            // 32-row tiles of O^T
+    constexpr int KLD = DG * 16 + 8;             // halves per K row (bytes = 16 mod 32: conflict-free b128 fragments)
+    constexpr int VLD = 36;                      // halves per V^T row (32 keys + 4)
+    constexpr float SQ = 16.f, SK = 16.f, SV = 16.f, SP = 16384.f;
+    __shared__ __attribute__((aligned(16))) half_t smem_f[2 * 32 * KLD + 2 * DT * 32 * VLD];
+    half_t* Kh = smem_f;
+    half_t* Kl = Kh + 32 * KLD;
+    half_t* Vh = Kl + 32 * KLD;                  // [DT*32][VLD]
+    half_t* Vl = Vh + DT * 32 * VLD;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+    const int bq = p.q_src ? p.q_src[b] : b, bk = p.k_src ? p.k_src[b] : b, bv = p.v_src ? p.v_src[b] : b;
+    const float* Q = p.Q + (long long)bq * p.sQb + (long long)h * D;
+    const float* Kp = p.K + (long long)bk * p.sKb + (long long)h * D;
+    const float* Vp = p.V + (long long)bv * p.sVb + (long long)h * D;
+    float* O = p.Out + (long long)b * p.sOb + (long long)h * D;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int qi = q0 + li;
+    // zero the LDS once: padding columns of K (d >= D) and padding rows of V^T stay zero (staging never writes them)
+    for (int c = tid; c < (int)(sizeof(smem_f) / 16); c += 256) ((f32x4*)smem_f)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's query, split: for every 16-deep d group the 8 values d = 16 g + 8 lh + j
+    half8_t qh[DG], ql[DG];
+#pragma unroll
+    for (int g = 0; g < DG; ++g) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int d0 = g * 16 + 8 * lh + 4 * c2;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (qi < p.N && d0 < D) v = *(const f32x4*)(Q + (long long)qi * p.ldq + d0);
+            half4 hh, ll;
+            split4(v, SQ, hh, ll);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qh[g][4 * c2 + j] = hh[j]; ql[g][4 * c2 + j] = ll[j]; }
+        }
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = p.scale * 1.44269504088896341f / (SQ * SK);      // scores in log2 units
+    constexpr int KCH = 32 * (D / 4);            // 16-byte chunks of one K (or V) tile
+    constexpr int NLD = (KCH + 255) / 256;
+    const rsrc_t rK = make_rsrc(Kp, (unsigned)(((long long)(p.L - 1) * p.ldk + D) * 4));
+    const rsrc_t rV = make_rsrc(Vp, (unsigned)(((long long)(p.L - 1) * p.ldv + D) * 4));
+    f32x4 rk[NLD], rv[NLD];
+    auto load_kv = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / (D / 4), ch = c - row * (D / 4);
+            const bool ok = (c < KCH) & (k0 + row < p.L);
+            rk[i] = bload(rK, ok ? (unsigned)(((k0 + row) * p.ldk + ch * 4) * 4) : 0xFFFFFFF0u);
+            rv[i] = bload(rV, ok ? (unsigned)(((k0 + row) * p.ldv + ch * 4) * 4) : 0xFFFFFFF0u);
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            if (c < KCH) {
+                const int row = c / (D / 4), ch = c - row * (D / 4);
+                half4 hh, ll;
+                split4(rk[i], SK, hh, ll);
+                *(half4*)(Kh + row * KLD + ch * 4) = hh;
+                *(half4*)(Kl + row * KLD + ch * 4) = ll;
+                split4(rv[i], SV, hh, ll);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Vh[(ch * 4 + j) * VLD + row] = hh[j];
+                    Vl[(ch * 4 + j) * VLD + row] = ll[j];
+                }
+            }
+        }
+    };
+    const int nt = (p.L + 31) / 32;
+    load_kv(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();                          // everybody is done with the previous tile (first pass: the zero fill)
+        store_kv();
+        __syncthreads();
+        load_kv((t + 1) * 32);                    // past L: zeros, never stored
+        // ---- S^T tile: 32 keys x 32 queries
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < DG; ++g) {
+            const half8_t kh = *(const half8_t*)(Kh + li * KLD + g * 16 + 8 * lh);
+            const half8_t kl = *(const half8_t*)(Kl + li * KLD + g * 16 + 8 * lh);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc, 0, 0, 0);
+        }
+        // ---- online softmax over the key rows of this tile (register r <-> key (r&3) + 8 (r>>2) + 4 lh)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sacc[r] = key < p.L ? sacc[r] * sc2 : -INFINITY;
+            mx = fmaxf(mx, sacc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = exp2f(sacc[r] - m_new); ls += sacc[r]; }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+        // ---- O^T += V^T P^T, two 16-key steps; P split with scale 2^14
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            half8_t ph, pl;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const f32x4 v = {sacc[8 * s + 4 * c2], sacc[8 * s + 4 * c2 + 1], sacc[8 * s + 4 * c2 + 2], sacc[8 * s + 4 * c2 + 3]};
+                half4 hh, ll;
+                split4(v, SP, hh, ll);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
+            }
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt) {
+                const half_t* vr = Vh + (tt * 32 + li) * VLD + 16 * s + 4 * lh;
+                const half_t* vq = Vl + (tt * 32 + li) * VLD + 16 * s + 4 * lh;
+                half8_t vh, vl;
+                const half4 a0 = *(const half4*)vr, a1 = *(const half4*)(vr + 8);
+                const half4 b0 = *(const half4*)vq, b1 = *(const half4*)(vq + 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[tt], 0, 0, 0);
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[tt], 0, 0, 0);
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[tt], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / (l_tot * SV * SP);
+    if (qi < p.N) {
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = tt * 32 + 8 * g + 4 * lh;       // registers 4g .. 4g+3 <-> d .. d+3
+                if (d < D) {
+                    const f32x4 v = {o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv};
+                    *(f32x4*)(O + (long long)qi * p.ldo + d) = v;
+                }
+            }
+    }
+}
+
+// called by ief_attn_flash_f32 (exact_f32.hip) after its argument checks when p.x3 != 0
+int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st) {
+    if ((p.ldo & 3) || (p.sOb & 3) || ((uintptr_t)p.Out & 15)) return IEF_EALIGN;
+    const unsigned long long lim = 0xFFFFFFF0ull;
+    if (((unsigned long long)(p.L - 1) * p.ldk + p.d) * 4 >= lim || ((unsigned long long)(p.L - 1) * p.ldv + p.d) * 4 >= lim) return IEF_ESHAPE;
+    dim3 grid((p.N + 127) / 128, p.B * p.heads);
+    switch (p.d) {
+        case 32: hipLaunchKernelGGL(attn_flash_x3_kernel<32>, grid, dim3(256), 0, st, p); break;
+        case 40: hipLaunchKernelGGL(attn_flash_x3_kernel<40>, grid, dim3(256), 0, st, p); break;
+        case 64: hipLaunchKernelGGL(attn_flash_x3_kernel<64>, grid, dim3(256), 0, st, p); break;
+        case 80: hipLaunchKernelGGL(attn_flash_x3_kernel<80>, grid, dim3(256), 0, st, p); break;
+        case 160: hipLaunchKernelGGL(attn_flash_x3_kernel<160>, grid, dim3(256), 0, st, p); break;
+        default: return IEF_ESHAPE;
+    }
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}

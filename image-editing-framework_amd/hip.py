@@ -106,6 +106,7 @@ class IefAttnF32Params(Structure):
         ("sQb", c_longlong), ("sKb", c_longlong), ("sVb", c_longlong), ("sOb", c_longlong),
         ("scale", c_float),
         ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p),
+        ("x3", c_int),
     ]
 
 
@@ -211,7 +212,7 @@ def load():
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
     for which, st in ((0, IefGemmParams), (1, IefAttnParams), (2, IefCrossParams), (3, IefAttnBwdParams), (4, IefMapLossParams),
-                      (5, IefGemmF32Params)):
+                      (5, IefGemmF32Params), (6, IefAttnF32Params)):
         if lib.ief_struct_size(which) != ctypes.sizeof(st):
             raise HipExtensionMissing(f"{st.__name__}: ctypes layout ({ctypes.sizeof(st)} B) != library "
                                       f"({lib.ief_struct_size(which)} B); rebuild libief_hip.so")
@@ -1230,7 +1231,8 @@ def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, o
     p.sVb, _, p.ldv = _batched32(p, v, heads, d, "v")
     p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
-    with _Timed(f"attn_flash_f32_kernel<{d}>", 4.0 * B * heads * N * L * d, 4.0 * B * heads * d * (2 * N + 2 * L)):
+    p.x3 = 1 if _F32_CONTRACT == "x3" else 0
+    with _Timed(f"attn_flash_{'x3' if p.x3 else 'f32'}_kernel<{d}>", 4.0 * B * heads * N * L * d, 4.0 * B * heads * d * (2 * N + 2 * L)):
         _check(lib.ief_attn_flash_f32(byref(p), _stream()), "ief_attn_flash_f32")
     return out
 

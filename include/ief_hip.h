@@ -282,6 +282,7 @@ typedef struct IefAttnF32Params {
     long long sQb, sKb, sVb, sOb;
     float scale;
     const int* q_src; const int* k_src; const int* v_src;
+    int x3;                 /* ABI 3: != 0 -> both products on split fp16 operands (csrc/split_x3.hip), softmax in fp32 */
 } IefAttnF32Params;
 int ief_attn_flash_f32(const IefAttnF32Params* p, void* stream);
 int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
