@@ -691,6 +691,195 @@ __global__ __launch_bounds__(256) void groupnorm_f32_scalar_kernel(const float* 
         out[((long long)b * HW + pix) * C + c] = v;
     }
 }
+// ---- GroupNorm in three launches that stream whole rows (every access a 16-byte piece of a contiguous channel run):
+//   gn3_stats:    workgroup = (image, run of P pixels); a thread keeps one channel quad over the run: per-channel mean, then
+//                 the centred second moment about it (two passes over a run that stays in L1 / L2: no cancellation)
+//   gn3_finalize: one wave per (image, group): Chan's pairwise merge of the (count, mean, M2) of its channels x runs in a
+//                 fixed order (bit-reproducible), then per-channel scale = rstd gamma, shift = beta - mean scale
+//   gn3_apply:    y = x scale + shift (+ SiLU), same thread layout as the statistics pass
+// (the one-launch kernel above reads a 40-byte slice of every 1280-byte pixel row: 0.74 TB/s; this form: see DESIGN.md)
+#define GN3_U 12          // pixels a thread keeps in registers: a run is GN3_U x (pixel lanes of the workgroup) pixels
+static inline void gn3_chunks(int HW, int C, int* nch, int* P) {
+    const int CQ = C >> 2, CQB = CQ < 256 ? CQ : 256, PY = 256 / CQB;
+    int p = GN3_U * PY;
+    if (p > HW) p = HW;
+    *P = p;
+    *nch = (HW + p - 1) / p;
+}
+extern "C" long long ief_groupnorm_f32_ws_floats(int B, int HW, int C) {
+    int nch, P;
+    gn3_chunks(HW, C, &nch, &P);
+    return 2ll * B * nch * C + 2ll * B * C;
+}
+
+__device__ __forceinline__ const float* gn3_src(const float* x, const float* x2, int C1, int C2, int b, int HW, int c, int* cs) {
+    if (c < C1) { *cs = C1; return x + (long long)b * HW * C1 + c; }
+    *cs = C2;
+    return x2 + (long long)b * HW * C2 + (c - C1);
+}
+
+__global__ __launch_bounds__(256) void gn3_stats_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
+                                                        int HW, int P, float* __restrict__ pmean, float* __restrict__ pm2) {
+    __shared__ f32x4 red[256];
+    const int C = C1 + C2, CQ = C >> 2;
+    const int CQB = CQ < 256 ? CQ : 256, PY = 256 / CQB;
+    const int tid = threadIdx.x, cq = tid % CQB, py = tid / CQB;
+    const bool lane_ok = py < PY;
+    const int chunk = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+    const int p0 = chunk * P, pn = min(P, HW - p0);
+    for (int qb = 0; qb * CQB < CQ; ++qb) {
+        const int q = qb * CQB + cq;
+        const bool ok = lane_ok && q < CQ;
+        int cs = 4;
+        const float* src = gn3_src(x, x2, C1, C2, b, HW, ok ? q * 4 : 0, &cs) + (long long)p0 * cs;
+        // the thread's pixels py, py + PY, ... of the run: all loads issued before the first use
+        f32x4 v[GN3_U];
+#pragma unroll
+        for (int u = 0; u < GN3_U; ++u) {
+            const int pp = py + u * PY;
+            v[u] = (ok && pp < pn) ? *(const f32x4*)(src + (long long)pp * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GN3_U; ++u) s += v[u];
+        __syncthreads();
+        red[tid] = s;
+        __syncthreads();
+        f32x4 mean = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            for (int y = 0; y < PY; ++y) mean += red[y * CQB + cq];        // fixed order: every pixel lane holds the same mean
+            mean = mean * (1.0f / (float)pn);
+        }
+        f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GN3_U; ++u) {
+            if (py + u * PY < pn) { const f32x4 d = v[u] - mean; m2 += d * d; }
+        }
+        __syncthreads();
+        red[tid] = m2;
+        __syncthreads();
+        if (ok && py == 0) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < PY; ++y) t += red[y * CQB + cq];
+            const long long o = ((long long)b * nch + chunk) * C + q * 4;
+            *(f32x4*)(pmean + o) = mean;
+            *(f32x4*)(pm2 + o) = t;
+        }
+    }
+}
+
+// (n, mean, M2) <- merge with (nb, mb, M2b)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb == 0.f) return;
+    const float nn = n + nb, d = mb - mean;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+}
+
+__global__ __launch_bounds__(256) void gn3_finalize_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2, int C, int HW,
+                                                           int P, int nch, int groups, float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float sn[4], sm[4], sq[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups, cpg = C / groups, tid = threadIdx.x, lane = tid & 63;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    // entries = runs x channels of the group; a thread walks runs (stride 256 / cpg-rounded) for ONE channel: no division in
+    // the loop, every load independent of the merges before it
+    const int cl = tid % cpg, r0 = tid / cpg, rstep = 256 / cpg;
+    if (r0 < rstep) {
+        const float* pm = pmean + (long long)b * nch * C + g * cpg + cl;
+        const float* pq = pm2 + (long long)b * nch * C + g * cpg + cl;
+        for (int ch = r0; ch < nch; ch += rstep) {
+            const float cnt = (float)min(P, HW - ch * P);
+            chan_merge(n, mean, m2, cnt, pm[(long long)ch * C], pq[(long long)ch * C]);
+        }
+    }
+    auto pair = [&](float& n_, float& me_, float& q_, int off) {      // fixed pairing: identical in every run
+        const float nb = __shfl_xor(n_, off), mb = __shfl_xor(me_, off), qb = __shfl_xor(q_, off);
+        float n1 = n_, me1 = me_, q1 = q_, n2 = nb, me2 = mb, q2 = qb;
+        if (lane & off) { n1 = nb; me1 = mb; q1 = qb; n2 = n_; me2 = me_; q2 = q_; }     // lower lane's triple first
+        chan_merge(n1, me1, q1, n2, me2, q2);
+        n_ = n1; me_ = me1; q_ = q1;
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pair(n, mean, m2, off);
+    if (lane == 0) { sn[tid >> 6] = n; sm[tid >> 6] = mean; sq[tid >> 6] = m2; }
+    __syncthreads();
+    n = sn[0]; mean = sm[0]; m2 = sq[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) chan_merge(n, mean, m2, sn[w], sm[w], sq[w]);
+    const float rstd = 1.0f / sqrtf(m2 / n + eps);
+    for (int j = tid; j < cpg; j += 256) {
+        const int c = g * cpg + j;
+        const float sc = rstd * gamma[c];
+        scale[(long long)b * C + c] = sc;
+        shift[(long long)b * C + c] = beta[c] - mean * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn3_apply_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2, int HW,
+                                                        int P, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float* __restrict__ out, int silu) {
+    const int C = C1 + C2, CQ = C >> 2;
+    const int CQB = CQ < 256 ? CQ : 256, PY = 256 / CQB;
+    const int tid = threadIdx.x, cq = tid % CQB, py = tid / CQB;
+    if (py >= PY) return;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int p0 = chunk * P, pn = min(P, HW - p0);
+    for (int qb = 0; qb * CQB < CQ; ++qb) {
+        const int q = qb * CQB + cq;
+        if (q >= CQ) continue;
+        int cs = 0;
+        const float* src = gn3_src(x, x2, C1, C2, b, HW, q * 4, &cs) + (long long)p0 * cs;
+        float* dst = out + ((long long)b * HW + p0) * C + q * 4;
+        f32x4 v[GN3_U];
+#pragma unroll
+        for (int u = 0; u < GN3_U; ++u) {
+            const int pp = py + u * PY;
+            v[u] = pp < pn ? *(const f32x4*)(src + (long long)pp * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x4 sc = *(const f32x4*)(scale + (long long)b * C + q * 4), sh = *(const f32x4*)(shift + (long long)b * C + q * 4);
+#pragma unroll
+        for (int u = 0; u < GN3_U; ++u) {
+            const int pp = py + u * PY;
+            if (pp < pn) {
+                f32x4 y = v[u] * sc + sh;
+                if (silu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = silu_x(y[j]);
+                }
+                *(f32x4*)(dst + (long long)pp * C) = y;
+            }
+        }
+    }
+}
+
+extern "C" int ief_groupnorm_silu_f32_ws(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma,
+                                         const float* beta, int B, int HW, int groups, float eps, int silu, float* ws,
+                                         long long ws_floats, void* stream) {
+    if (!x || !out || !gamma || !beta || !ws || (C2 > 0 && !x2)) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups || (C1 & 3) || (C2 & 3)) return IEF_ESHAPE;
+    const int C = C1 + C2;
+    if (C / groups > 256) return IEF_ESHAPE;
+    if (ws_floats < ief_groupnorm_f32_ws_floats(B, HW, C)) return IEF_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)ws | (uintptr_t)(x2 ? x2 : x)) & 15) return IEF_EALIGN;
+    int nch, P;
+    gn3_chunks(HW, C, &nch, &P);
+    float* pmean = ws;
+    float* pm2 = pmean + (long long)B * nch * C;
+    float* scale = pm2 + (long long)B * nch * C;
+    float* shift = scale + (long long)B * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn3_stats_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, pmean, pm2);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_finalize_kernel, dim3(B * groups), dim3(256), 0, st, pmean, pm2, C, HW, P, nch, groups, eps, gamma, beta,
+                       scale, shift);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_apply_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, scale, shift, out, silu);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 extern "C" int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma,
                                       const float* beta, int B, int HW, int groups, float eps, int silu, void* stream) {
     if (!x || !out || !gamma || !beta || (C2 > 0 && !x2)) return IEF_EINVAL;
@@ -733,12 +922,51 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
     for (int i = lane; i < C; i += 64) o[i] = (r[i] - mean) * rstd * gamma[i] + beta[i];
 }
+// C % 4 == 0, C <= 256 NV: the row stays in registers (NV 16-byte pieces per lane): one read, one write
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                long long rows, int C, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* r = x + row * C;
+    float* o = out + row * C;
+    const int lane = threadIdx.x & 63, CQ = C >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int qd = lane + 64 * j;
+        v[j] = qd < CQ ? *(const f32x4*)(r + qd * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (lane + 64 * j < CQ) {
+            const f32x4 d = v[j] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int qd = lane + 64 * j;
+        if (qd < CQ) *(f32x4*)(o + qd * 4) = (v[j] - mean) * rstd * *(const f32x4*)(gamma + qd * 4) + *(const f32x4*)(beta + qd * 4);
+    }
+}
 extern "C" int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C,
                                  float eps, void* stream) {
     if (!x || !out || !gamma || !beta) return IEF_EINVAL;
     if (rows <= 0 || C <= 0) return IEF_ESHAPE;
-    hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, gamma,
-                       beta, rows, C, eps);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+    if (vec && C <= 512) hipLaunchKernelGGL(layernorm_f32_vec_kernel<2>, grid, dim3(256), 0, st, x, out, gamma, beta, rows, C, eps);
+    else if (vec && C <= 1280) hipLaunchKernelGGL(layernorm_f32_vec_kernel<5>, grid, dim3(256), 0, st, x, out, gamma, beta, rows, C, eps);
+    else if (vec && C <= 2560) hipLaunchKernelGGL(layernorm_f32_vec_kernel<10>, grid, dim3(256), 0, st, x, out, gamma, beta, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_f32_kernel, grid, dim3(256), 0, st, x, out, gamma, beta, rows, C, eps);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
@@ -758,6 +986,20 @@ __global__ __launch_bounds__(256) void ew_f32_kernel(const float* __restrict__ a
         }
     }
 }
+// GEGLU on the interleaved FF1 layout, 16-byte accesses: output quad (row, c .. c+3) = hidden quad x gelu(gate quad), the
+// gate 8 floats behind the hidden values inside their group of 16
+__global__ __launch_bounds__(256) void geglu_il_f32_vec_kernel(const float* __restrict__ pre, float* __restrict__ out, long long nq, int Chq) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long long)gridDim.x * 256) {
+        const long long row = i / Chq;
+        const int cq = (int)(i - row * Chq);             // output quad inside the row: columns 4 cq .. 4 cq + 3
+        const float* pr = pre + row * (8ll * Chq) + (cq >> 1) * 16 + (cq & 1) * 4;
+        const f32x4 hv = *(const f32x4*)pr, gv = *(const f32x4*)(pr + 8);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = hv[j] * gelu_f(gv[j]);
+        *(f32x4*)(out + i * 4) = y;
+    }
+}
 static int launch_ew(const float* a, const float* b, float* out, long long n, int which, int Ch, void* stream) {
     if (!a || !out || (which == 0 && !b)) return IEF_EINVAL;
     if (n <= 0) return IEF_ESHAPE;
@@ -771,6 +1013,14 @@ extern "C" int ief_add_f32(const float* a, const float* b, float* out, long long
 extern "C" int ief_silu_f32(const float* x, float* out, long long n, void* stream) { return launch_ew(x, nullptr, out, n, 1, 1, stream); }
 extern "C" int ief_geglu_il_f32(const float* pre, float* out, long long rows, int Ch, void* stream) {
     if (Ch <= 0 || (Ch & 7)) return IEF_ESHAPE;
+    if (pre && out && rows > 0 && (((uintptr_t)pre | (uintptr_t)out) & 15) == 0) {
+        const long long nq = rows * (Ch / 4);
+        long long grid = (nq + 255) / 256;
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(geglu_il_f32_vec_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, pre, out, nq, Ch / 4);
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
     return launch_ew(pre, nullptr, out, rows * Ch, 2, Ch, stream);
 }
 

@@ -11,17 +11,23 @@
 // at 1/16; measured against fp64 the results are as close as the fp32 MFMA's (tests/test_gpu_x3.py).  The scales keep `lo`
 // out of the fp16 subnormal range for elements of ordinary size (|lo| <= 2^-11 |hi|: a normal number once |s x| >= 2^-3;
 // smaller elements keep an absolute resolution of 2^-25 / s — gfx950's MFMA does not flush fp16 subnormals); the host
-// picks them per call (activations 2^4, weights 2^8, softmax maps 2^14), the epilogue divides them out.  `hi` is clamped to
-// +-65504, `lo` then carries the excess: elements up to 1.3e5 / s stay finite.
+// picks them per call (activations 2^2, weights 2^8, softmax maps 2^14), the epilogue divides them out.  |s x| must stay
+// below 65504 (the fp16 range, as on the fp16-storage path): beyond it `hi` is infinite and the output NaN, not silently wrong.
 //
-//   igemm_x3_kernel<WM, WN, TM, TN, CONV, TRANSB>
+//   igemm_x3_kernel<WM, WN, TM, TN, KIND, TRANSB>
 //       the operator set and parameter struct of igemm_f32_kernel (linear / 1x1 / 3x3 implicit GEMM with concat sources,
 //       nearest-2x, stride 2, fused 1x1 shortcut sources, the two batched attention products, split-K slabs).
 //       Tile (16 WM TM) x (16 WN TN) x 32, WM x WN waves, each TM x TN MFMA blocks of 16 x 16.  The MFMA's A operand is the
 //       WEIGHT block, its B operand the activation block: a lane then owns one output row m and four consecutive columns
 //       n — one 16-byte store (and 16-byte bias / residual loads) per block.  Operand tiles are fetched TWO K tiles ahead
-//       into registers (two register sets), split and written to a double-buffered LDS image one tile ahead; LDS rows of
-//       48 halves (96 B): conflict-free ds_read_b128 fragments of the 16x16x32 layout and ds_write_b64 staging.
+//       into registers (two register sets) through buffer descriptors (out-of-range lanes read zeros: no branch around a
+//       load), split and written to a double-buffered LDS image one tile ahead; LDS rows of 48 halves (96 B): conflict-free
+//       ds_read_b128 fragments of the 16x16x32 layout; 8-lane groups of the staging writes alternate rows r, r + 2
+//       (96 B x 2 = 64 mod 128: the two rows of a 16-lane ds_write_b64 group fall into different bank halves).
+//       KIND: 0 linear, 1 linear with A rows that are not 16-byte chunked (element loads), 2 3x3 convolution whose channel
+//       counts are multiples of 32 (a K tile is ONE tap of ONE source: per row the tile's offset is a precomputed pixel
+//       offset + a uniform term, its validity one bit of a 9-bit tap mask), 3 the same with the nearest-2x upsample folded
+//       in, 4 any other convolution (per-lane tap decode).
 //   attn_flash_x3_kernel<D>             fused attention without materialised maps (below)
 #include "ief_common.h"
 #include "ief_params.h"
@@ -30,6 +36,7 @@
 #define YLD 48          // halves per LDS row: 32 of the K tile + 16 of padding (96 B)
 
 typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct RowCoordY { int b, oy, ox, ok; };
 
@@ -41,25 +48,38 @@ __device__ __forceinline__ f32x4 bload(rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
 
-// s x -> (hi, lo) for four consecutive k
+// s x -> (hi, lo) for four consecutive k: v_pk_mul, v_cvt_pk_f16_f32 (round to nearest), then lo = fp16(s x - hi) with the
+// subtraction as ONE v_fma_mix_f32 per element (it reads the fp16 half directly: no conversion back) -- 10 VALU per chunk
 __device__ __forceinline__ void split4(const f32x4 v, const float s, half4& hi, half4& lo) {
     const f32x4 x = v * s;
-    f32x4 c;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_fmed3f(x[j], -65504.f, 65504.f);     // hi never overflows to inf
-    hi = __builtin_convertvector(c, half4);
-    const f32x4 r = x - __builtin_convertvector(hi, f32x4);
-    lo = __builtin_convertvector(r, half4);
+    const half2_t h0 = __builtin_convertvector(f32x2{x[0], x[1]}, half2_t);
+    const half2_t h1 = __builtin_convertvector(f32x2{x[2], x[3]}, half2_t);
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x[0]), "v"(h0));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x[1]), "v"(h0));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(x[2]), "v"(h1));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(x[3]), "v"(h1));
+    const half2_t l0 = __builtin_convertvector(f32x2{r0, r1}, half2_t);
+    const half2_t l1 = __builtin_convertvector(f32x2{r2, r3}, half2_t);
+    hi = half4{h0[0], h0[1], h1[0], h1[1]};
+    lo = half4{l0[0], l0[1], l1[0], l1[1]};
 }
 
-template <int WM, int WN, int TM, int TN, bool CONV, bool TRANSB, bool SLOW>
+enum { X3_LIN = 0, X3_LIN_SLOW = 1, X3_CONV = 2, X3_CONV_UPS = 3, X3_CONV_SLOW = 4 };
+
+template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3_kernel(const IefGemmF32Params p) {
+    constexpr bool CONV = KIND >= X3_CONV;
     constexpr int NTH = 64 * WM * WN;
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
     constexpr int ROWS = BM + BN;
     constexpr int NA = (BM * 8 + NTH - 1) / NTH;            // 16-byte chunks of the A tile per thread
     constexpr int NB = (BN * 8 + NTH - 1) / NTH;
     constexpr bool A_EXACT = (BM * 8) % NTH == 0, B_EXACT = (BN * 8) % NTH == 0;
+#ifndef X3_INTERLEAVE
+#define X3_INTERLEAVE 0
+#endif
+    constexpr bool INTERLEAVE = X3_INTERLEAVE != 0;
     // per buffer: [A hi][A lo][B hi][B lo], rows of YLD halves
     __shared__ __attribute__((aligned(16))) half_t smem_y[2 * 2 * ROWS * YLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -82,10 +102,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
     }
     const int M = p.M, N = p.N, K = p.K;
     const float sa = p.sa, sb = p.sb;
-    // ---- loader assignment: chunk c = tid + NTH i of a tile = (row c >> 3, 4 floats at k = 4 (c & 7))
-    const int kc4 = (tid & 7) * 4, r0 = tid >> 3;
+    // ---- loader assignment: chunk (row, 4 floats at k = 4 (tid & 7)); thread t takes rows rsw(t >> 3) + RSTEP i, where rsw
+    // swaps the two low bits' order so that lanes 8-15 of a 16-lane write group sit two rows below lanes 0-7
+    const int kc4 = (tid & 7) * 4;
+    const int rq = tid >> 3;
+    const int r0 = (rq & ~3) | ((rq & 1) << 1) | ((rq >> 1) & 1);
     constexpr int RSTEP = NTH / 8;
     RowCoordY rc[NA];
+    unsigned pixo1[NA], pixo2[NA], tmask[NA];   // KIND 2: byte offset of the centre tap's pixel in source 1 / 2; valid taps
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -97,6 +121,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
             const int rem = mm - rc[i].b * hw;
             rc[i].oy = rem / p.Wo;
             rc[i].ox = rem - rc[i].oy * p.Wo;
+            if (KIND == X3_CONV) {
+                const int pl = p.pad_hi_only ? 0 : 1;
+                const unsigned pix = (unsigned)((rc[i].b * p.H + rc[i].oy * p.stride) * p.Wd + rc[i].ox * p.stride);
+                pixo1[i] = pix * (unsigned)p.C1 * 4u; pixo2[i] = pix * (unsigned)p.C2 * 4u;
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = rc[i].oy * p.stride + t / 3 - pl, ix = rc[i].ox * p.stride + t % 3 - pl;
+                    mk |= (rc[i].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd) ? (1u << t) : 0u;
+                }
+                tmask[i] = mk;
+            }
         }
     }
     const int Ct = p.C1 + p.C2, K9 = 9 * Ct;
@@ -114,48 +150,83 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
         if (nk < 0) nk = 0;
     }
     const int kend = min(K, (kt0 + nk) * YBK);       // loads past this workgroup's K range read zeros
+
     // Every operand is read through a buffer descriptor (wave-uniform: kernel arguments and blockIdx only) with a per-lane
     // byte offset: an element outside the tensor, the K range or the image (3x3 padding) is a lane whose offset is pushed
     // past the descriptor's size and reads zeros -- no branch around any load, so the loads of a tile issue back to back and
-    // stay in flight under the MFMAs of two K tiles.
+    // stay in flight under the MFMAs of two K tiles.  The SLOW kinds keep the general per-lane loaders (a convolution whose
+    // channel counts are not multiples of 32: a K tile straddles taps / sources; A rows that are not 16-byte chunked); in
+    // the fast kinds the K loop is one basic block, which is what lets the compiler count the outstanding loads exactly.
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const rsrc_t rA = make_rsrc(A, p.bytesA), rW = make_rsrc(W, p.bytesW);
     const rsrc_t rA2 = make_rsrc(p.A2, p.bytesA2), rE1 = make_rsrc(p.E1, p.bytesE1), rE2 = make_rsrc(p.E2, p.bytesE2);
-    // SLOW instantiations hold the general loaders (a convolution whose channel counts are not multiples of 32: a K tile then
-    // straddles taps / sources; A rows that are not 16-byte chunked) -- kept out of the fast kernels, whose K loop is then one
-    // basic block: the compiler counts the outstanding loads exactly (branches inside the loop made it wait for vmcnt(0))
     // running decode of the next K tile to load (tiles are requested in order): tap, first channel inside the tap
     int l_tap = 0, l_ch = 0;
+    // per-thread constant parts of the linear operands' offsets
+    unsigned aoff[NA], boff[NB];
+    bool aval[NA], bval[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int ml = r0 + RSTEP * i, m = m0 + ml;
+        aval[i] = (m < M) & (A_EXACT || ml < BM);
+        aoff[i] = (unsigned)((m * p.lda + kc4) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (!TRANSB) {
+            const int nl = r0 + RSTEP * i, n = n0 + nl;
+            bval[i] = (n < N) & (B_EXACT || nl < BN);
+            boff[i] = (unsigned)((n * p.ldw + kc4) * 4);
+        } else {                        // W [K][N]: chunk c = tid + NTH i -> k row c & 31, 4 columns at 4 (c >> 5)
+            const int c = tid + NTH * i;
+            const int nl = (c >> 5) * 4, n = n0 + nl;
+            bval[i] = (n < N) & (B_EXACT || nl < BN);                                  // N % 4 == 0 (host-checked)
+            boff[i] = (unsigned)(((c & 31) * p.ldw + n) * 4);
+        }
+    }
 
     auto load_tile = [&](int k0, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
         const int kk = k0 + kc4;
-        if (CONV && !SLOW) {
-            // uniform decode of the tile: mode 1 = 3x3 tap (ky, kx) of source 1 / 2, mode 2 = 1x1 extra source 1 / 2
+        if (KIND == X3_CONV || KIND == X3_CONV_UPS) {
+            // uniform decode of the tile: a 3x3 tap (ky, kx) of source 1 / 2, or (l_tap == 9) the 1x1 extra source 1 / 2
             rsrc_t rs = rA;
             int cs = p.C1, chs = l_ch, ky = 0, kx = 0;
             const bool tapm = l_tap < 9;
+            bool second = false;
             if (tapm) {
                 ky = (l_tap * 11) >> 5; kx = l_tap - 3 * ky;
-                if (l_ch >= p.C1) { rs = rA2; cs = p.C2; chs = l_ch - p.C1; }
+                if (l_ch >= p.C1) { rs = rA2; cs = p.C2; chs = l_ch - p.C1; second = true; }
             } else if (l_ch < p.CE1) { rs = rE1; cs = p.CE1; }
             else { rs = rE2; cs = p.CE2; chs = l_ch - p.CE1; }
-            // no branch below: uniform selects, bitwise predicates
             const int kin = k0 < kend ? 1 : 0;
-            const int st = tapm ? p.stride : 1, dy = tapm ? ky - pad_lo : 0, dx = tapm ? kx - pad_lo : 0;
-            const unsigned Hc = tapm ? p.H : p.Ho, Wc = tapm ? p.Wd : p.Wo;       // bounds of the image the tap samples
-            const int sh = (tapm && p.ups) ? 1 : 0;
-            const int hs = tapm ? Hs : p.Ho, ws = tapm ? Ws : p.Wo;               // dims of the stored source
-            const int cb = chs + kc4;
+            if (KIND == X3_CONV) {
+                // offset = centre-pixel offset of the row (precomputed per source) + a uniform term; validity = one mask bit
+                const int uni = tapm ? (((ky - pad_lo) * p.Wd + (kx - pad_lo)) * cs + chs) * 4 : chs * 4;
+                const unsigned bit = tapm ? (1u << l_tap) : 0u;
+                const unsigned cs4 = (unsigned)cs * 4u;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int iy = rc[i].oy * st + dy, ix = rc[i].ox * st + dx;
-                const int ok = rc[i].ok & kin & ((unsigned)iy < Hc ? 1 : 0) & ((unsigned)ix < Wc ? 1 : 0);
-                const unsigned off = (unsigned)((((rc[i].b * hs + (iy >> sh)) * ws + (ix >> sh)) * cs + cb) * 4);
-                ra[i] = bload(rs, ok ? off : OOB);
+                for (int i = 0; i < NA; ++i) {
+                    const unsigned base = tapm ? (second ? pixo2[i] : pixo1[i]) : (unsigned)(m0 + r0 + RSTEP * i) * cs4;
+                    const bool ok = tapm ? (tmask[i] & bit) != 0 : rc[i].ok != 0;
+                    ra[i] = bload(rs, (ok & (kin != 0)) ? base + (unsigned)uni + (unsigned)(kc4 * 4) : OOB);
+                }
+            } else {                       // nearest-2x upsample folded in: the tap samples the virtual 2H x 2W image
+                const int dy = tapm ? ky - pad_lo : 0, dx = tapm ? kx - pad_lo : 0;
+                const unsigned Hc = tapm ? p.H : p.Ho, Wc = tapm ? p.Wd : p.Wo;
+                const int sh = tapm ? 1 : 0;
+                const int hs = tapm ? Hs : p.Ho, ws = tapm ? Ws : p.Wo;
+                const int cb = chs + kc4;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = rc[i].oy + dy, ix = rc[i].ox + dx;
+                    const int ok = rc[i].ok & kin & ((unsigned)iy < Hc ? 1 : 0) & ((unsigned)ix < Wc ? 1 : 0);
+                    const unsigned off = (unsigned)((((rc[i].b * hs + (iy >> sh)) * ws + (ix >> sh)) * cs + cb) * 4);
+                    ra[i] = bload(rs, ok ? off : OOB);
+                }
             }
             l_ch += YBK;                       // advance the decode by one K tile
             if (l_tap < 9 && l_ch >= Ct) { l_ch -= Ct; ++l_tap; }
-        } else if (CONV) {               // SLOW
+        } else if (KIND == X3_CONV_SLOW) {
             const float* src = nullptr;
             int cs = 0, chs = 0, ky = 0, kx = 0, mode = 0;       // mode 0: zero, 1: 3x3 tap, 2: 1x1 extra source
             if (kk < K9 && kk < kend) {
@@ -182,13 +253,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
                 }
                 ra[i] = v;
             }
-        } else if (!SLOW) {
+        } else if (KIND == X3_LIN) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int ml = r0 + RSTEP * i, m = m0 + ml;
-                const bool ok = (m < M) & (kk < kend) & (A_EXACT || ml < BM);
-                ra[i] = bload(rA, ok ? (unsigned)((m * p.lda + kk) * 4) : OOB);
-            }
+            for (int i = 0; i < NA; ++i) ra[i] = bload(rA, (aval[i] & (kk < kend)) ? aoff[i] + (unsigned)(k0 * 4) : OOB);
         } else {                        // rows of 77 keys: neither the row stride nor K is a multiple of 4 floats
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -204,60 +271,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
         }
         if (!TRANSB) {                  // W [N][K]: rows n0 + r0 + RSTEP i
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int nl = r0 + RSTEP * i, n = n0 + nl;
-                const bool ok = (n < N) & (kk < kend) & (B_EXACT || nl < BN);
-                rb[i] = bload(rW, ok ? (unsigned)((n * p.ldw + kk) * 4) : OOB);
-            }
-        } else {                        // W [K][N]: chunk c = tid + NTH i -> k row c & 31, 4 columns at 4 (c >> 5)
+            for (int i = 0; i < NB; ++i) rb[i] = bload(rW, (bval[i] & (kk < kend)) ? boff[i] + (unsigned)(k0 * 4) : OOB);
+        } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int c = tid + NTH * i;
-                const int kr = k0 + (c & 31), nl = (c >> 5) * 4, n = n0 + nl;
-                const bool ok = (kr < kend) & (n < N) & (B_EXACT || nl < BN);     // N % 4 == 0 (host-checked)
-                rb[i] = bload(rW, ok ? (unsigned)((kr * p.ldw + n) * 4) : OOB);
+                const int kr = k0 + ((tid + NTH * i) & 31);
+                rb[i] = bload(rW, (bval[i] & (kr < kend)) ? boff[i] + (unsigned)(k0 * p.ldw * 4) : OOB);
             }
         }
     };
-    auto store_tile = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
+    // split + LDS write of ONE staged chunk (idx < NA: A chunk, else B chunk idx - NA) of the tile held in (ra, rb)
+    auto store_chunk = [&](int buf, int idx, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
         half_t* ah = smem_y + buf * (2 * ROWS * YLD);
         half_t* al = ah + BM * YLD;
         half_t* bh = al + BM * YLD;
         half_t* bl = bh + BN * YLD;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (!A_EXACT && r0 + RSTEP * i >= BM) continue;
+        if (idx < NA) {
+            const int i = idx;
+            if (!A_EXACT && r0 + RSTEP * i >= BM) return;
             half4 h, l;
             split4(ra[i], sa, h, l);
             const int off = (r0 + RSTEP * i) * YLD + kc4;
             *(half4*)(ah + off) = h;
             *(half4*)(al + off) = l;
-        }
-        if (!TRANSB) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if (!B_EXACT && r0 + RSTEP * i >= BN) continue;
-                half4 h, l;
-                split4(rb[i], sb, h, l);
-                const int off = (r0 + RSTEP * i) * YLD + kc4;
-                *(half4*)(bh + off) = h;
-                *(half4*)(bl + off) = l;
-            }
+        } else if (!TRANSB) {
+            const int i = idx - NA;
+            if (!B_EXACT && r0 + RSTEP * i >= BN) return;
+            half4 h, l;
+            split4(rb[i], sb, h, l);
+            const int off = (r0 + RSTEP * i) * YLD + kc4;
+            *(half4*)(bh + off) = h;
+            *(half4*)(bl + off) = l;
         } else {
+            const int i = idx - NA;
+            const int c = tid + NTH * i;
+            const int kr = c & 31, nl = (c >> 5) * 4;
+            if (!B_EXACT && nl >= BN) return;
+            half4 h, l;
+            split4(rb[i], sb, h, l);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int c = tid + NTH * i;
-                const int kr = c & 31, nl = (c >> 5) * 4;
-                if (!B_EXACT && nl >= BN) continue;
-                half4 h, l;
-                split4(rb[i], sb, h, l);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bh[(nl + j) * YLD + kr] = h[j];
-                    bl[(nl + j) * YLD + kr] = l[j];
-                }
+            for (int j = 0; j < 4; ++j) {
+                bh[(nl + j) * YLD + kr] = h[j];
+                bl[(nl + j) * YLD + kr] = l[j];
             }
         }
+    };
+    auto store_tile = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
+#pragma unroll
+        for (int c = 0; c < NA + NB; ++c) store_chunk(buf, c, ra, rb);
     };
 
     f32x4 acc[TN][TM];
@@ -266,7 +327,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
 #pragma unroll
         for (int a = 0; a < TM; ++a) acc[b][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mma_tile = [&](int buf) {
+    // the MFMAs of the tile in LDS buffer `buf`, with the split + LDS write of the NEXT tile (registers ra, rb -> buffer
+    // buf ^ 1) spread between the TN column blocks: the conversions' VALU work issues in the shadow of the matrix pipe
+    auto mma_tile = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
         const half_t* ah = smem_y + buf * (2 * ROWS * YLD) + (wm * TM * 16 + lr) * YLD + 8 * lg;
         const half_t* al = ah + BM * YLD;
         const half_t* bh = smem_y + buf * (2 * ROWS * YLD) + 2 * BM * YLD + (wn * TN * 16 + lr) * YLD + 8 * lg;
@@ -277,6 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
             fah[a] = *(const half8_t*)(ah + a * 16 * YLD);
             fal[a] = *(const half8_t*)(al + a * 16 * YLD);
         }
+        constexpr int NC = NA + NB;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const half8_t fbh = *(const half8_t*)(bh + b * 16 * YLD);
@@ -287,10 +351,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
                 acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh, fal[a], acc[b][a], 0, 0, 0);
                 acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh, fah[a], acc[b][a], 0, 0, 0);
             }
+            if (INTERLEAVE) {
+#pragma unroll
+                for (int c = b; c < NC; c += TN) store_chunk(buf ^ 1, c, ra, rb);
+            }
         }
+        if (!INTERLEAVE) store_tile(buf ^ 1, ra, rb);
     };
 
-    if (CONV && !SLOW) {                     // decode of this workgroup's first K tile
+    if (KIND == X3_CONV || KIND == X3_CONV_UPS) {            // decode of this workgroup's first K tile
         const int k0 = kt0 * YBK;
         if (k0 < K9) { l_tap = k0 / Ct; l_ch = k0 - l_tap * Ct; } else { l_tap = 9; l_ch = k0 - K9; }
     }
@@ -301,20 +370,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
     load_tile((kt0 + 1) * YBK, ra1, rb1);
     store_tile(0, ra0, rb0);
     __syncthreads();
+    // NOTE the order inside a half step: the loads of tile kt + 2 overwrite register set (kt & 1), whose previous content
+    // (tile kt) went to LDS during the previous half step; the tile converted now is kt + 1 from the OTHER set
     for (int kt = 0; kt < nk; kt += 2) {
         load_tile((kt0 + kt + 2) * YBK, ra0, rb0);
-        mma_tile(0);
-        store_tile(1, ra1, rb1);
+        mma_tile(0, ra1, rb1);
         __syncthreads();
         load_tile((kt0 + kt + 3) * YBK, ra1, rb1);
-        mma_tile(1);
-        store_tile(0, ra0, rb0);
+        mma_tile(1, ra0, rb0);
         __syncthreads();
     }
     const float inv = 1.0f / (sa * sb);
     // lane: output row m (lane & 15 of the block), columns n .. n + 3 (4 (lane >> 4) of the block)
     const bool vec = p.vec_out != 0;
-    if (p.splits > 1) {       // raw partial sums (already in output units); ws rows are N floats, N % 4 == 0 whenever vec
+    if (p.splits > 1) {       // raw partial sums (already in output units); ws rows are N floats
         float* slab = p.ws + (long long)blockIdx.y * M * N;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -368,15 +437,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
 
 // column-tile width for N output columns: 80 where it divides N (every SD width is a multiple of 320), else 64
 extern "C" int ief_gemm_x3_bn(int N) { return (N % 80 == 0) ? 80 : 64; }
-extern "C" int ief_gemm_x3_bm(void) { return 128; }
+extern "C" int ief_gemm_x3_bm(int M, int N) {
+    (void)M; (void)N;
+    return 128;       // a 64 x 80 tile (4 waves of 16 rows) without split-K measured slower than 128 x 80 with it: not instantiated
+}
 
-template <int WM, int WN, int TM, int TN, bool CONV, bool TRANSB, bool SLOW>
+template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB>
 static int launch_igemm_x3(const IefGemmF32Params& p, hipStream_t st) {
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int z = p.heads > 0 ? p.batch * p.heads : 1;
     const int splits = p.splits > 1 ? p.splits : 1;
-    hipLaunchKernelGGL((igemm_x3_kernel<WM, WN, TM, TN, CONV, TRANSB, SLOW>), dim3(tiles, splits, z), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((igemm_x3_kernel<WM, WN, TM, TN, KIND, TRANSB>), dim3(tiles, splits, z), dim3(64 * WM * WN), 0, st, p);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
@@ -406,11 +478,11 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
     if (bA >= lim || bW >= lim || bA2 >= lim || bE1 >= lim || bE2 >= lim) return IEF_ESHAPE;      // 32-bit buffer offsets
     p.bytesA = (unsigned)bA; p.bytesW = (unsigned)bW; p.bytesA2 = (unsigned)bA2; p.bytesE1 = (unsigned)bE1; p.bytesE2 = (unsigned)bE2;
     const bool n80 = ief_gemm_x3_bn(p.N) == 80;
-#define X3_GO(CONV_, TRANSB_, SLOW_) (n80 ? launch_igemm_x3<4, 1, 2, 5, CONV_, TRANSB_, SLOW_>(p, st) \
-                                          : launch_igemm_x3<2, 2, 4, 2, CONV_, TRANSB_, SLOW_>(p, st))
-    if (p.conv) return p.al32 ? X3_GO(true, false, false) : X3_GO(true, false, true);
-    if (p.transb) return p.a_scalar ? X3_GO(false, true, true) : X3_GO(false, true, false);
-    return p.a_scalar ? X3_GO(false, false, true) : X3_GO(false, false, false);
+#define X3_GO(KIND_, TRANSB_) (n80 ? launch_igemm_x3<4, 1, 2, 5, KIND_, TRANSB_>(p, st) \
+                                   : launch_igemm_x3<2, 2, 4, 2, KIND_, TRANSB_>(p, st))
+    if (p.conv) return !p.al32 ? X3_GO(X3_CONV_SLOW, false) : p.ups ? X3_GO(X3_CONV_UPS, false) : X3_GO(X3_CONV, false);
+    if (p.transb) return p.a_scalar ? X3_GO(X3_LIN_SLOW, true) : X3_GO(X3_LIN, true);
+    return p.a_scalar ? X3_GO(X3_LIN_SLOW, false) : X3_GO(X3_LIN, false);
 #undef X3_GO
 }
 
@@ -433,7 +505,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     constexpr int DT = (D + 31) / 32;            // 32-row tiles of O^T
     constexpr int KLD = DG * 16 + 8;             // halves per K row (bytes = 16 mod 32: conflict-free b128 fragments)
     constexpr int VLD = 36;                      // halves per V^T row (32 keys + 4)
-    constexpr float SQ = 16.f, SK = 16.f, SV = 16.f, SP = 16384.f;
+    constexpr float SQ = 4.f, SK = 4.f, SV = 4.f, SP = 16384.f;
     __shared__ __attribute__((aligned(16))) half_t smem_f[2 * 32 * KLD + 2 * DT * 32 * VLD];
     half_t* Kh = smem_f;
     half_t* Kl = Kh + 32 * KLD;

@@ -124,7 +124,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
 ]
 
 
@@ -199,6 +199,11 @@ def load():
     lib.ief_p2p_cross_edit_f32.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
     lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_float, c_int, c_void_p]
+    lib.ief_gemm_x3_bm.argtypes = [c_int, c_int]
+    lib.ief_groupnorm_f32_ws_floats.argtypes = [c_int, c_int, c_int]
+    lib.ief_groupnorm_f32_ws_floats.restype = c_longlong
+    lib.ief_groupnorm_silu_f32_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                              c_float, c_int, c_void_p, c_longlong, c_void_p]
     lib.ief_layernorm_f32.argtypes = [c_void_p] * 4 + [c_longlong, c_int, c_float, c_void_p]
     lib.ief_add_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_silu_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
@@ -580,7 +585,7 @@ def _dev16(t, name):
 # A model sets it for the duration of its own calls (`with hip.f32_contraction(mode)`): one Python thread drives the
 # library, and a captured graph keeps the kernels that were chosen while it was recorded.
 _F32_CONTRACT = "f32"
-X3_SCALE_ACT, X3_SCALE_W, X3_SCALE_PROB = 16.0, 256.0, 16384.0      # powers of two: fp16(s x) keeps hi and lo normal
+X3_SCALE_ACT, X3_SCALE_W, X3_SCALE_PROB = 4.0, 256.0, 16384.0      # powers of two: fp16(s x) keeps hi and lo normal
 
 
 class f32_contraction:
@@ -852,11 +857,18 @@ def _splits_f32(lib, p, M, N, K, device):
     """split-K for the fp32 GEMM when M x N alone gives too few 128-row tiles for the 256 CUs (the 16x16 / 8x8 levels):
     aim at ~512 workgroups, every slice keeping >= 4 K tiles of 32"""
     x3 = _F32_CONTRACT == "x3"
-    tiles = -(-M // 128) * -(-N // (lib.ief_gemm_x3_bn(N) if x3 else lib.ief_gemm_f32_bn(N)))
     nk = -(-K // 32)
-    if tiles >= (384 if x3 else 256) or nk < 8:       # x3 tiles: two workgroups per CU
-        return None
-    splits = max(1, min(-(-512 // tiles), nk // 4, 16))
+    if x3:      # 128 x 80 tiles, two workgroups per CU: split below 1.5 per CU, towards 2 per CU (measured: without the split the
+        # 32x32 / 16x16 levels run 1.5-2x slower than the reducer launches cost)
+        tiles = -(-M // lib.ief_gemm_x3_bm(M, N)) * -(-N // lib.ief_gemm_x3_bn(N))
+        if tiles >= X3_SPLIT_BELOW or nk < 8:
+            return None
+        splits = max(1, min(-(-X3_SPLIT_TARGET // tiles), nk // 4, 16))
+    else:
+        tiles = -(-M // 128) * -(-N // lib.ief_gemm_f32_bn(N))
+        if tiles >= 256 or nk < 8:
+            return None
+        splits = max(1, min(-(-512 // tiles), nk // 4, 16))
     if splits <= 1:
         return None
     ws = torch.empty(splits * M * N, dtype=torch.float32, device=device)
@@ -1110,6 +1122,14 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
         HW = x.numel() // (B * C1)
         if out is None:
             out = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float32, device=x.device)
+        if GN3_F32 and C1 % 4 == 0 and C2 % 4 == 0:
+            nws = lib.ief_groupnorm_f32_ws_floats(B, HW, C1 + C2)
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            with _Timed("gn3_f32 (stats + finalize + apply)", 0.0, 12.0 * (x.numel() + (0 if x2 is None else x2.numel()))):
+                _check(lib.ief_groupnorm_silu_f32_ws(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                                     _dev32(beta, "beta").data_ptr(), B, HW, groups, eps, 1 if silu else 0,
+                                                     ws.data_ptr(), nws, _stream()), "ief_groupnorm_silu_f32_ws")
+            return out
         with _Timed("groupnorm_f32_kernel", 0.0, 8.0 * (x.numel() + (0 if x2 is None else x2.numel()))):
             _check(lib.ief_groupnorm_silu_f32(x.data_ptr(), _ptr(x2), C1, C2, out.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
                                               _dev32(beta, "beta").data_ptr(), B, HW, groups, eps, 1 if silu else 0, _stream()),
@@ -1211,6 +1231,9 @@ def _batched32(p, t, heads, d, which):
     return t.stride(0), d, t.stride(1)
 
 
+X3_SPLIT_BELOW = int(os.environ.get("IEF_X3_SPLIT_BELOW", "384"))      # split-K policy of the x3 GEMM (A/B runs)
+X3_SPLIT_TARGET = int(os.environ.get("IEF_X3_SPLIT_TARGET", "512"))
+GN3_F32 = os.environ.get("IEF_GN3_F32", "1") == "1"          # 0: the one-launch fp32 GroupNorm (A/B runs)
 FLASH_F32 = os.environ.get("IEF_FLASH_F32", "1") == "1"      # 0: always materialise the fp32 maps (A/B runs)
 
 

@@ -270,8 +270,8 @@ typedef struct IefGemmF32Params {
     unsigned bytesA, bytesW, bytesA2, bytesE1, bytesE2;
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
-int ief_gemm_x3_bn(int N);    /* x3 != 0: output-tile width (80 or 64) for N columns; ief_gemm_x3_bm(): its row count (128) */
-int ief_gemm_x3_bm(void);
+int ief_gemm_x3_bn(int N);    /* x3 != 0: output-tile width (80 or 64) for N columns; ief_gemm_x3_bm(M, N): its row count (128 or 64) */
+int ief_gemm_x3_bm(int M, int N);
 int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */
 /* fused fp32 attention (maps never written): out[b] = softmax(scale q[q_src[b]] k[k_src[b]]^T) v[v_src[b]]; q [B][N][heads*d]
  * (row stride ldq, batch stride sQb; likewise k, v over L keys and out); d in {32, 40, 64, 80, 160}; *_src NULL = identity */
@@ -292,6 +292,11 @@ int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* edit_slot, 
                            int heads, int N, int L, void* stream);
 int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma, const float* beta,
                            int B, int HW, int groups, float eps, int silu, void* stream);
+/* the same operator in three row-streaming launches (per-run channel statistics, Chan merge per group, apply); C1, C2
+ * multiples of 4; ws: ief_groupnorm_f32_ws_floats(B, HW, C1 + C2) floats of scratch the caller owns until the stream passes */
+long long ief_groupnorm_f32_ws_floats(int B, int HW, int C);
+int ief_groupnorm_silu_f32_ws(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma, const float* beta,
+                              int B, int HW, int groups, float eps, int silu, float* ws, long long ws_floats, void* stream);
 int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C, float eps,
                       void* stream);
 int ief_add_f32(const float* a, const float* b, float* out, long long n, void* stream);

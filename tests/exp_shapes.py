@@ -1,5 +1,5 @@
 """Per-layer-shape timing of one eager edit step (HIP events per launch, GPU kept busy while the host enqueues):
-which GEMM / conv shapes the step's matrix time goes to and at what rate.   IEF_PROF_SHAPES=1 python tests/exp_shapes.py [cfg] [latent]"""
+which GEMM / conv shapes the step's matrix time goes to and at what rate.   IEF_PROF_SHAPES=1 python tests/exp_shapes.py [cfg] [latent] [f16 | f32 | f16x3]"""
 import os
 import sys
 
@@ -13,7 +13,8 @@ import bench
 
 cfg_name = sys.argv[1] if len(sys.argv) > 1 else "sd15"
 dev = torch.device("cuda:0")
-pipe, cfg = bench.build_pipe(cfg_name, dev, 0, 1)
+precision = sys.argv[3] if len(sys.argv) > 3 else "f16"
+pipe, cfg = bench.build_pipe(cfg_name, dev, 0, 1, precision=precision)
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else cfg.sample_size
 B = 4
 x = torch.randn(B, 4, hw, hw, device=dev)

