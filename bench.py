@@ -3,6 +3,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+The headline (`value`, `roofline`) is measured in the mode that meets north_star's tolerance -- edited images within 1e-3
+max-abs of the fp32 reference (`/root/reference/p2p/edit_syn.py:38` computes in fp32): `--precision f16x3`, fp32 storage with
+every contraction on split fp16 operands (three fp16 MFMAs per product, fp32 accumulate; csrc/split_x3.hip; a 50-step
+512x512 edit ends 4e-6 from the fp32 oracle's images, tests/test_gpu_zz_fullsize.py).  The fp16-storage path (3e-3 on the same
+edit: outside the bound) is reported beside it as `fp16_mode`, the fp32-input-MFMA mode as `exact_mode`.
+
 A "step" is one pass of the hot path over one batch: one denoising step of the P2P edit loop =
 UNet forward at batch 4 (2 prompts x classifier-free guidance) with the AttentionRefine controller
 active + CFG combine + DDIM update (`/root/reference/p2p/model/sd_utils.py:67-79`), SD1.5-shaped
@@ -17,9 +23,10 @@ divided by the slowest rank's time ("weak" scaling).
 The JSON line also carries
   roofline      the kernel TEMPLATE with the largest share of the step (all tile / ring-depth instantiations of one
                 template count as one kernel): sum of algorithmic FLOP / sum of launch durations measured live with HIP
-                events on the launch stream, against the 2.5 PFLOP/s dense fp16 MFMA peak; `frac_rocprof` is the same
-                fraction from the committed rocprofv3 kernel-trace of this command (profiles/), `roofline_frac` prices
-                every launch against min(MFMA peak, arithmetic intensity x HBM peak)
+                events on the launch stream, against the matrix peak of the mode: 2.5 PFLOP/s dense fp16 MFMA for the
+                fp16 path, a third of it for f16x3 (three MFMAs per algorithmic product), 157.3 TFLOP/s for the fp32-input
+                MFMA; `frac_rocprof` is the same fraction from the committed rocprofv3 kernel-trace of this command
+                (profiles/), `roofline_frac` prices every launch against min(matrix peak, arithmetic intensity x HBM peak)
   cpu_baseline  the fp32 CPU oracle (`oracle/`, reference execution semantics: materialised maps +
                 Python controller) timed on this host's cores on a bounded sample of the same workload (>= 3 steps)
   images_per_sec          PIE-Bench loop of `/root/reference/p2p/test.py:114-181` on synthetic 512x512 images, in the
@@ -42,6 +49,15 @@ if ROOT not in sys.path:
 PROMPTS = ["a photo of a house on a mountain", "a photo of a house on a mountain at fall"]  # edit_syn.py:20-21
 FLOP_PER_STEP = 3.213e12      # 0.803 TFLOP / sample-forward x 4
 PEAK_MFMA_F16 = 2.5e15        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32-input MFMA (= fp32 vector) peak
+# per mode: (algorithmic-FLOP peak of its contractions, the line's "dtype", what the arithmetic is)
+MODES = {
+    "f16": (PEAK_MFMA_F16, "f16", "fp16 storage, fp16 MFMA operands, fp32 accumulate / statistics"),
+    "f16x3": (PEAK_MFMA_F16 / 3.0, "f16x3", "fp32 storage; every contraction on split operands: hi + lo fp16 halves of each fp32 "
+              "element, Ah Bh + Al Bh + Ah Bl = three v_mfma_f32_*_f16 per product, fp32 accumulate; softmax / norms in fp32"),
+    "f32": (PEAK_MFMA_F32, "f32", "fp32 storage, fp32-input MFMA (v_mfma_f32_32x32x2_f32)"),
+}
+IMAGE_ERR_50 = {"f16x3": 4.3e-6, "f32": 5.3e-6, "f16": 3.0e-3}   # measured: tests/test_gpu_zz_fullsize.py::test_sd15_edit50_vs_oracle_fixture
 MAX_STEPS = 50                # controller tables cover one 50-step edit
 
 
@@ -64,9 +80,12 @@ def parse():
                     help="cfg: --gpus 2 run ONE edit together (rank 0 the unconditional rows of the CFG batch, rank 1 the "
                     "conditional rows + controller plan, one 128 KiB eps all-gather per step over RCCL; SURVEY.md 8e); "
                     "value is then the steps/s of that one edit (strong scaling)")
-    ap.add_argument("--exact-steps", type=int, default=5,
-                    help="also time this many edit steps in the reference-precision mode (fp32 weights / activations on the "
-                    "fp32-input MFMA, precision='f32'); N = 1 only; 0: skip")
+    ap.add_argument("--precision", choices=["f16x3", "f16", "f32"], default="f16x3",
+                    help="the mode the headline value is measured in (default: the one that meets the 1e-3 image bound)")
+    ap.add_argument("--other-modes", type=str, default="f16,f32",
+                    help="modes reported beside the headline (N = 1 only): f16 -> `fp16_mode` with its own roofline, in-flight "
+                    "throughput, 1024x1024 and PIE numbers; f32 -> `exact_mode` (a few steps + roofline); '' to skip")
+    ap.add_argument("--exact-steps", type=int, default=5, help="timed steps of the fp32-input-MFMA mode")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one "
                     "GPU, which RCCL refuses: rehearsals of the N > 1 paths on a one-GPU box)")
     ap.add_argument("--pie-images", type=int, default=8, help="synthetic PIE images timed per GPU for images_per_sec (0: skip)")
@@ -194,7 +213,7 @@ def main():
     from ief_amd.p2p.model.sd_utils import _encode_prompts
     hip.load()
 
-    pipe, cfg = build_pipe(args.config, dev, rank, world)
+    pipe, cfg = build_pipe(args.config, dev, rank, world, precision=args.precision)
     from ief_amd import weights as _w
     nparams = _w.num_params(cfg)
     pipe.scheduler.set_timesteps(MAX_STEPS)
@@ -225,7 +244,7 @@ def main():
                           "edit CFG-split over 2 GPUs)",
                 "value": round(args.steps / elapsed, 3), "unit": "steps/s", "n_gpus": 2, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "scaling": "strong", "vs_baseline": None, "dtype": MODES[args.precision][1], "data": "synthetic",
                 "config": {"workload": f"{args.config} UNet P2P AttentionRefine edit step, rank 0: unconditional rows (UNet batch 2), "
                                        f"rank 1: conditional rows + controller plan (UNet batch 2), one eps all-gather per step, "
                                        f"{hw}x{hw} latents"}}), flush=True)
@@ -233,67 +252,77 @@ def main():
         dist.destroy_process_group()
         return
 
-    # ---- headline: K edit steps between barriers
-    job = EditJob(pipe, cfg, ctx, hw, dev, rank, uncond_list)
-    elapsed = job.timed(args.steps, args.warmup, barrier, dist, dev)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed
+    def measure(pipe_m, precision, steps, warmup, full):
+        """the numbers of ONE mode: K edit steps between barriers (+ in-flight throughput, roofline, 1024x1024, PIE if `full`)"""
+        peak, dtype, what = MODES[precision]
+        job = EditJob(pipe_m, cfg, ctx, hw, dev, rank, uncond_list)
+        elapsed = job.timed(steps, warmup, barrier, dist, dev)
+        value = world * steps / elapsed
+        res = {"value": round(value, 3), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "dtype": dtype,
+               "arithmetic": what,
+               "image_max_abs_err_50_step_edit": IMAGE_ERR_50[precision] if (args.config, hw) == ("sd15", 64) else None,
+               "meets_1e-3_image_bound": IMAGE_ERR_50[precision] <= 1e-3}
+        if full:
+            # throughput schedule: E independent edits in flight per GPU (denoise.run_interleaved); `value` stays E = 1
+            res["throughput_edits_in_flight"] = {
+                str(E): round(edits_in_flight(pipe_m, cfg, ctx, job.x_T, hw, E, dev, dist, barrier, world, rank, uncond_list), 3)
+                for E in [int(e) for e in args.in_flight.split(",") if e.strip()]}
+        if rank == 0:
+            register_job(pipe_m, job)
+            res["roofline"] = roofline(job, value, world, args.config, precision)      # last use of this job: it ends eager
+        job.close()
+        if full and args.steps_1024 > 0 and hw != 128:       # the same edit step on 128x128 latents (1024x1024 px)
+            job2 = EditJob(pipe_m, cfg, ctx, 128, dev, rank, uncond_list)
+            el2 = job2.timed(args.steps_1024, 2, barrier, dist, dev)
+            res["steps_per_sec_1024"] = round(world * args.steps_1024 / el2, 3)
+            res["ms_per_step_1024"] = round(el2 / args.steps_1024 * 1e3, 3)
+            if rank == 0:
+                register_job(pipe_m, job2)
+                res["roofline_1024"] = roofline(job2, res["steps_per_sec_1024"], world, args.config, precision)
+            job2.close()
+            del job2
+            torch.cuda.empty_cache()
+        # BASELINE.json's second metric: PIE-Bench images/sec (reference per-image order, then the batched schedule)
+        if full and args.pie_images > 0 and not cfg.addition_embed:
+            res.update(pie_images_per_sec(pipe_m, dev, rank, world, dist, barrier, args.pie_images))
+        return res, job
 
-    # ---- throughput schedule: E independent edits in flight per GPU (denoise.run_interleaved); the headline stays E = 1
-    in_flight = {}
-    for E in [int(e) for e in args.in_flight.split(",") if e.strip()]:
-        in_flight[str(E)] = round(edits_in_flight(pipe, cfg, ctx, job.x_T, hw, E, dev, dist, barrier, world, rank, uncond_list), 3)
-
+    # ---- headline mode
+    head, job = measure(pipe, args.precision, args.steps, args.warmup, True)
     out = {
         "metric": f"denoising steps/sec ({MODEL_NAMES.get(args.config, args.config)} {hw * 8}x{hw * 8} P2P edit step, UNet batch 4)",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
+        "value": head["value"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.config} UNet ({nparams / 1e6:.1f}M params) P2P AttentionRefine edit step, 2 prompts x CFG = batch 4, "
                                f"{hw}x{hw} latents ({hw * 8}x{hw * 8} px), 50-step DDIM, guidance 7.5, cross 0.8 / self 0.4, "
                                + ("per-step null-text unconditional embeddings (P2P_NTI, edit_real.py); "
                                   if args.uncond == "per-step" else "fixed unconditional embedding (edit_syn.py); ")
-                               + "one independent edit per GPU"},
-        # same edit step, E independent edits stepped concurrently per GPU (steps/s over all ranks); the schedule
-        # `p2p/test.py --in_flight E` uses for PIE-Bench throughput.  The headline `value` above is E = 1.
-        "throughput_edits_in_flight": in_flight,
+                               + "one independent edit per GPU; precision mode " + args.precision + ": " + head["arithmetic"]
+                               + (" -- the mode that meets north_star's bound (edited images within 1e-3 max-abs of the fp32 "
+                                  "reference: measured 4e-6 on a 50-step 512x512 edit)" if args.precision == "f16x3" else "")},
     }
-    if rank == 0:
-        register_job(pipe, job)
-        out["roofline"] = roofline(job, value, world, args.config)      # last use of this job: it ends eager
-    job.close()
+    for k, v in head.items():
+        if k not in ("value", "ms_per_step", "steps", "dtype"):
+            out[k] = v
 
-    # ---- the same edit step on 128x128 latents (1024x1024 px): north_star's second latent size
-    if args.steps_1024 > 0 and hw != 128:
-        job2 = EditJob(pipe, cfg, ctx, 128, dev, rank, uncond_list)
-        el2 = job2.timed(args.steps_1024, 2, barrier, dist, dev)
-        out["steps_per_sec_1024"] = round(world * args.steps_1024 / el2, 3)
-        out["ms_per_step_1024"] = round(el2 / args.steps_1024 * 1e3, 3)
-        if rank == 0:
-            register_job(pipe, job2)
-            out["roofline_1024"] = roofline(job2, out["steps_per_sec_1024"], world, args.config)
-        job2.close()
-        del job2
-        torch.cuda.empty_cache()
-
-    # ---- BASELINE.json's second metric: PIE-Bench images/sec (reference per-image order, then the batched schedule)
-    if args.pie_images > 0 and not cfg.addition_embed:
-        out.update(pie_images_per_sec(pipe, dev, rank, world, dist, barrier, args.pie_images))
-
-    # ---- the same edit step in the reference-precision mode (edited images within 1e-3 of the fp32 reference: DESIGN.md §4)
-    if args.exact_steps > 0 and world == 1 and not cfg.addition_embed:
+    # ---- the other modes beside it (N = 1: they are context for the headline, not scaled)
+    others = [m.strip() for m in args.other_modes.split(",") if m.strip() and m.strip() != args.precision]
+    if world == 1 and not cfg.addition_embed:
         sd_host = pipe._state_dict
-        pipe32, _ = build_pipe(args.config, dev, rank, world, precision="f32")
-        pipe32.scheduler.set_timesteps(MAX_STEPS)
-        job3 = EditJob(pipe32, cfg, ctx, hw, dev, rank, uncond_list)
-        el3 = job3.timed(args.exact_steps, 1, barrier, dist, dev)
-        out["exact_mode"] = {"precision": "f32 storage, fp32-input MFMA (v_mfma_f32_32x32x2_f32), attention maps materialised",
-                             "steps_per_sec": round(args.exact_steps / el3, 3), "ms_per_step": round(el3 / args.exact_steps * 1e3, 3),
-                             "steps": args.exact_steps, "peak_tflops_f32_mfma": 157.3,
-                             "achieved_tflops": round(args.exact_steps / el3 * FLOP_PER_STEP / 1e12, 2) if (args.config, hw) == ("sd15", 64) else None}
-        job3.close()
-        del job3, pipe32
-        torch.cuda.empty_cache()
+        for m in others:
+            pipe_m, _ = build_pipe(args.config, dev, rank, world, precision=m)
+            pipe_m.scheduler.set_timesteps(MAX_STEPS)
+            if m == "f32":
+                r, j = measure(pipe_m, m, args.exact_steps, 1, False)
+                r["peak_tflops_f32_mfma"] = PEAK_MFMA_F32 / 1e12
+                r["achieved_tflops"] = round(r["value"] * FLOP_PER_STEP / 1e12, 2) if (args.config, hw) == ("sd15", 64) else None
+                out["exact_mode"] = r
+            else:
+                r, j = measure(pipe_m, m, args.steps, args.warmup, True)
+                out["fp16_mode" if m == "f16" else m + "_mode"] = r
+            del pipe_m, j
+            torch.cuda.empty_cache()
         pipe._state_dict = sd_host
 
     if rank == 0:
@@ -394,6 +423,14 @@ def _family(kernel_name: str) -> str:
                 else "igemm_f16_kernel<.., CONV=false> (linear / 1x1)")
     if kernel_name.startswith("conv3x3_halo_kernel"):
         return "conv3x3_halo_kernel<..> (3x3 convolution, input tile resident in LDS across the taps)"
+    if kernel_name.startswith("igemm_x3_kernel") or kernel_name.startswith("igemm_f32_kernel"):
+        base = kernel_name.split("<")[0]
+        inner = kernel_name.split("<", 1)[1] if "<" in kernel_name else ""
+        if inner.startswith("true"):
+            return base + "<.., conv> (3x3 implicit-GEMM convolution)"
+        if inner.startswith("scores") or inner.startswith("apply"):
+            return base + "<.., batched> (materialised attention products)"
+        return base + "<.., linear> (linear / 1x1)"
     if kernel_name.startswith("attn_flash"):
         return kernel_name.split("<")[0] + "<..> (self-attention, all head dims)"
     return kernel_name
@@ -402,8 +439,10 @@ def _family(kernel_name: str) -> str:
 PEAK_HBM = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.3e12 measured with a float4 copy)
 
 
-def roofline(job, steps_per_sec, world, config):
-    """dominant kernel's algorithmic FLOP/s from per-launch HIP-event timings of one eager step"""
+def roofline(job, steps_per_sec, world, config, precision="f16"):
+    """dominant kernel's algorithmic FLOP/s from per-launch HIP-event timings of one eager step; `peak` is the matrix peak
+    in ALGORITHMIC FLOP/s of the mode (f16x3: a third of the fp16 MFMA peak, three MFMAs per product)"""
+    PEAK = MODES[precision][0]
     from ief_amd import hip
     loop, ctrl, x_T = job.loop, job.ctrl, job.x_T
     loop.release()                         # drops the captured graph: the rest of this job runs eagerly
@@ -423,7 +462,7 @@ def roofline(job, steps_per_sec, world, config):
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += ms
         # price of this launch on the roofline: the larger of its MFMA time and its HBM time
-        floor_ms = max(flops / PEAK_MFMA_F16, nbytes / PEAK_HBM) * 1e3
+        floor_ms = max(flops / PEAK, nbytes / PEAK_HBM) * 1e3
         f = fam.setdefault(_family(name), [0, 0.0, 0.0, 0.0, 0.0])
         f[0] += 1; f[1] += flops; f[2] += ms; f[3] += nbytes; f[4] += floor_ms
     total_ms = sum(a[2] for a in agg.values())
@@ -437,17 +476,20 @@ def roofline(job, steps_per_sec, world, config):
     # those profiles were taken on
     prof = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_roofline_inputs.json")) as f:
-            prof = json.load(f).get(f"{config}|{job.hw}", {}).get(name, {})
+        with open(os.path.join(ROOT, "profiles", "r03_roofline_inputs.json")) as f:
+            prof = json.load(f).get(f"{config}|{job.hw}|{precision}", {}).get(name, {})
     except (OSError, ValueError):
         prof = {}
     out = {
-        "bound": "mfma" if flops / PEAK_MFMA_F16 >= nbytes / PEAK_HBM else "hbm",
+        "bound": "mfma" if flops / PEAK >= nbytes / PEAK_HBM else "hbm",
         "kernel": name, "launches_per_step": n,
         "avg_launch_ms": round(ms / n, 4), "alg_gflop_per_launch": round(flops / n / 1e9, 3),
         "alg_mbytes_per_launch": round(nbytes / n / 1e6, 3),
-        "achieved": round(achieved, 2), "peak": PEAK_MFMA_F16 / 1e12, "unit": "TFLOP/s",
-        "frac": round(achieved * 1e12 / PEAK_MFMA_F16, 4),
+        "achieved": round(achieved, 2), "peak": round(PEAK / 1e12, 1), "unit": "TFLOP/s",
+        "frac": round(achieved * 1e12 / PEAK, 4),
+        "peak_note": {"f16": "dense fp16 MFMA peak", "f32": "fp32-input MFMA peak",
+                      "f16x3": "algorithmic FLOP/s: dense fp16 MFMA peak (2500) / 3 MFMAs per product; the matrix pipe itself runs at "
+                               "3 x `achieved`"}[precision],
         "timing": "HIP events around every launch on the launch stream (includes ~3 us of event pair per launch)",
         # each launch priced at max(FLOP / MFMA peak, algorithmic bytes / HBM peak): what share of the measured time the
         # roofline accounts for (the square K = C projections are HBM-side on this measure)
@@ -459,13 +501,13 @@ def roofline(job, steps_per_sec, world, config):
         "kernel_share_of_step": round(ms / total_ms, 3),
         "whole_step": {"alg_tflop_per_step": round(alg_flop / 1e12, 3),
                        "achieved": round(steps_per_sec / world * alg_flop / 1e12, 2),
-                       "frac": round(steps_per_sec / world * alg_flop / PEAK_MFMA_F16, 4)},
+                       "frac": round(steps_per_sec / world * alg_flop / PEAK, 4)},
         "per_kernel_ms": {k: round(v[2], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
     }
     if "avg_launch_us_rocprof" in prof:
         us = prof["avg_launch_us_rocprof"]
         out["avg_launch_ms_rocprof"] = round(us * 1e-3, 4)
-        out["frac_rocprof"] = round(flops / n / (us * 1e-6) / PEAK_MFMA_F16, 4)
+        out["frac_rocprof"] = round(flops / n / (us * 1e-6) / PEAK, 4)
         out["rocprof_source"] = prof.get("source")
     if job.hw == 64 and config == "sd15":
         out["whole_step"]["survey_tflop_per_step_512px"] = FLOP_PER_STEP / 1e12
