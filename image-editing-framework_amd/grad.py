@@ -41,9 +41,10 @@ class UNetAdjoint:
     def __init__(self, unet, grad_scale: float = 1.0, mode: str = "context"):
         if mode not in ("context", "input"):
             raise ValueError("UNetAdjoint: mode must be 'context' or 'input'")
-        if unet.dtype != torch.float16:
-            raise NotImplementedError("the activation-gradient pass (null-text inversion, Pix2Pix-zero) exists on the fp16 "
-                                      'path only: build the pipeline with precision="f16"')
+        # fp32-storage modes ("f32" / "f16x3"): same chain on the fp32 kernels (csrc/backward_f32.hip; attention gradients
+        # on materialised fp32 maps, hip._attn_bwd_f32) -- the reference's own precision for this pass
+        self.f32 = unet.dtype == torch.float32
+        self.contract = getattr(unet, "contract", "f32")
         self.unet = unet
         self.mode = mode
         self.grad_scale = float(grad_scale)
@@ -142,12 +143,13 @@ class UNetAdjoint:
             a1, a2, ff = blk.attn1, blk.attn2, blk.ff
             h0 = h
             qkv = hip.gemm(blk.norm1(h0), a1.w_qkv)
-            lse1 = torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device)
+            # fp16: the row log-sum-exp feeds the fused backward kernels; fp32: the backward re-materialises the maps
+            lse1 = None if self.f32 else torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device)
             o1 = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], a1.heads, a1.scale, lse=lse1)
             h1 = a1.to_out[0](o1, residual=h0)
             q2 = hip.gemm(blk.norm2(h1), a2.to_q.weight)
             off = a2._kv_off
-            lse2 = torch.empty(B, a2.heads, N, dtype=torch.float32, device=x.device)
+            lse2 = None if self.f32 else torch.empty(B, a2.heads, N, dtype=torch.float32, device=x.device)
             o2 = hip.attn_flash(q2, kv_all[..., off:off + C], kv_all[..., off + C:off + 2 * C], a2.heads, a2.scale, lse=lse2)
             h2 = a2.to_out[0](o2, residual=h1)
             pre = hip.gemm(blk.norm3(h2), ff.net[0].proj.weight, bias=ff.net[0].proj.bias)
@@ -158,7 +160,16 @@ class UNetAdjoint:
         return out
 
     def forward(self, sample, temb_row, ctx16):
-        """sample fp32 NCHW [B,4,h,w]; temb_row fp32 [1, width] (`unet.time_rows`); ctx16 fp16 [B,77,Cc] -> eps fp32 NCHW."""
+        with hip.f32_contraction(self.contract):
+            return self._forward(sample, temb_row, ctx16)
+
+    def backward(self, d_eps):
+        with hip.f32_contraction(self.contract):
+            return self._backward(d_eps)
+
+    def _forward(self, sample, temb_row, ctx16):
+        """sample fp32 NCHW [B,4,h,w]; temb_row fp32 [1, width] (`unet.time_rows`); ctx16 [B,77,Cc] in the model's activation
+        dtype (fp16; fp32 in the fp32-storage modes) -> eps fp32 NCHW."""
         u = self.unet
         if u._plan is not None or not all(m.is_native() for m in u.attention_modules()):
             raise RuntimeError("UNetAdjoint: an attention controller is registered; the reference runs null-text "
@@ -257,12 +268,13 @@ class UNetAdjoint:
         self._cross_index = {id(m): i for i, m in enumerate(self.cross)}
         off = [0]
         for m, r in zip(self.cross, ref_maps):
-            off.append(off[-1] + r.shape[0] * hip.map_loss_blocks(r.shape[1], m.dim_head))
+            off.append(off[-1] + (hip.map_loss_blocks_f32(r.shape[0] * r.shape[1]) if self.f32 else
+                                  r.shape[0] * hip.map_loss_blocks(r.shape[1], m.dim_head)))
         self._loss_off = off
         if self.loss_parts is None or self.loss_parts.numel() != off[-1]:
             self.loss_parts = torch.zeros(off[-1], dtype=torch.float32, device=ref_maps[0].device)
 
-    def backward(self, d_eps):
+    def _backward(self, d_eps):
         """mode "context": d_eps fp32 NCHW (gradient of the objective w.r.t. the UNet output, already scaled) -> fp16
         [B,77,Cc]: the gradient w.r.t. the fp16 context the last `forward` ran on, in the same scale.
         mode "input": d_eps is the (usually zero) gradient entering at eps; -> fp32 NCHW gradient w.r.t. `sample`,
@@ -274,7 +286,7 @@ class UNetAdjoint:
             if self.ref_maps is None:
                 raise RuntimeError("UNetAdjoint(mode='input'): set_reference_maps() first")
         else:
-            self.dkv_all = torch.empty(B, self.kv_all.shape[1], self.kv_width, dtype=torch.float16, device=hf.device)
+            self.dkv_all = torch.empty(B, self.kv_all.shape[1], self.kv_width, dtype=self.unet.dtype, device=hf.device)
         n = u.conv_norm_out
         d = hip.conv_out_bwd(d_eps, u.conv_out.weight)
         d = hip.groupnorm_bwd(hf, d, n.weight, n.bias, n.num_groups, n.eps, silu=True, stats=stf)

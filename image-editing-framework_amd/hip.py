@@ -125,6 +125,10 @@ EXPORTS = [
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
     "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
+    # activation gradients of the fp32-storage modes (csrc/backward_f32.hip)
+    "ief_groupnorm_bwd_f32", "ief_layernorm_bwd_f32", "ief_geglu_il_bwd_f32", "ief_zero_insert2x_f32", "ief_pool2x2_sum_f32",
+    "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
+    "ief_map_loss_rows_f32", "ief_nti_adam_f32g",
 ]
 
 
@@ -200,6 +204,17 @@ def load():
     lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_float, c_int, c_void_p]
     lib.ief_gemm_x3_bm.argtypes = [c_int, c_int]
+    lib.ief_groupnorm_bwd_f32.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int, c_void_p]
+    lib.ief_layernorm_bwd_f32.argtypes = [c_void_p] * 5 + [c_longlong, c_int, c_float, c_void_p]
+    lib.ief_geglu_il_bwd_f32.argtypes = [c_void_p] * 3 + [c_longlong, c_int, c_void_p]
+    lib.ief_zero_insert2x_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.ief_pool2x2_sum_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.ief_conv_out_bwd_f32w.argtypes = [c_void_p] * 3 + [c_int] * 5 + [c_void_p]
+    lib.ief_softmax_bwd_rows_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p]
+    lib.ief_transpose_batched_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.ief_map_loss_rows_blocks.argtypes = [c_longlong]
+    lib.ief_map_loss_rows_f32.argtypes = [c_void_p] * 4 + [c_longlong, c_int, c_float, c_float, c_void_p]
+    lib.ief_nti_adam_f32g.argtypes = [c_void_p] * 7 + [c_int, c_void_p]
     lib.ief_groupnorm_f32_ws_floats.argtypes = [c_int, c_int, c_int]
     lib.ief_groupnorm_f32_ws_floats.restype = c_longlong
     lib.ief_groupnorm_silu_f32_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -1113,8 +1128,8 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out=None, return
     cstat / cstat2: the ColStats the launches that PRODUCED x / x2 returned (`col_stats=True`), or None."""
     lib = load()
     if _is32(x):
-        if return_stats:
-            raise ValueError("groupnorm: return_stats exists only on the fp16 path")
+        if return_stats:        # the fp32 backward recomputes its (two-pass) statistics: nothing to hand over
+            return groupnorm(x, gamma, beta, groups, eps, silu=silu, x2=x2, out=out), None
         if not _act32(x, "x").is_contiguous() or (x2 is not None and not _act32(x2, "x2").is_contiguous()):
             raise ValueError("groupnorm: inputs must be contiguous")
         B, C1 = x.shape[0], x.shape[-1]
@@ -1347,7 +1362,7 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     fp32 operands (reference-precision mode): the maps are materialised in HBM, as the reference does."""
     if _is32(q):
         if lse is not None:
-            raise ValueError("attn_flash: lse output exists only on the fp16 path")
+            raise ValueError("attn_flash: lse output exists only on the fp16 path (the fp32 backward recomputes the maps)")
         o = _attn_flash_f32(q, k, v, heads, scale, q_src, k_src, v_src, out)
         if o is not None:
             return o
@@ -1548,6 +1563,8 @@ def attn_map_loss_bwd(q, k, ref, dq, heads, scale, gcoef, accumulate=True, loss=
     q [B,N,h*d], k [B,L,h*d] (strided views ok), ref fp16 [B*heads,N,L];
     loss: optional fp32 [B*heads*map_loss_blocks(N, d)] partials of sum e^2 (each times loss_coef)."""
     lib = load()
+    if _is32(q):
+        return _attn_map_loss_bwd_f32(q, k, ref, dq, heads, scale, gcoef, accumulate, loss, loss_coef)
     _dev16(q, "q"), _dev16(k, "k"), _dev16(ref, "ref"), _dev16(dq, "dq")
     B, N, C = q.shape
     L = k.shape[1]
@@ -1572,6 +1589,71 @@ def attn_map_loss_bwd(q, k, ref, dq, heads, scale, gcoef, accumulate=True, loss=
     return dq
 
 
+
+# ------------------------------------------------------------------------------- attention gradients, fp32-storage modes
+def _transpose_maps_f32(x):
+    """[R, N, L] fp32 -> contiguous [R, L, N]"""
+    lib = load()
+    R, N, L = x.shape
+    out = torch.empty(R, L, N, dtype=torch.float32, device=x.device)
+    _check(lib.ief_transpose_batched_f32(_act32(x, "maps").data_ptr(), out.data_ptr(), R, N, L, _stream()), "ief_transpose_batched_f32")
+    return out
+
+
+def _softmax_bwd_f32_(probs, dprobs, scale):
+    """in place on dprobs: dS = scale * P o (dP - rowsum(dP o P))"""
+    lib = load()
+    L = probs.shape[-1]
+    _check(lib.ief_softmax_bwd_rows_f32(probs.data_ptr(), dprobs.data_ptr(), probs.numel() // L, L, float(scale), _stream()),
+           "ief_softmax_bwd_rows_f32")
+    return dprobs
+
+
+def _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv):
+    """gradients of softmax(scale q k^T) v on MATERIALISED fp32 maps (`/root/reference/p2p/model/register.py:43-51` is the
+    forward being differentiated): P recomputed, dP = dO V^T, dS, then dQ = dS K, dK = dS^T Q, dV = P^T dO -- every
+    product an `ief_gemm_f32` launch in the model's contraction mode"""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (do, "do")):
+        _act32(t, nm)
+    probs = _attn_scores_f32(q, k, heads, scale)                          # [B*h, N, L]
+    ds = _attn_scores_f32(do, v, heads, 1.0, softmax=False)               # dP = dO V^T
+    _softmax_bwd_f32_(probs, ds, scale)
+    if want_dq:
+        dq = _attn_apply_f32(ds, k, heads, out=dq)                        # dQ = dS K   (out: the caller's column slice, if any)
+    if want_dkv:
+        dk = _attn_apply_f32(_transpose_maps_f32(ds), q, heads, out=dk)            # dK = dS^T Q
+        dv = _attn_apply_f32(_transpose_maps_f32(probs), do, heads, out=dv)        # dV = P^T dO
+    return dq, dk, dv
+
+
+def map_loss_blocks_f32(rows):
+    return load().ief_map_loss_rows_blocks(rows)
+
+
+def _attn_map_loss_bwd_f32(q, k, ref, dq, heads, scale, gcoef, accumulate, loss, loss_coef):
+    """fp32 form of `attn_map_loss_bwd` on materialised maps: e = P - ref, dP = gcoef e, dS = scale P o (dP - sum dP P),
+    dq (+)= dS k; loss: fp32 [map_loss_blocks_f32(B*heads*N)] partials"""
+    lib = load()
+    B, N, C = q.shape
+    L = k.shape[1]
+    if tuple(_act32(ref, "ref").shape) != (B * heads, N, L) or not ref.is_contiguous():
+        raise ValueError("attn_map_loss_bwd: ref must be contiguous fp32 [B*heads, N, L]")
+    probs = _attn_scores_f32(q, k, heads, scale)
+    dp = torch.empty_like(probs)
+    rows = B * heads * N
+    if loss is not None and _dev32(loss, "loss").numel() < lib.ief_map_loss_rows_blocks(rows):
+        raise ValueError("attn_map_loss_bwd: loss needs map_loss_blocks_f32(B*heads*N) floats")
+    _check(lib.ief_map_loss_rows_f32(probs.data_ptr(), ref.data_ptr(), dp.data_ptr(), _ptr(loss), rows, L, float(gcoef),
+                                     float(loss_coef), _stream()), "ief_map_loss_rows_f32")
+    _softmax_bwd_f32_(probs, dp, scale)
+    g = _attn_apply_f32(dp, k, heads)
+    if accumulate:
+        add(dq, g, out=dq)
+    else:
+        dq.copy_(g)
+    return dq
+
+
 def axpy(y, x, a):
     """y += a * x (fp32, in place)"""
     lib = load()
@@ -1586,6 +1668,8 @@ def attn_bwd(q, k, v, o, do, lse, heads, scale, dq=None, dk=None, dv=None, ds_mu
     """Gradients of out = softmax(q k^T scale) v w.r.t. q, k, v given dO (`do`), the forward output `o` and its `lse`.
     q/do/o [B,N,h*d], k/v [B,L,h*d] (strided views ok); dq/dk/dv may be column slices of larger buffers."""
     lib = load()
+    if _is32(q):
+        return _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv)
     B, N, _ = q.shape
     L = k.shape[1]
     d = o.shape[-1] // heads
@@ -1635,6 +1719,22 @@ def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None
     """dx (and dx2 for a channel-concat input) of groupnorm(x | x2) [+ SiLU]; `add` is summed into the result.
     stats: (mean, rstd) [B, groups, 2] from `groupnorm(..., return_stats=True)` — enables the split two-launch path."""
     lib = load()
+    if _is32(x):
+        _act32(x, "x"), _act32(dy, "dy")
+        B, C1 = x.shape[0], x.shape[-1]
+        C2 = 0 if x2 is None else _act32(x2, "x2").shape[-1]
+        HW = x.numel() // (B * C1)
+        if not x.is_contiguous() or not dy.is_contiguous() or dy.numel() != B * HW * (C1 + C2) or (
+                x2 is not None and (not x2.is_contiguous() or x2.numel() != B * HW * C2)) or (
+                add is not None and (not _act32(add, "add").is_contiguous() or add.numel() != dy.numel())):
+            raise ValueError("groupnorm_bwd: x / x2 / dy / add must be contiguous, dy and add [B, HW, C1+C2]")
+        dx = torch.empty_like(x)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        with _Timed("gn_bwd_f32_kernel", 0.0):
+            _check(lib.ief_groupnorm_bwd_f32(x.data_ptr(), _ptr(x2), C1, C2, dy.data_ptr(), _ptr(add), dx.data_ptr(), _ptr(dx2),
+                                             _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups,
+                                             eps, 1 if silu else 0, _stream()), "ief_groupnorm_bwd_f32")
+        return (dx, dx2) if x2 is not None else dx
     _dev16(x, "x"), _dev16(dy, "dy")
     B, C1 = x.shape[0], x.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
@@ -1662,6 +1762,16 @@ def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None
 
 def layernorm_bwd(x, dy, gamma, eps=1e-5, add=None):
     lib = load()
+    if _is32(x):
+        _act32(x, "x"), _act32(dy, "dy")
+        if not x.is_contiguous() or not dy.is_contiguous() or dy.shape != x.shape or (
+                add is not None and (not _act32(add, "add").is_contiguous() or add.shape != x.shape)):
+            raise ValueError("layernorm_bwd: x / dy / add must be contiguous and of equal shape")
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        _check(lib.ief_layernorm_bwd_f32(x.data_ptr(), dy.data_ptr(), _ptr(add), dx.data_ptr(), _dev32(gamma, "gamma").data_ptr(),
+                                         x.numel() // C, C, eps, _stream()), "ief_layernorm_bwd_f32")
+        return dx
     _dev16(x, "x"), _dev16(dy, "dy")
     if not x.is_contiguous() or not dy.is_contiguous() or dy.shape != x.shape:
         raise ValueError("layernorm_bwd: x / dy must be contiguous and of equal shape")
@@ -1696,6 +1806,15 @@ def geglu_il(pre, out=None):
 
 def geglu_il_bwd(pre, dy):
     lib = load()
+    if _is32(pre):
+        _act32(pre, "pre"), _act32(dy, "dy")
+        Ch = pre.shape[-1] // 2
+        if not pre.is_contiguous() or not dy.is_contiguous() or dy.shape[-1] != Ch or dy.numel() * 2 != pre.numel():
+            raise ValueError("geglu_il_bwd: pre [..., 2*Ch], dy [..., Ch], both contiguous")
+        dpre = torch.empty_like(pre)
+        _check(lib.ief_geglu_il_bwd_f32(pre.data_ptr(), dy.data_ptr(), dpre.data_ptr(), pre.numel() // (2 * Ch), Ch, _stream()),
+               "ief_geglu_il_bwd_f32")
+        return dpre
     _dev16(pre, "pre"), _dev16(dy, "dy")
     Ch = pre.shape[-1] // 2
     if not pre.is_contiguous() or not dy.is_contiguous() or dy.shape[-1] != Ch or dy.numel() * 2 != pre.numel():
@@ -1709,6 +1828,13 @@ def geglu_il_bwd(pre, dy):
 def zero_insert2x(x):
     """[B,H,W,C] -> [B,2H,2W,C] with x at the even positions, zeros elsewhere (stride-2 conv data gradient)"""
     lib = load()
+    if _is32(x):
+        if _act32(x, "x").dim() != 4 or not x.is_contiguous():
+            raise ValueError("zero_insert2x: contiguous NHWC expected")
+        B, H, W, C = x.shape
+        out = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float32, device=x.device)
+        _check(lib.ief_zero_insert2x_f32(x.data_ptr(), out.data_ptr(), B, H, W, C, _stream()), "ief_zero_insert2x_f32")
+        return out
     _dev16(x, "x")
     if x.dim() != 4 or not x.is_contiguous():
         raise ValueError("zero_insert2x: contiguous NHWC expected")
@@ -1721,6 +1847,13 @@ def zero_insert2x(x):
 def pool2x2_sum(x):
     """[B,2H,2W,C] -> [B,H,W,C] summing each 2x2 block (nearest-2x upsample backward)"""
     lib = load()
+    if _is32(x):
+        if _act32(x, "x").dim() != 4 or not x.is_contiguous() or (x.shape[1] & 1) or (x.shape[2] & 1):
+            raise ValueError("pool2x2_sum: contiguous NHWC with even H, W expected")
+        B, H2, W2, C = x.shape
+        out = torch.empty(B, H2 // 2, W2 // 2, C, dtype=torch.float32, device=x.device)
+        _check(lib.ief_pool2x2_sum_f32(x.data_ptr(), out.data_ptr(), B, H2 // 2, W2 // 2, C, _stream()), "ief_pool2x2_sum_f32")
+        return out
     _dev16(x, "x")
     if x.dim() != 4 or not x.is_contiguous() or (x.shape[1] & 1) or (x.shape[2] & 1):
         raise ValueError("pool2x2_sum: contiguous NHWC with even H, W expected")
@@ -1733,6 +1866,16 @@ def pool2x2_sum(x):
 def conv_out_bwd(d_eps, w):
     """d_eps fp32 NCHW [B,Cout,H,W], w fp16 [Cout,3,3,C] (conv_out's own weight) -> fp16 NHWC [B,H,W,C]"""
     lib = load()
+    if _is32(w):
+        _dev32(d_eps, "d_eps")
+        B, Cout, H, W = d_eps.shape
+        C = w.shape[-1]
+        if tuple(_act32(w, "w").shape) != (Cout, 3, 3, C) or not w.is_contiguous():
+            raise ValueError("conv_out_bwd: weight must be contiguous [Cout, 3, 3, C]")
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=w.device)
+        _check(lib.ief_conv_out_bwd_f32w(d_eps.data_ptr(), w.data_ptr(), out.data_ptr(), B, C, H, W, Cout, _stream()),
+               "ief_conv_out_bwd_f32w")
+        return out
     _dev32(d_eps, "d_eps"), _dev16(w, "w")
     B, Cout, H, W = d_eps.shape
     C = w.shape[-1]
@@ -1762,6 +1905,13 @@ def nti_adam(param, m, v, grad16, stats, hyper, step, param16):
     lib = load()
     for t, nm in ((param, "param"), (m, "m"), (v, "v"), (stats, "stats"), (hyper, "hyper")):
         _dev32(t, nm)
+    if _is32(grad16):       # fp32-storage modes: the context IS the fp32 parameter (param16 unused)
+        if grad16.numel() != param.numel() or not _act32(grad16, "grad").is_contiguous():
+            raise ValueError("nti_adam: gradient shape mismatch")
+        _check(lib.ief_nti_adam_f32g(param.data_ptr(), m.data_ptr(), v.data_ptr(), grad16.data_ptr(), stats.data_ptr(),
+                                     hyper.data_ptr(), _devi32(step, "step").data_ptr(), param.numel(), _stream()),
+               "ief_nti_adam_f32g")
+        return
     _dev16(grad16, "grad16"), _dev16(param16, "param16")
     _devi32(step, "step")
     n = param.numel()

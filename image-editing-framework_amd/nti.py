@@ -56,12 +56,13 @@ class NullTextOptimizer:
         else:
             self.temb_table_c, self.temb_c = self.temb_table, self.temb
         self.lr, self.restart, self.lr_decay = float(lr), bool(restart), float(lr_decay)      # lr_i = lr (1 - i / lr_decay)
-        self.cond16 = hip.to_f16(cond.to(dev).float().contiguous())
+        self.f32 = self.unet.dtype == torch.float32          # fp32-storage modes: the context the UNet reads IS the parameter
+        self.cond16 = self.unet._act(cond.to(dev))
         L, Cc = self.cond16.shape[1:]
         self.param = torch.zeros(1, L, Cc, **f32)
         self.m = torch.zeros_like(self.param)
         self.v = torch.zeros_like(self.param)
-        self.p16 = torch.zeros(1, L, Cc, dtype=torch.float16, device=dev)
+        self.p16 = self.param if self.f32 else torch.zeros(1, L, Cc, dtype=torch.float16, device=dev)
         self.use_graph = use_graph
         self._graphs = None
         self.inner_steps_run: List[int] = []     # per timestep, how many Adam steps the early-stop rule allowed
@@ -82,10 +83,15 @@ class NullTextOptimizer:
         eps_u = self.unet(self.lat, encoder_hidden_states=self.p16, temb_row=self.temb)["sample"]
         hip.cfg_ddim_step(eps_u, self.eps_c, self.lat, self.coef, out=self.lat)
 
+    def _sync_p16(self):
+        if not self.f32:
+            hip.to_f16(self.param, out=self.p16)
+
     def _capture(self):
         for m in self.unet.attention_modules():
             m.cache_kv = False          # the uncond context changes under the same buffer: never cache its K/V
-        saved = [t.clone() for t in (self.lat, self.param, self.m, self.v, self.p16, self.adam_step, self.eps_c)]
+        state = [self.lat, self.param, self.m, self.v, self.adam_step, self.eps_c] + ([] if self.f32 else [self.p16])
+        saved = [t.clone() for t in state]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         need = []
@@ -104,7 +110,7 @@ class NullTextOptimizer:
                 body()
             graphs.append(g)
             self._arenas.append(arena)
-        for t, sv in zip((self.lat, self.param, self.m, self.v, self.p16, self.adam_step, self.eps_c), saved):
+        for t, sv in zip(state, saved):
             t.copy_(sv)
         self._graphs = graphs
 
@@ -122,7 +128,7 @@ class NullTextOptimizer:
         self.lat.copy_(latents[-1].to(dev).float())
         self.param.copy_(uncond.to(dev).float()[:1])
         self._param0 = self.param.clone()
-        hip.to_f16(self.param, out=self.p16)
+        self._sync_p16()
         if self.use_graph and self._graphs is None:
             self._capture()
         elif not self.use_graph:
@@ -138,7 +144,7 @@ class NullTextOptimizer:
             self.temb_c.copy_(self.temb_table_c[i:i + 1])
         if self.restart:
             self.param.copy_(self._param0)
-            hip.to_f16(self.param, out=self.p16)
+            self._sync_p16()
         self.coef.copy_(self.coef_table[i])
         self.target.copy_(latents[len(latents) - i - 2].to(self.dev).float())
         self.m.zero_(), self.v.zero_(), self.adam_step.zero_()          # `Adam([uncond], lr=...)` anew (nti.py:17)

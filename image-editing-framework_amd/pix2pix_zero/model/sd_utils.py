@@ -46,16 +46,24 @@ class _Engine:
         self.x_in = torch.zeros(2, C, h, w, **f32)
         self.zero_eps = torch.zeros(2, C, h, w, **f32)
         self.step_loss = torch.zeros(1, **f32)
-        self.ctx16 = torch.zeros(2, 77, unet.config.cross_attention_dim, dtype=torch.float16, device=dev)
+        adt = unet.dtype                # activation dtype: fp16, or fp32 in the fp32-storage modes (maps then fp32 as well)
+        self.ctx16 = torch.zeros(2, 77, unet.config.cross_attention_dim, dtype=adt, device=dev)
         self.cross = [m for m in unet.attention_modules() if m.is_cross]
         with torch.no_grad():           # one dry forward: allocator warm-up, and every module notes its query count
             unet(self.x_in, encoder_hidden_states=self.ctx16, temb_row=self.temb)
-        self.stage = [torch.zeros(2 * m.heads, m.last_tokens, 77, dtype=torch.float16, device=dev) for m in self.cross]
-        self.maps = [torch.zeros(nsteps, *st.shape, dtype=torch.float16, device=dev) for st in self.stage]
+        self.stage = [torch.zeros(2 * m.heads, m.last_tokens, 77, dtype=adt, device=dev) for m in self.cross]
+        self.maps = [torch.zeros(nsteps, *st.shape, dtype=adt, device=dev) for st in self.stage]
         self.adj = UNetAdjoint(unet, GRAD_SCALE, mode="input")
         self.adj.prepack()
         self.adj.set_reference_maps(self.stage)      # the edit graph reads the staged maps of the current step
         self._ref = self._edit = None
+
+    def set_ctx(self, emb):
+        """fp32 [2,77,C] embeddings -> the context buffer the graphs read"""
+        if self.ctx16.dtype == torch.float32:
+            self.ctx16.copy_(emb)
+        else:
+            hip.to_f16(emb.contiguous(), out=self.ctx16)
 
     def _ref_body(self):
         self.x_in.copy_(self.lat.expand_as(self.x_in))
@@ -142,7 +150,7 @@ class P2P_Zero:
         ts_dev = torch.tensor(ts, **f32)
         null_rows = None
         if uncond_embeddings_list is not None:       # P2P_Zero_NTI: `prompt_embeds[0] = uncond_embeddings_list[i]` (:518,582)
-            null_rows = [hip.to_f16(u.to(dev).float().contiguous())[0] for u in uncond_embeddings_list]
+            null_rows = [unet._act(u.to(dev))[0] for u in uncond_embeddings_list]
 
         def context_of(p):
             """-> ([2,77,C] = (negative, prompt) embeddings, per-step time-embedding rows [steps, 1 or 2, width])"""
@@ -171,7 +179,7 @@ class P2P_Zero:
 
             # ---------------- reference pass: record the maps
             emb, temb_table = context_of(prompt[0])
-            hip.to_f16(emb.contiguous(), out=E.ctx16)
+            E.set_ctx(emb)
             for m, st in zip(E.cross, E.stage):
                 m.map_out = st
             with torch.no_grad():
@@ -191,7 +199,7 @@ class P2P_Zero:
             emb, temb_table = context_of(prompt[1])
             if edit_dir is not None:            # `prompt_embeds_edit += edit_dir` (:145-146)
                 emb = emb + edit_dir.to(dev).float()
-            hip.to_f16(emb.contiguous(), out=E.ctx16)
+            E.set_ctx(emb)
             loss_log = torch.zeros(len(ts), **f32)
             with torch.no_grad():
                 E.lat.copy_(latents_init)

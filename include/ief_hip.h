@@ -314,6 +314,31 @@ int ief_conv_out_f32act(const float* x, const float* w, const float* bias, float
  * (x / 2 + 0.5).clamp(0, 1) * 255 truncated */
 int ief_image_u8(const float* x, unsigned char* out, int B, int C, int H, int Wd, void* stream);
 
+/* ------------------------------------------------------------------ activation gradients of the fp32-storage modes
+ * (csrc/backward_f32.hip): the reverse pass of null-text inversion / Pix2Pix-zero at the reference's precision
+ * (/root/reference/p2p/inversion/nti.py:15-33 and /root/reference/pix2pix-zero/model/sd_utils.py:160-174 run torch autograd in
+ * fp32).  Same formulas as the fp16 entry points below; attention gradients are assembled by the host from ief_gemm_f32
+ * products on MATERIALISED fp32 maps plus ief_softmax_bwd_rows_f32 / ief_transpose_batched_f32. */
+int ief_groupnorm_bwd_f32(const float* x, const float* x2, int C1, int C2, const float* dy, const float* add, float* dx, float* dx2,
+                          const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu, void* stream);
+int ief_layernorm_bwd_f32(const float* x, const float* dy, const float* add, float* dx, const float* gamma, long long rows, int C,
+                          float eps, void* stream);
+int ief_geglu_il_bwd_f32(const float* pre, const float* dy, float* dpre, long long rows, int Ch, void* stream);
+int ief_zero_insert2x_f32(const float* in, float* out, int B, int H, int W, int C, void* stream);   /* [B,H,W,C] -> [B,2H,2W,C] */
+int ief_pool2x2_sum_f32(const float* in, float* out, int B, int H, int W, int C, void* stream);     /* [B,2H,2W,C] -> [B,H,W,C] */
+int ief_conv_out_bwd_f32w(const float* d_eps, const float* w, float* dh, int B, int C, int H, int W, int Cout, void* stream);
+/* in place on dP [rows][L]: dS = scale * P o (dP - sum_j dP_j P_j) */
+int ief_softmax_bwd_rows_f32(const float* P, float* dP, long long rows, int L, float scale, void* stream);
+int ief_transpose_batched_f32(const float* in, float* out, int R, int N, int L, void* stream);        /* [R][N][L] -> [R][L][N] */
+/* Pix2Pix-zero map objective on materialised maps: dP = gcoef (P - ref); loss[block] = loss_coef * sum (P - ref)^2 over the
+ * block's rows (ief_map_loss_rows_blocks(rows) blocks, fixed order) */
+int ief_map_loss_rows_blocks(long long rows);
+int ief_map_loss_rows_f32(const float* P, const float* ref, float* dP, float* loss, long long rows, int L, float gcoef,
+                          float loss_coef, void* stream);
+/* torch.optim.Adam step with an fp32 gradient (g = grad * stats[1]); hyper = {lr, beta1, beta2, eps}; step[0] += 1 */
+int ief_nti_adam_f32g(float* param, float* m, float* v, const float* grad, const float* stats, const float* hyper, int* step, int n,
+                      void* stream);
+
 /* ------------------------------------------------------------------ null-text inversion: activation gradients
  * The reference optimises the unconditional embedding with torch autograd through the whole UNet
  * (/root/reference/p2p/inversion/nti.py:15-33: `uncond_embeddings.requires_grad`, `loss.backward()`,
