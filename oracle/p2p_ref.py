@@ -171,12 +171,16 @@ def ddim_inversion_loop(sd, cfg, cond_emb, latent, sched: DDIMRef, num_steps: Op
 def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps: int = 10,
                       epsilon: float = 1e-5, guidance_scale: float = 7.5,
                       num_outer: Optional[int] = None, added_cond=None, added_uncond=None, lr: float = 1e-2,
-                      restart: bool = False, lr_decay: float = 100.0, grad_trace: Optional[list] = None):
+                      restart: bool = False, lr_decay: float = 100.0, grad_trace: Optional[list] = None,
+                      start: int = 0, cur0: Optional[torch.Tensor] = None):
     """`/root/reference/p2p/inversion/nti.py:9-45` with the oracle UNet as `model.unet`.
     `NTI_XL` (`/root/reference/pix2pix-zero/inversion/nti.py:47-96`; the masactrl and pnp folders hold the same file, the
     p2p folder's copy uses lr = 0.5 (1 - i / 500), `p2p/inversion/nti.py:50,69`) is the same loop with lr = 5e-2 (:69), the embedding
     RESTARTED from the negative prompt embedding at every timestep (:67, `restart`), and the conditional / unconditional
-    UNet calls taking their own `added_cond_kwargs` (:58-61,74,76,90-92)."""
+    UNet calls taking their own `added_cond_kwargs` (:58-61,74,76,90-92).
+    start / cur0 (tests): run timesteps start .. start + num_outer - 1 only, from the latent `cur0` and the embedding in
+    `context` -- the reference's loop body entered with a given state, so that a product run can be checked timestep by
+    timestep from identical starting points."""
     from torch.optim.adam import Adam
     import torch.nn.functional as F
 
@@ -186,9 +190,9 @@ def null_optimization(sd, cfg, latents, context, sched: DDIMRef, num_inner_steps
     if added_cond is not None:
         both = {k: torch.cat([added_uncond[k], added_cond[k]]) for k in added_cond}
     out = []
-    cur = latents[-1]
+    cur = latents[-1] if cur0 is None else cur0
     n = sched.num_inference_steps if num_outer is None else num_outer
-    for i in range(n):
+    for i in range(start, start + n):
         uncond = (uncond0 if restart else uncond).clone().detach()
         uncond.requires_grad = True
         opt = Adam([uncond], lr=lr * (1.0 - i / lr_decay))
