@@ -277,43 +277,49 @@ def _nti_case(pipe, steps, inner, seed=0):
 
 
 def test_nti_loop_vs_oracle(tiny):
-    """epsilon = 0 disables the early stop, so both sides take exactly `inner` Adam steps per timestep and the
-    trajectories can be compared step for step.
+    """epsilon = 0 disables the early stop, so both sides take exactly `inner` Adam steps per timestep.  Every timestep is
+    judged from IDENTICAL starting points: the oracle's loop body (`oracle.p2p_ref.null_optimization(start=i, cur0=...)`) is
+    entered with the product's own latent and embedding of that moment, so nothing accumulates from timestep to timestep and
+    the same strict criterion holds at all of them (round 2 applied it to the first timestep only and a bulk percentile to
+    the others).
 
-    Adam moves every element by ~lr per step whatever |grad| is, so an element whose gradient sits at the fp16 noise
-    floor can legitimately take the other sign; elements with a SIGNIFICANT gradient cannot.  The oracle therefore
-    reports its gradients, and the first timestep (where both sides still start from the same embedding) is judged on the
-    elements whose first gradient is >= 5 % of the largest: after the three Adam steps >= 99 % of them must have moved the
-    oracle's way and >= 98 % must sit within 10 % of the total movement (measured 99.5 % / 99 %; the rest are elements
-    whose later gradients shrink to the noise floor) — a wrong-sign or mis-scaled gradient flips half or all of them.
-    Later timesteps start from already (slightly) different embeddings: the bulk criterion there is what is left."""
+    Adam moves every element by ~lr per step whatever |grad| is, so an element whose gradient sits at the fp16 noise floor
+    (the fp16 pass resolves the gradient to 3-5e-3 of its largest element, `test_unet_context_gradient_*`) can legitimately
+    take the other sign; elements with a SIGNIFICANT gradient cannot.  The oracle reports its gradients, and each timestep
+    is judged on the elements whose first gradient is >= 5 % of the largest: after the three Adam steps >= 99 % of them must
+    have moved the oracle's way and >= 98 % must sit within 10 % of the movement -- a wrong-sign or mis-scaled gradient
+    flips half or all of them; no element may be further than a full step the other way (2.1 movements).  The fp32-storage
+    modes meet an element-by-element bound of 1e-2 instead (tests/test_gpu_grad_f32.py)."""
     steps, inner, outer, gs = 4, 3, 3, 7.5
     ctx, lat_ref, sched = _nti_case(tiny, steps, inner)
-    trace = []
-    ref = p2p_ref.null_optimization(tiny._state_dict, tiny.cfg, lat_ref, ctx, sched, num_inner_steps=inner, epsilon=0.0,
-                                    guidance_scale=gs, num_outer=outer, grad_trace=trace)
     opt = NullTextOptimizer(tiny, ctx[1:], gs, tuple(lat_ref[-1].shape[-2:]))
-    got = opt.run([l.to(DEV) for l in lat_ref], ctx[:1], inner, 0.0, num_outer=outer)
+    opt.begin([l.to(DEV) for l in lat_ref], ctx[:1])
+    for i in range(outer):
+        lat_i, u_i = opt.lat.clone().cpu(), opt.param.clone().cpu()
+        opt.outer_begin(i)
+        for j in range(inner):
+            opt.inner_step()
+            opt.inner_loss()
+        opt.outer_end()
+        a = opt.out[-1].cpu()
+        trace = []
+        b = p2p_ref.null_optimization(tiny._state_dict, tiny.cfg, lat_ref, torch.cat([u_i, ctx[1:]]), sched, num_inner_steps=inner,
+                                      epsilon=0.0, guidance_scale=gs, num_outer=1, start=i, cur0=lat_i, grad_trace=trace)[0]
+        g0 = trace[0][2][:1]
+        strong = g0.abs() >= 0.05 * g0.abs().max()
+        moved = (b - u_i).abs().max().item()
+        diff = (a - b).abs()
+        same_way = (torch.sign(a - u_i)[strong] == torch.sign(b - u_i)[strong]).float().mean().item()
+        near = (diff[strong] <= 0.1 * moved).float().mean().item()
+        frac_close = (diff <= 0.1 * moved).float().mean().item()
+        print(f"NTI timestep {i}: moved {moved:.3e}, max diff {diff.max().item():.3e}; {int(strong.sum())} elements with a significant "
+              f"first gradient: {same_way:.4f} moved the oracle's way, {near:.4f} within 10 % of the movement; all elements within "
+              f"10 %: {frac_close:.4f}")
+        assert strong.sum() > 50
+        assert same_way >= 0.99 and near >= 0.98
+        assert diff.max().item() <= 2.1 * moved
     opt.release()
     assert opt.inner_steps_run == [inner] * outer
-    u0 = ctx[:1]
-    g0 = next(g for i, j, g in trace if (i, j) == (0, 0))
-    strong = g0.abs() >= 0.05 * g0.abs().max()
-    for i, (a, b) in enumerate(zip(got, ref)):
-        a = a.cpu()
-        moved = (b - u0).abs().max().item()
-        diff = (a - b).abs()
-        frac_close = (diff <= 0.1 * moved).float().mean().item()
-        print(f"NTI step {i}: moved {moved:.3e}, max diff {diff.max().item():.3e}, within 10% of movement: {frac_close:.4f}; "
-              f"{int(strong.sum())} elements with a significant first gradient")
-        if i == 0:
-            assert strong.sum() > 50
-            same_way = (torch.sign(a - u0)[strong] == torch.sign(b - u0)[strong]).float().mean().item()
-            near = (diff[strong] <= 0.1 * moved).float().mean().item()
-            print(f"  significant elements: {same_way:.4f} moved the oracle's way, {near:.4f} within 10 % of the movement")
-            assert same_way >= 0.99 and near >= 0.98
-        assert frac_close > 0.93
-        assert diff.max().item() <= 2.1 * moved
 
 
 def test_nti_reduces_reconstruction_error(tiny):
