@@ -29,6 +29,33 @@ def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32, precis
     pipeline with torch_dtype=float32, :38): fp32 weights / activations on the fp32-MFMA kernels.  `--precision` of the
     CLIs, or the IEF_PRECISION environment variable for the folders whose CLIs do not carry the flag."""
     precision = precision or os.environ.get("IEF_PRECISION", "f16")
+    # multi-GPU runs (the PIE drivers under torchrun): rank 0 loads / draws the weights, the others build the same module
+    # tree from zeros and receive the packed tensors by ONE bucketed broadcast (RCCL over xGMI) -- `dist.broadcast_pipeline`
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+    empty = world > 1 and tdist.get_rank() != 0
+    pipe = _build_pipe(sd_version, device, dtype, precision, empty)
+    if world > 1:
+        from ief_amd.dist import broadcast_pipeline
+        pipe._broadcasts = broadcast_pipeline(pipe, src=0)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+    return pipe
+
+
+def init_distributed(device):
+    """process group of a PIE driver started by torchrun: RCCL ("nccl") unless IEF_DIST_BACKEND says otherwise (gloo lets
+    several ranks share ONE GPU: rehearsals of the multi-rank path on a one-GPU box)"""
+    import torch.distributed as tdist
+    backend = os.environ.get("IEF_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        tdist.init_process_group("nccl", device_id=device)
+    else:
+        tdist.init_process_group(backend)
+    return tdist
+
+
+def _build_pipe(sd_version, device, dtype, precision, empty):
     from ief_amd.pipeline import StableDiffusionPipeline
     from ief_amd.scheduler import DDIMScheduler
     from ief_amd.p2p.sd_mapping import sd_maps
@@ -36,9 +63,9 @@ def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32, precis
     scheduler = DDIMScheduler.from_config(SCHEDULER_CONFIG)
     if sd_version in ("1.5", "1.4", "2.1", "tiny", "small", "small21"):
         return StableDiffusionPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device,
-                                                       precision=precision)
+                                                       precision=precision, empty_weights=empty)
     if sd_version in ("xl-base", "smallxl"):       # `StableDiffusionXLPipeline` branch of edit_syn.py:63-65
         from ief_amd.pipeline import StableDiffusionXLPipeline
         return StableDiffusionXLPipeline.from_pretrained(model_key, torch_dtype=dtype, scheduler=scheduler, device=device,
-                                                         precision=precision)
+                                                         precision=precision, empty_weights=empty)
     raise ValueError("please use the right sd_version")

@@ -68,6 +68,30 @@ class NTI_XL(ddim_inversion_xl):
         self.inner_steps_run = opt.inner_steps_run
         return out
 
+    def _optimizer(self, model, latents, context, guidance_scale, lr=None):
+        prompt_embeds, negative_prompt_embeds, pooled, negative_pooled = context
+        height, width = latents[-1].shape[-2] * model.vae_scale_factor, latents[-1].shape[-1] * model.vae_scale_factor
+        dev = model.unet.device
+        ids = model._get_add_time_ids((height, width), (0, 0), (height, width), dtype=prompt_embeds.dtype).to(dev)
+        return NullTextOptimizer(model, prompt_embeds, guidance_scale, tuple(latents[-1].shape[-2:]),
+                                 added_cond={"text_embeds": pooled.to(dev), "time_ids": ids},
+                                 added_uncond={"text_embeds": negative_pooled.to(dev), "time_ids": ids},
+                                 lr=self.LR if lr is None else lr, lr_decay=self.LR_DECAY, restart=True)
+
+    def null_optimization_many(self, model, latents_list, contexts, num_inner_steps, epsilon, guidance_scale):
+        """`null_optimization` for several independent images IN FLIGHT on one GPU (`ief_amd.nti.run_many`), as
+        `NTI.null_optimization_many`; contexts[k]: image k's 4-tuple of `get_context`"""
+        opts = []
+        try:
+            for latents, context in zip(latents_list, contexts):
+                opts.append(self._optimizer(model, latents, context, guidance_scale))
+            outs = run_many(opts, latents_list, [c[1] for c in contexts], num_inner_steps, epsilon)
+        finally:
+            for o in opts:
+                o.release()
+        self.inner_steps_run = [o.inner_steps_run for o in opts]
+        return outs
+
 
 class NTI_XL_5e2(NTI_XL):
     """the `NTI_XL` of the masactrl, pnp and pix2pix-zero folders (identical files): lr = 5e-2 (1 - i / 100)"""

@@ -172,10 +172,12 @@ class P2P:
                 register_attention_control(model, controller)
                 if not _fusable(model, controller, False):
                     raise RuntimeError("edit_many: only controllers lowered to a device plan can run concurrently")
-                uncond_embeddings, text_embeddings = _encode_prompts(model, prompt)
+                # `_encode`: the SD1.x / 2.x text encoder, or (P2P_XL) both SDXL encoders + pooled embedding / time ids
+                uncond_embeddings, text_embeddings, added_cond_kwargs = self._encode(model, prompt, height, width)
                 latent, latents = self.init_latent(latent, model, height, width, None, len(prompt))
                 loop = acquire(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
-                                     (height // 8, width // 8), guidance_scale, uncond_list=uncond_list)
+                                     (height // 8, width // 8), guidance_scale, uncond_list=uncond_list,
+                                     added_cond_kwargs=added_cond_kwargs)
                 loop.start(latents)
                 loops.append(loop)
                 firsts.append(latent)

@@ -74,10 +74,13 @@ def run_items(pipe, editor, invertor, items, size, device, inversion_type="ddim"
                                 for im in originals[b0:b0 + bs]])
             latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk[b0:b0 + bs]])
             k = latent.shape[0]
-            unc, cnd = context.chunk(2)
             for j in range(k):
                 traj.append([t[j:j + 1].clone() for t in latents])
-                ctxs.append(torch.cat([unc[j:j + 1], cnd[j:j + 1]]))
+                if isinstance(context, tuple):       # SDXL family: (prompt, negative, pooled, negative pooled) embeddings
+                    ctxs.append(tuple(t[j:j + 1] for t in context))
+                else:
+                    unc, cnd = context.chunk(2)
+                    ctxs.append(torch.cat([unc[j:j + 1], cnd[j:j + 1]]))
         x_T = [t[-1] for t in traj]
         # null-text optimisation: E images in flight
         uncond = [None] * len(chunk)
@@ -131,13 +134,11 @@ def main(argv=None):
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        from _bootstrap import init_distributed
+        dist = init_distributed(device)       # rank 0 loads the weights; `load_pipe` broadcasts them (RCCL over xGMI)
     seed_everything(42)
     pipe = load_pipe(args.sd_version, device, precision=args.precision)
     xl = pipe.__class__.__name__ == "StableDiffusionXLPipeline"          # dispatch of test.py:86-104
-    if xl and (args.invert_batch > 1 or args.in_flight > 1):
-        raise NotImplementedError("--invert_batch / --in_flight on the SDXL family: run the reference's per-image order")
     if args.inversion_type == "ddim":
         editor = (P2P_XL if xl else P2P)(model=pipe, num_inference_steps=50)
         invertor = ddim_inversion_xl() if xl else ddim_inversion()

@@ -60,8 +60,10 @@ class StableDiffusionPipeline:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
-                        keep_state_dict: bool = False, precision: str = "f16", **unused):
-        """precision: "f16" (default: fp16 storage / fp32 accumulation, the fast path whatever `torch_dtype` says) or
+                        keep_state_dict: bool = False, precision: str = "f16", empty_weights: bool = False, **unused):
+        """empty_weights: build the UNet from ZERO tensors of the right shapes without drawing / reading any weight -- what
+        every rank but 0 of a multi-GPU run does before `dist.broadcast_pipeline` overwrites the packed tensors.
+        precision: "f16" (default: fp16 storage / fp32 accumulation, the fast path whatever `torch_dtype` says) or
         "f32" — the reference's own precision (`/root/reference/p2p/edit_syn.py:38` loads the pipeline in fp32): UNet and
         VAE run on the fp32-MFMA kernels, edited images then agree with the fp32 reference to ~1e-4"""
         from .unet import UNet2DConditionModel
@@ -69,12 +71,12 @@ class StableDiffusionPipeline:
             parts = model_key.split(":")
             cfg = CONFIGS[parts[1]]
             seed = int(parts[2]) if len(parts) > 2 else 0
-            sd = _weights.synthetic_state_dict(cfg, seed)
+            sd = _zeros_state_dict(cfg) if empty_weights else _weights.synthetic_state_dict(cfg, seed)
             tokenizer = WordPieceTokenizer(cfg.text_max_length)
             text_encoder = SyntheticTextEncoder(cfg.cross_attention_dim)
             vae = AutoencoderKL(SD_VAE if parts[1] in ("sd15", "sd21") else TINY_VAE, device=device, precision=precision)
         elif os.path.isdir(model_key):
-            cfg, sd = _load_local_unet(model_key)
+            cfg, sd = _load_local_unet(model_key, empty=empty_weights)
             tokenizer, text_encoder = _load_local_text(model_key, cfg)
             vae = _load_local_vae(model_key, device, precision)
         else:
@@ -113,14 +115,14 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
 
     @classmethod
     def from_pretrained(cls, model_key: str, torch_dtype=None, scheduler=None, device="cuda:0",
-                        keep_state_dict: bool = False, precision: str = "f16", **unused):
+                        keep_state_dict: bool = False, precision: str = "f16", empty_weights: bool = False, **unused):
         from .unet import UNet2DConditionModel
         import dataclasses
         sched = scheduler if scheduler is not None else DDIMScheduler()
         if os.path.isdir(model_key):
             # a local diffusers-layout SDXL directory: unet/ and vae/ are required; text_encoder/ and text_encoder_2/ (CLIP
             # weights for `transformers`) and tokenizer/ are used when present, seeded stand-ins otherwise
-            cfg, sd = _load_local_unet(model_key)
+            cfg, sd = _load_local_unet(model_key, empty=empty_weights)
             if not cfg.addition_embed:
                 raise ValueError(f"{model_key}: unet/config.json is not an SDXL-family configuration")
             vae = _load_local_vae(model_key, device, precision)
@@ -138,7 +140,7 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         if not cfg.addition_embed:
             raise ValueError(f"{parts[1]} is not an SDXL-family configuration")
         seed = int(parts[2]) if len(parts) > 2 else 0
-        sd = _weights.synthetic_state_dict(cfg, seed)
+        sd = _zeros_state_dict(cfg) if empty_weights else _weights.synthetic_state_dict(cfg, seed)
         d2 = cfg.pooled_text_dim
         tokenizer = WordPieceTokenizer(cfg.text_max_length)
         enc1 = SyntheticTextEncoder(cfg.cross_attention_dim - d2, seed=1).to(device)
@@ -187,7 +189,12 @@ class StableDiffusionXLPipeline(StableDiffusionPipeline):
         return torch.tensor([list(original_size + crops_coords_top_left + target_size)], dtype=dtype)
 
 
-def _load_local_unet(path):
+def _zeros_state_dict(cfg):
+    """zero tensors with the UNet's parameter names and shapes (a rank that will RECEIVE the packed weights)"""
+    return {k: torch.zeros(shape) for k, shape in _weights.unet_param_shapes(cfg).items()}
+
+
+def _load_local_unet(path, empty=False):
     import json
     from safetensors.torch import load_file
     with open(os.path.join(path, "unet", "config.json")) as f:
@@ -208,6 +215,8 @@ def _load_local_unet(path):
         addition_time_embed_dim=c.get("addition_time_embed_dim") or 256,
         pooled_text_dim=(c["projection_class_embeddings_input_dim"] - 6 * (c.get("addition_time_embed_dim") or 256))
         if c.get("addition_embed_type") == "text_time" else 1280)
+    if empty:
+        return cfg, _zeros_state_dict(cfg)
     sd = load_file(os.path.join(path, "unet", "diffusion_pytorch_model.safetensors"))
     missing = [k for k in _weights.unet_param_shapes(cfg) if k not in sd]
     if missing:

@@ -45,8 +45,8 @@ def main(argv=None):
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        from _bootstrap import init_distributed
+        dist = init_distributed(device)       # rank 0 loads the weights; `load_pipe` broadcasts them (RCCL over xGMI)
     seed_everything(42)
     pipe = load_pipe(args.sd_version, device)
     num_inference_steps, guidance_scale = 50, 7.5

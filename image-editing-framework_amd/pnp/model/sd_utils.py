@@ -103,8 +103,6 @@ class PnP:
         dev = model.unet.device
         if not guidance_scale > 1.0:
             raise NotImplementedError("PnP.edit_many: classifier-free guidance is what the reference's drivers run")
-        if self.xl:
-            raise NotImplementedError("PnP.edit_many on the SDXL family: run the sampler once per image")
         model.scheduler.set_timesteps(num_inference_steps)
         height = height or model.unet.config.sample_size * model.vae_scale_factor
         width = width or model.unet.config.sample_size * model.vae_scale_factor
@@ -114,7 +112,12 @@ class PnP:
             for job in jobs:
                 prompt, latents = job[0], job[1]
                 uncond_list = job[2] if len(job) > 2 else None
-                uncond_embeddings, text_embeddings = _encode_prompts(model, list(prompt))
+                added_cond_kwargs = None
+                if self.xl:       # as `__call__`: both text encoders, pooled embedding and time ids
+                    emb, added_cond_kwargs = encode_prompt_xl(model, list(prompt), dev, True, height, width, len(prompt))
+                    uncond_embeddings, text_embeddings = emb[:len(prompt)], emb[len(prompt):]
+                else:
+                    uncond_embeddings, text_embeddings = _encode_prompts(model, list(prompt))
                 latents = latents.to(dev).float() * model.scheduler.init_noise_sigma
                 if latents.shape[0] == 1:
                     latents = latents.expand(len(prompt), C, height // 8, width // 8)
@@ -122,7 +125,8 @@ class PnP:
                               qk_injection_t=int(num_inference_steps * pnp_attn_t))
                 try:
                     loop = acquire(model, torch.cat([uncond_embeddings, text_embeddings]), len(prompt),
-                                   (height // 8, width // 8), guidance_scale, uncond_list=uncond_list)
+                                   (height // 8, width // 8), guidance_scale, uncond_list=uncond_list,
+                                   added_cond_kwargs=added_cond_kwargs)
                     loops.append(loop)
                     loop.start(latents)
                 finally:                                    # the captured graph carries the plan's tables

@@ -46,8 +46,8 @@ def main(argv=None):
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        from _bootstrap import init_distributed
+        dist = init_distributed(device)       # rank 0 loads the weights; `load_pipe` broadcasts them (RCCL over xGMI)
     seed_everything(42)
     pipe = load_pipe(args.sd_version, device)
     num_inference_steps, guidance_scale, pnp_attn_t, pnp_f_t = 50, 7.5, 1.0, 1.0
@@ -71,8 +71,6 @@ def main(argv=None):
     bs = max(1, args.invert_batch)
     E = max(1, args.in_flight)
     if E > 1:
-        if xl:
-            raise NotImplementedError("--in_flight on the SDXL family: run the reference's per-image order")
         bs = max(bs, E)
     writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
     torch.cuda.synchronize()

@@ -151,3 +151,23 @@ def test_masactrl_edit_real_and_pie_driver(tmp_path):
               cwd=str(tmp_path))
     rec = json.loads(out.strip().splitlines()[-1])
     assert rec["images"] == 2 and rec["images_per_sec"] > 0
+
+
+def test_pie_driver_two_ranks_weight_broadcast_and_shards(tmp_path):
+    """the PIE driver itself on two ranks (torchrun, both on this box's one GPU over gloo: RCCL refuses two ranks per device):
+    rank 0 draws the weights, rank 1 builds its pipeline from zeros and receives the packed UNet + VAE tensors by the
+    driver's broadcast (`_bootstrap.load_pipe` -> `dist.broadcast_pipeline`); the shards are disjoint and complete, and the
+    PNGs equal a one-rank run's -- which they can only do if rank 1 got rank 0's weights."""
+    a, b = tmp_path / "one", tmp_path / "two"
+    run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "4", "--exp_path", str(a)], cwd=str(tmp_path))
+    out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29655", os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "4",
+               "--exp_path", str(b)], cwd=str(tmp_path), env={"IEF_DIST_BACKEND": "gloo"}, timeout=900)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["images"] == 4 and rec["n_gpus"] == 2
+    dirs = sorted(x for x in os.listdir(a) if x.startswith("syn_"))
+    assert len(dirs) == 4 and sorted(x for x in os.listdir(b) if x.startswith("syn_")) == dirs
+    for d in dirs:
+        for name in ("inversion.png", "edit.png"):
+            pa, pb = np.array(Image.open(a / d / name)).astype(int), np.array(Image.open(b / d / name)).astype(int)
+            assert pa.shape == pb.shape and np.abs(pa - pb).max() == 0, (d, name)

@@ -447,6 +447,39 @@ def test_xl_drivers_and_masactrl_clis(tmp_path):
         assert json.loads(r.stdout.strip().splitlines()[-1])["images"] == 1
 
 
+def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
+    """`--invert_batch` / `--in_flight` on the SDXL family (round 2 raised NotImplementedError): batched `ddim_inversion_xl`,
+    `P2P_XL.edit_many` / `PnP_XL.edit_many` with the prompts' `added_cond_kwargs`, `NTI_XL.null_optimization_many` -- the
+    schedules regroup independent images, so the PNGs must equal the per-image run's (`/root/reference/p2p/test.py:114-181`
+    is the per-image loop)"""
+    import json
+    pkg = os.path.join(ROOT, "image-editing-framework_amd")
+
+    def drive(folder, out, *flags):
+        r = subprocess.run([sys.executable, os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "3",
+                            "--exp_path", str(out)] + list(flags), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (folder, flags, r.stderr[-3000:])
+        assert json.loads(r.stdout.strip().splitlines()[-1])["images"] == 3
+
+    def same(a, b):
+        dirs = sorted(x for x in os.listdir(a) if x.startswith("syn_"))
+        assert len(dirs) == 3
+        for d in dirs:
+            for name in ("inversion.png", "edit.png"):
+                pa, pb = np.array(Image.open(a / d / name)).astype(int), np.array(Image.open(b / d / name)).astype(int)
+                assert pa.shape == pb.shape and np.abs(pa - pb).max() <= 1, (d, name, np.abs(pa - pb).max())
+
+    for folder in ("p2p", "pnp"):
+        one, many = tmp_path / (folder + "_one"), tmp_path / (folder + "_many")
+        drive(folder, one)
+        drive(folder, many, "--invert_batch", "3", "--in_flight", "2")
+        same(one, many)
+    one, many = tmp_path / "nti_one", tmp_path / "nti_many"
+    drive("p2p", one, "--inversion_type", "null-text")
+    drive("p2p", many, "--inversion_type", "null-text", "--invert_batch", "2", "--in_flight", "2")
+    same(one, many)
+
+
 # ------------------------------------------------------------------------------------------------ Plug-and-Play on the XL family
 def test_pnp_xl_forward_loop_and_cli(xlpipe, tmp_path):
     """`PnP_XL`: the `_xl` injection sites (self-attention of every transformer block of up_blocks[1]; conv2 output of
