@@ -43,7 +43,7 @@ def main(argv=None):
     nti = args.inversion_type == "null-text"
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local}")
+    device = torch.device(f"cuda:{local % max(1, torch.cuda.device_count())}")   # ranks beyond the device count share GPUs (gloo rehearsals)
     torch.cuda.set_device(device)
     if world > 1:
         from _bootstrap import init_distributed
