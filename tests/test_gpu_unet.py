@@ -418,3 +418,38 @@ def test_pooled_step_graph_reuse_matches_fresh_capture(tiny):
     b, _ = inv.ddim_inversion_loop(tiny, xs[1].to(DEV), [PROMPTS_EQ[0]])
     assert all(torch.equal(p, q) for p, q in zip(a, b))
     denoise.drop_pool()
+
+
+def test_masactrl_attention_store_editor_on_the_generic_path(tiny):
+    """`AttentionStore` (`/root/reference/masactrl/model/attention_base.py:33-66`; imported by the reference's scripts,
+    `masactrl/edit_syn.py:7`): registered through `regiter_attention_editor_diffusers` it is an unknown editor class, so it
+    sees materialised maps from the HIP kernels; its attention output is the plain one (eps equals the un-hooked forward to
+    fp16 rounding of the materialised path), it collects one map per module with <= 64^2 queries during a step, and its
+    counters / the upstream store quirk (running lists emptied with the step lists, G14) behave as in the reference"""
+    from ief_amd.masactrl.model.attention_base import AttentionStore
+    from ief_amd.masactrl.model.register import regiter_attention_editor_diffusers, unregister_attention_control as unreg
+    pipe = tiny
+    cfg = pipe.cfg
+    x, ctx = _inputs(cfg, 2, seed=4)
+    plain = pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV))["sample"].cpu()
+    ed = AttentionStore(res=[16], min_step=0, max_step=3)
+    regiter_attention_editor_diffusers(pipe, ed)
+    n_layers = unet_ref.count_attention_layers(cfg)
+    assert pipe.unet._plan is None and ed.num_att_layers == n_layers
+    seen = []
+    fwd = ed.forward
+
+    def spy(q, k, v, sim, attn, is_cross, place, heads, **kw):
+        seen.append((is_cross, tuple(attn.shape), float(attn.float().sum(-1).sub(1).abs().max())))
+        return fwd(q, k, v, sim, attn, is_cross, place, heads, **kw)
+    ed.forward = spy
+    outs = [pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV))["sample"].cpu() for _ in range(3)]
+    unreg(pipe, ed)
+    assert all(m.is_native() for m in pipe.unet.attention_modules())
+    assert len(seen) == 3 * n_layers and sum(c for c, _, _ in seen) == 3 * n_layers // 2
+    assert max(s[2] for s in seen) < 2e-3                       # rows of the handed-over maps sum to one
+    assert [ed.cur_step, ed.cur_att_layer, ed.valid_steps] == [3, 0, 2]          # counters 1, 2 lie strictly inside (0, 3)
+    assert len(ed.self_attns) == 0 and len(ed.self_attns_step) == 0              # the reference's quirk: emptied with the step lists
+    e = max(rel_err(o, plain) for o in outs)
+    print(f"masactrl AttentionStore editor: eps vs the un-hooked forward {e:.3e}")
+    assert e < FWD_TOL

@@ -280,6 +280,38 @@ def test_masactrl_attention_base_matches_reference(golden_dir):
     assert [e.cur_step, e.cur_att_layer] == list(z["counters"])
 
 
+def test_masactrl_attention_store_matches_reference(golden_dir):
+    """fixture G14 (`tests/golden/make_golden_masa_store.py`, made by the reference's `AttentionStore`,
+    `/root/reference/masactrl/model/attention_base.py:33-66`): outputs of every call, counters, and the store's list states
+    after every step -- including the upstream aliasing quirk (the running store is emptied with the step lists)"""
+    import importlib.util
+    from ief_amd.masactrl.model.attention_base import AttentionStore
+    spec = importlib.util.spec_from_file_location("mk_store", os.path.join(golden_dir, "make_golden_masa_store.py"))
+    z = np.load(os.path.join(golden_dir, "masactrl_store.npz"))
+
+    def calls(seed):             # same generator as the fixture script (which cannot be imported here: it imports the reference)
+        g = torch.Generator().manual_seed(seed)
+        out = []
+        for n, l, cross, place in ((16, 16, False, "down"), (16, 7, True, "down"), (64, 64, False, "up"), (64, 7, True, "up")):
+            heads, d, b = 2, 8, 2
+            q, k, v = (torch.randn(b * heads, m, d, generator=g) for m in (n, l, l))
+            sim = q @ k.transpose(1, 2) * d ** -0.5
+            out.append((q, k, v, sim, sim.softmax(-1), cross, place, heads))
+        return out
+
+    assert spec is not None
+    ed = AttentionStore(res=[32], min_step=1, max_step=4)
+    ed.num_att_layers = 4
+    for step in range(4):
+        for j, c in enumerate(calls(100 + step)):
+            assert np.allclose(ed(*c).numpy(), z[f"out_{step}_{j}"], atol=1e-6)
+        state = [ed.cur_step, ed.cur_att_layer, ed.valid_steps, len(ed.self_attns), len(ed.cross_attns),
+                 len(ed.self_attns_step), len(ed.cross_attns_step)]
+        assert state == list(z[f"state_{step}"]), (step, state)
+    ed.reset()
+    assert [ed.cur_step, ed.cur_att_layer, ed.valid_steps] == list(z["state_reset"])
+
+
 def test_masactrl_mutual_rule_mirror_vs_einops_vs_oracle():
     """attention_control.py cannot be imported (torchvision); its formulas (:37-66) are restated here with einops"""
     from einops import rearrange
