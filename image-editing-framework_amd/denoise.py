@@ -287,6 +287,13 @@ class CfgSplitDenoiser(FusedDenoiser):
         want = num_latents
         if plan is not None and plan.kind == "p2p" and (not plan.cond_only or self.half != 1 or plan.batch != want):
             raise ValueError('CFG split: register the controller with rows="cond" on rank 1 and rows="uncond" on rank 0')
+        # every other plan kind (MasaCtrl, Plug-and-Play) and every Python hook was built for the FULL [uncond..., cond...]
+        # batch: on a half batch its row indirections would point at the wrong or at missing rows without any error
+        if plan is not None and plan.kind not in ("p2p", "empty"):
+            raise ValueError(f"CFG split: a '{plan.kind}' control plan addresses the full CFG batch; only Prompt-to-Prompt "
+                             'controllers registered with rows="cond" / "uncond" (or no controller) can be split')
+        if plan is None and not all(m.is_native() for m in model.unet.attention_modules()):
+            raise ValueError("CFG split: an attention hook is installed that was written for the full CFG batch")
         super().__init__(model, cfg_split_rows(context, num_latents, self.half), num_latents, latent_hw, None, mode="denoise",
                          uncond_list=uncond_list if self.half == 0 else None, use_graph=use_graph)
         C = self.unet.config.in_channels

@@ -430,11 +430,25 @@ def _splitk_counters(device, n, combine_kb=0):
     if n > _CNT_RING:
         return None
     if ring[1] + n > _CNT_RING:
-        ring[1] = 0
+        # wrap: the slots about to be re-used may belong to launches of OTHER streams that have not run yet, and a launch
+        # that faulted (or an exception between two ticket draws) leaves non-zero counters behind -- wait for the device and
+        # zero the ring before handing its start out again (once per ~_CNT_RING counters: not on the hot path, which is the
+        # captured graph with its own arena)
+        reset_counters(device)
     ptr = ring[0].data_ptr() + 4 * ring[1]
     ring[1] += n
     _cnt_used += n
     return ptr
+
+
+def reset_counters(device=None):
+    """zero the eager split-K arrival-counter ring(s) after a device sync -- on wrap, and for callers recovering from a failed
+    launch (a faulted kernel leaves its tickets drawn: every later launch re-using those slots would combine too early or never)"""
+    for dev, ring in _cnt_ring.items():
+        if device is None or dev == device:
+            torch.cuda.synchronize(dev)
+            ring[0].zero_()
+            ring[1] = 0
 
 
 def _tile_count(lib, tile_hint, M, N, splits=1):

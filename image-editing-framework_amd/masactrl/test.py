@@ -55,19 +55,21 @@ def main(argv=None):
             items += PIE(args.dataset_path, None, category=category).items
     mine = list(range(rank, len(items), world))
     writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in mine:
-        image_path, source_prompt, target_prompt = items[i]
-        original = Image.open(image_path).convert("RGB").resize((size, size))
-        images = edit_one(pipe, editor, invertor, original, [source_prompt], [target_prompt], args.inversion_type, device, size)
-        if not args.no_save:
-            out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
-            os.makedirs(out_path, exist_ok=True)
-            writer.save_pil(original, os.path.join(out_path, "source.png"))
-            writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
-            writer.save_img(images[1], os.path.join(out_path, "edit.png"))
-    writer.close()                # the timing includes the last files
+    try:                           # the pool is drained (and a failed write reported) even if the GPU loop raises
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in mine:
+            image_path, source_prompt, target_prompt = items[i]
+            original = Image.open(image_path).convert("RGB").resize((size, size))
+            images = edit_one(pipe, editor, invertor, original, [source_prompt], [target_prompt], args.inversion_type, device, size)
+            if not args.no_save:
+                out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+                os.makedirs(out_path, exist_ok=True)
+                writer.save_pil(original, os.path.join(out_path, "source.png"))
+                writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+                writer.save_img(images[1], os.path.join(out_path, "edit.png"))
+    finally:
+        writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

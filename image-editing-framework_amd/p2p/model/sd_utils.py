@@ -133,9 +133,15 @@ class P2P:
             raise NotImplementedError("CFG split is built for the SD1.x / SD2.x pipelines")
         latent, latents = self.init_latent(latent, model, height, width, None, batch_size)
         # both ranks must start from the SAME x_T: take the first rank's (seeded draws agree anyway; a passed-in latent might not)
-        x0 = latents.float().contiguous().cpu()
-        dist.broadcast(x0, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        latents = x0.to(model.device)
+        # (a host tensor only on a gloo group: an RCCL group has no backend for CPU tensors -- as `denoise.exchange_eps`)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        if dist.get_backend(group) == "gloo":
+            x0 = latents.float().contiguous().cpu()
+            dist.broadcast(x0, src=src, group=group)
+            latents = x0.to(model.device)
+        else:
+            latents = latents.float().contiguous().clone()
+            dist.broadcast(latents, src=src, group=group)
         model.scheduler.set_timesteps(num_inference_steps)
         loop = CfgSplitDenoiser(model, torch.cat([uncond_embeddings, text_embeddings]), batch_size,
                                 (height // 8, width // 8), guidance_scale, group=group, uncond_list=uncond_embeddings_list)

@@ -161,19 +161,21 @@ def main(argv=None):
     t0 = time.perf_counter()
 
     writer = PngWriter()          # encodes / writes on host threads: the GPU loop never waits for a file
+    try:                           # the pool is drained (and a failed write reported) even if the GPU loop raises
 
-    def save(image_path, original, images):
-        if args.no_save:
-            return
-        out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
-        os.makedirs(out_path, exist_ok=True)
-        writer.save_pil(original, os.path.join(out_path, "source.png"))
-        writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
-        writer.save_img(images[1], os.path.join(out_path, "edit.png"))
+        def save(image_path, original, images):
+            if args.no_save:
+                return
+            out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+            os.makedirs(out_path, exist_ok=True)
+            writer.save_pil(original, os.path.join(out_path, "source.png"))
+            writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+            writer.save_img(images[1], os.path.join(out_path, "edit.png"))
 
-    run_items(pipe, editor, invertor, [items[i] for i in mine], size, device, args.inversion_type, args.invert_batch,
-              args.in_flight, save)
-    writer.close()                # the timing below includes the last files
+        run_items(pipe, editor, invertor, [items[i] for i in mine], size, device, args.inversion_type, args.invert_batch,
+                  args.in_flight, save)
+    finally:
+        writer.close()                # the timing below includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

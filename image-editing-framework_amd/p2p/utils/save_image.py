@@ -14,18 +14,43 @@ def save_img(image, path):
 class PngWriter:
     """PNG encoding (zlib, ~30 ms per 512x512 image) on host threads, so the GPU loop of a PIE driver never waits for a
     file between two edits (the reference writes synchronously, `/root/reference/p2p/utils/save_image.py:6-14`,
-    `p2p/test.py:171-178`).  `flush()` waits for every file and re-raises a writer's exception."""
+    `p2p/test.py:171-178`).  A writer's exception (disk full, bad path) surfaces at the NEXT `save_*` call after the file
+    failed -- not only at the end of the dataset -- and at `flush()` / `close()`, which wait for every file; used as a context
+    manager the pool is drained even when the GPU loop itself raises."""
 
     def __init__(self, workers: int = 2):
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=workers)
         self._pending = []
 
+    def _reap(self):
+        """drop finished writes, re-raising the first one that failed"""
+        still = []
+        for f in self._pending:
+            if f.done():
+                f.result()
+            else:
+                still.append(f)
+        self._pending = still
+
     def save_img(self, image, path):
+        self._reap()
         self._pending.append(self._pool.submit(save_img, np.array(image, copy=True), path))
 
     def save_pil(self, image, path):
+        self._reap()
         self._pending.append(self._pool.submit(image.save, path))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            self.close()
+        except Exception:
+            if exc_type is None:
+                raise                   # a write failed and nothing else did: report it
+        return False                    # otherwise the loop's own exception propagates (the pool is shut down either way)
 
     def flush(self):
         pending, self._pending = self._pending, []
@@ -33,8 +58,10 @@ class PngWriter:
             f.result()
 
     def close(self):
-        self.flush()
-        self._pool.shutdown()
+        try:
+            self.flush()
+        finally:
+            self._pool.shutdown()
 
 
 def save_images(images, path, num_rows=1, offset_ratio=0.02):

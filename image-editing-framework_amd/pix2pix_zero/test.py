@@ -70,33 +70,35 @@ def main(argv=None):
     mine = list(range(rank, len(items), world))
     bs = max(1, args.invert_batch)
     writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for c0 in range(0, len(mine), bs):
-        chunk = [items[i] for i in mine[c0:c0 + bs]]
-        originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
-        latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32) for im in originals])
-        latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
-        for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
-            extra = {}
-            if nti:
-                lat_j = [l[j:j + 1].clone() for l in latents]
-                if xl:      # the encoder's 4-tuple, one row per image
-                    ctx_j = tuple(c[j:j + 1] for c in context)
-                else:
-                    ctx_j = torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]])
-                extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, lat_j, ctx_j, num_inner_steps,
-                                                                             early_stop_epsilon, guidance_scale)
-            image_source, image_edit = editor(prompt=[source_prompt] + [target_prompt],
-                                              num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                                              only_sample=False, edit_dir=None, latents=latents[-1][j:j + 1].clone(), **extra)
-            if not args.no_save:
-                out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
-                os.makedirs(out_path, exist_ok=True)
-                writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
-                writer.save_img(image_source, os.path.join(out_path, "inversion.png"))
-                writer.save_img(image_edit, os.path.join(out_path, "edit.png"))
-    writer.close()                # the timing includes the last files
+    try:                           # the pool is drained (and a failed write reported) even if the GPU loop raises
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c0 in range(0, len(mine), bs):
+            chunk = [items[i] for i in mine[c0:c0 + bs]]
+            originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
+            latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32) for im in originals])
+            latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
+            for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
+                extra = {}
+                if nti:
+                    lat_j = [l[j:j + 1].clone() for l in latents]
+                    if xl:      # the encoder's 4-tuple, one row per image
+                        ctx_j = tuple(c[j:j + 1] for c in context)
+                    else:
+                        ctx_j = torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]])
+                    extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, lat_j, ctx_j, num_inner_steps,
+                                                                                 early_stop_epsilon, guidance_scale)
+                image_source, image_edit = editor(prompt=[source_prompt] + [target_prompt],
+                                                  num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                                  only_sample=False, edit_dir=None, latents=latents[-1][j:j + 1].clone(), **extra)
+                if not args.no_save:
+                    out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+                    os.makedirs(out_path, exist_ok=True)
+                    writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
+                    writer.save_img(image_source, os.path.join(out_path, "inversion.png"))
+                    writer.save_img(image_edit, os.path.join(out_path, "edit.png"))
+    finally:
+        writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

@@ -73,49 +73,51 @@ def main(argv=None):
     if E > 1:
         bs = max(bs, E)
     writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for c0 in range(0, len(mine), bs):
-        chunk = [items[i] for i in mine[c0:c0 + bs]]
-        originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
-        latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32) for im in originals])
-        latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
-        if E > 1 and not nti:       # the chunk's edits in flight, E at a time; same images as the per-image calls below
-            for e0 in range(0, len(chunk), E):
-                part = list(range(e0, min(e0 + E, len(chunk))))
-                jobs = []
-                for j in part:
-                    x_T = latents[-1][j:j + 1].clone()
-                    jobs.append(([chunk[j][1], chunk[j][2]], torch.cat([x_T, x_T])))
-                outs = editor.edit_many(jobs, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                                        pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t)
-                for j, images in zip(part, outs):
-                    if not args.no_save:
-                        out_path = os.path.join(args.exp_path, os.path.relpath(chunk[j][0].split(".")[0], root))
-                        os.makedirs(out_path, exist_ok=True)
-                        writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
-                        writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
-                        writer.save_img(images[1], os.path.join(out_path, "edit.png"))
-            continue
-        for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
-            x_T = latents[-1][j:j + 1].clone()
-            extra = {}
-            if nti:         # `PnP_NTI` (`/root/reference/pnp/test.py:132-`): null-text optimisation of this image first
-                lat_j = [l[j:j + 1].clone() for l in latents]
-                ctx_j = (tuple(c[j:j + 1] for c in context) if xl else
-                         torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]]))
-                extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, lat_j, ctx_j, num_inner_steps,
-                                                                             early_stop_epsilon, guidance_scale)
-            images = editor(prompt=[source_prompt] + [target_prompt], num_inference_steps=num_inference_steps,
-                            guidance_scale=guidance_scale, pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t,
-                            latents=torch.cat([x_T, x_T]), **extra)
-            if not args.no_save:
-                out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
-                os.makedirs(out_path, exist_ok=True)
-                writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
-                writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
-                writer.save_img(images[1], os.path.join(out_path, "edit.png"))
-    writer.close()                # the timing includes the last files
+    try:                           # the pool is drained (and a failed write reported) even if the GPU loop raises
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c0 in range(0, len(mine), bs):
+            chunk = [items[i] for i in mine[c0:c0 + bs]]
+            originals = [Image.open(path).convert("RGB").resize((size, size)) for path, _, _ in chunk]
+            latent = torch.cat([invertor.image2latent(model=pipe, image=im, device=device, dtype=torch.float32) for im in originals])
+            latents, context = invertor.ddim_inversion_loop(pipe, latent, [src for _, src, _ in chunk])
+            if E > 1 and not nti:       # the chunk's edits in flight, E at a time; same images as the per-image calls below
+                for e0 in range(0, len(chunk), E):
+                    part = list(range(e0, min(e0 + E, len(chunk))))
+                    jobs = []
+                    for j in part:
+                        x_T = latents[-1][j:j + 1].clone()
+                        jobs.append(([chunk[j][1], chunk[j][2]], torch.cat([x_T, x_T])))
+                    outs = editor.edit_many(jobs, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                            pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t)
+                    for j, images in zip(part, outs):
+                        if not args.no_save:
+                            out_path = os.path.join(args.exp_path, os.path.relpath(chunk[j][0].split(".")[0], root))
+                            os.makedirs(out_path, exist_ok=True)
+                            writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
+                            writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+                            writer.save_img(images[1], os.path.join(out_path, "edit.png"))
+                continue
+            for j, (image_path, source_prompt, target_prompt) in enumerate(chunk):
+                x_T = latents[-1][j:j + 1].clone()
+                extra = {}
+                if nti:         # `PnP_NTI` (`/root/reference/pnp/test.py:132-`): null-text optimisation of this image first
+                    lat_j = [l[j:j + 1].clone() for l in latents]
+                    ctx_j = (tuple(c[j:j + 1] for c in context) if xl else
+                             torch.cat([context[j:j + 1], context[len(chunk) + j:len(chunk) + j + 1]]))
+                    extra["uncond_embeddings_list"] = invertor.null_optimization(pipe, lat_j, ctx_j, num_inner_steps,
+                                                                                 early_stop_epsilon, guidance_scale)
+                images = editor(prompt=[source_prompt] + [target_prompt], num_inference_steps=num_inference_steps,
+                                guidance_scale=guidance_scale, pnp_attn_t=pnp_attn_t, pnp_f_t=pnp_f_t,
+                                latents=torch.cat([x_T, x_T]), **extra)
+                if not args.no_save:
+                    out_path = os.path.join(args.exp_path, os.path.relpath(image_path.split(".")[0], root))
+                    os.makedirs(out_path, exist_ok=True)
+                    writer.save_pil(originals[j], os.path.join(out_path, "source.png"))
+                    writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
+                    writer.save_img(images[1], os.path.join(out_path, "edit.png"))
+    finally:
+        writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

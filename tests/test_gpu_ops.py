@@ -686,6 +686,27 @@ def test_producer_column_statistics(kind, B, hw, cin, cout):
     assert torch.equal(again, stat)                     # fixed summation order
 
 
+@pytest.mark.parametrize("C,hw,offset", [(320, 64, 30.0), (640, 16, 30.0), (320, 32, 45.0), (1280, 16, -20.0)])
+def test_groupnorm_from_producer_statistics_offset_activations(C, hw, offset):
+    """|mean| >> std (deep residual-stream levels): the producer-statistics GroupNorm takes the variance as E[x^2] - mean^2
+    from fp32 column sums, where cancellation costs eps_fp32 * mean^2 / var of relative precision (mean 30-45, std ~0.5:
+    ~1e-3) -- one-launch (hw = 16) and fold + apply (hw >= 32) forms against F.group_norm on the same fp16 tensor"""
+    B = 2
+    bias = f32(C, seed=3, scale=0.3) + offset
+    x, cs = hip.conv3x3(dev(h16(B, hw, hw, 64, seed=1)), dev(h16(C, 3, 3, 64, seed=2, scale=1 / 48.0)), dev(bias), col_stats=True)
+    assert cs is not None
+    xf = x.float()
+    assert abs(xf.mean().item() - offset) < 1.0 and 0.2 < xf.std().item() < 1.5
+    gamma, beta = dev(1 + f32(C, seed=9, scale=0.1)), dev(f32(C, seed=10, scale=0.1))
+    got = hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True, cstat=cs)
+    ref = F.silu(F.group_norm(xf.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    plain = hip.groupnorm(x, gamma, beta, 32, 1e-5, silu=True)
+    e_cs, e_plain = (got.float() - ref).abs().max().item(), (plain.float() - ref).abs().max().item()
+    print(f"GroupNorm on offset activations (mean {xf.mean().item():.1f}, std {xf.std().item():.2f}) C={C} hw={hw}: producer statistics "
+          f"{e_cs:.2e}, own statistics {e_plain:.2e} (normalised outputs of size ~3)")
+    assert e_cs < 8e-3 and e_plain < 8e-3
+
+
 @pytest.mark.parametrize("C1,C2,hw", [(320, 0, 64), (640, 320, 64), (1280, 640, 32), (640, 320, 16), (1280, 0, 16), (1280, 1280, 16)])
 def test_groupnorm_from_producer_statistics(C1, C2, hw, monkeypatch):
     """GroupNorm on the producers' statistics (one launch at 2-8 tiles per image: the hw = 16 cases; fold + apply above) against F.group_norm, against the path without them, and bit
