@@ -67,19 +67,43 @@ __device__ __forceinline__ void split4(const f32x4 v, const float s, half4& hi, 
 
 enum { X3_LIN = 0, X3_LIN_SLOW = 1, X3_CONV = 2, X3_CONV_UPS = 3, X3_CONV_SLOW = 4 };
 
-template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB>
+// fp32 weights -> the two fp16 planes [2][n] the GEMM's B operand is staged from when it is a WEIGHT (static: split once per
+// tensor by the host wrapper, not once per launch and workgroup): planes[0] = hi = fp16(s w), planes[1] = lo = fp16(s w - hi)
+__global__ __launch_bounds__(256) void x3_split_weights_kernel(const float* __restrict__ w, half_t* __restrict__ planes, long long n4,
+                                                               float s) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        half4 h, l;
+        split4(((const f32x4*)w)[i], s, h, l);
+        ((half4*)planes)[i] = h;
+        ((half4*)planes)[n4 + i] = l;
+    }
+}
+extern "C" int ief_x3_split_weights(const float* w, void* planes, long long n, float scale, void* stream) {
+    if (!w || !planes) return IEF_EINVAL;
+    if (n <= 0 || (n & 3) || !(scale > 0.f)) return IEF_ESHAPE;
+    long long grid = (n / 4 + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(x3_split_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (half_t*)planes, n / 4, scale);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// BPRE: the B operand comes as pre-split fp16 planes (p.Wp: [2][N][K] contiguous, ief_x3_split_weights); otherwise it is
+// fp32 and split while staged, like A (the batched attention products: both operands are activations).
+template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB, bool BPRE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3_kernel(const IefGemmF32Params p) {
     constexpr bool CONV = KIND >= X3_CONV;
+    constexpr bool HASFAST = KIND == X3_LIN || KIND == X3_CONV;      // kinds with the predicate-free main-loop loader
     constexpr int NTH = 64 * WM * WN;
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
     constexpr int ROWS = BM + BN;
     constexpr int NA = (BM * 8 + NTH - 1) / NTH;            // 16-byte chunks of the A tile per thread
-    constexpr int NB = (BN * 8 + NTH - 1) / NTH;
-    constexpr bool A_EXACT = (BM * 8) % NTH == 0, B_EXACT = (BN * 8) % NTH == 0;
-#ifndef X3_INTERLEAVE
-#define X3_INTERLEAVE 0
-#endif
-    constexpr bool INTERLEAVE = X3_INTERLEAVE != 0;
+    constexpr int NBC = BPRE ? 2 * BN * 4 : BN * 8;          // 16-byte chunks of the B tile (BPRE: 8 halves each, two planes)
+    constexpr int NB = (NBC + NTH - 1) / NTH;
+    constexpr bool A_EXACT = (BM * 8) % NTH == 0, B_EXACT = NBC % NTH == 0;
+    static_assert(!(BPRE && TRANSB), "pre-split planes are [N][K]");
+    constexpr unsigned OOB = 0xFFFFFFF0u;        // general loader: an offset past every descriptor
+    constexpr unsigned OOBF = 0x80000000u;       // fast loader: stays out of range when a K offset (< 2^31) is added
     // per buffer: [A hi][A lo][B hi][B lo], rows of YLD halves
     __shared__ __attribute__((aligned(16))) half_t smem_y[2 * 2 * ROWS * YLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -102,8 +126,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
     }
     const int M = p.M, N = p.N, K = p.K;
     const float sa = p.sa, sb = p.sb;
-    // ---- loader assignment: chunk (row, 4 floats at k = 4 (tid & 7)); thread t takes rows rsw(t >> 3) + RSTEP i, where rsw
-    // swaps the two low bits' order so that lanes 8-15 of a 16-lane write group sit two rows below lanes 0-7
+    // ---- loader assignment.  A (and an fp32 B): chunk (row, 4 floats at k = 4 (tid & 7)); thread t takes rows
+    // rsw(t >> 3) + RSTEP i, rsw swapping the two low bits so that lanes 8-15 of a 16-lane ds_write_b64 group sit two rows
+    // below lanes 0-7 (96 B x 2 = 64 mod 128: different bank halves).  Pre-split B: chunk c = tid + NTH i of [plane][row][4
+    // chunks of 8 halves], rows swizzled the same way for the 8-lane groups of ds_write_b128.
     const int kc4 = (tid & 7) * 4;
     const int rq = tid >> 3;
     const int r0 = (rq & ~3) | ((rq & 1) << 1) | ((rq >> 1) & 1);
@@ -152,19 +178,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
     const int kend = min(K, (kt0 + nk) * YBK);       // loads past this workgroup's K range read zeros
 
     // Every operand is read through a buffer descriptor (wave-uniform: kernel arguments and blockIdx only) with a per-lane
-    // byte offset: an element outside the tensor, the K range or the image (3x3 padding) is a lane whose offset is pushed
-    // past the descriptor's size and reads zeros -- no branch around any load, so the loads of a tile issue back to back and
-    // stay in flight under the MFMAs of two K tiles.  The SLOW kinds keep the general per-lane loaders (a convolution whose
-    // channel counts are not multiples of 32: a K tile straddles taps / sources; A rows that are not 16-byte chunked); in
-    // the fast kinds the K loop is one basic block, which is what lets the compiler count the outstanding loads exactly.
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-    const rsrc_t rA = make_rsrc(A, p.bytesA), rW = make_rsrc(W, p.bytesW);
+    // byte offset: an element outside the tensor, the K range or the image (3x3 padding) is a lane whose offset lies past the
+    // descriptor's size and reads zeros -- no branch around any load, so the loads of a tile issue back to back and stay in
+    // flight under the MFMAs of two K tiles.  Two loaders: the GENERAL one predicates everything per lane (tensor edge, K
+    // range, K tail, tap decode per call) and serves the first two and the last tiles; the FAST one (KIND 0 / 2, the tiles that
+    // lie wholly inside the K range) adds a uniform K offset to per-thread bases computed once -- rows outside the tensor /
+    // taps outside the image carry the base 2^31, out of range whatever is added (every buffer is < 2^31 bytes, else p.fast_ok
+    // is 0) -- so the steady-state loop spends its vector instructions on the split, not on addresses.
+    const rsrc_t rA = make_rsrc(A, p.bytesA), rW = make_rsrc(BPRE ? (const void*)p.Wp : (const void*)W, p.bytesW);
     const rsrc_t rA2 = make_rsrc(p.A2, p.bytesA2), rE1 = make_rsrc(p.E1, p.bytesE1), rE2 = make_rsrc(p.E2, p.bytesE2);
-    // running decode of the next K tile to load (tiles are requested in order): tap, first channel inside the tap
-    int l_tap = 0, l_ch = 0;
-    // per-thread constant parts of the linear operands' offsets
+    // per-thread constant parts of the offsets
     unsigned aoff[NA], boff[NB];
     bool aval[NA], bval[NB];
+    int bq8[NB];                                   // BPRE: k offset (halves) of the chunk inside the tile
+    int bldsoff[NB];                               // LDS offset (halves, within a buffer's B area) of the B chunk
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int ml = r0 + RSTEP * i, m = m0 + ml;
@@ -173,36 +200,50 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        if (!TRANSB) {
+        bq8[i] = 0;
+        if (BPRE) {
+            const int c = tid + NTH * i;
+            const int plane = c >= BN * 4 ? 1 : 0, cc = c - plane * BN * 4;
+            const int rr = cc >> 2, q = cc & 3;
+            const int nl = (rr & ~3) | ((rr & 1) << 1) | ((rr >> 1) & 1), n = n0 + nl;
+            bval[i] = (c < NBC) & (n < N);
+            bq8[i] = q * 8;
+            boff[i] = (unsigned)(((long long)plane * N * K + (long long)n * K + q * 8) * 2);
+            bldsoff[i] = plane * BN * YLD + nl * YLD + q * 8;
+        } else if (!TRANSB) {
             const int nl = r0 + RSTEP * i, n = n0 + nl;
             bval[i] = (n < N) & (B_EXACT || nl < BN);
             boff[i] = (unsigned)((n * p.ldw + kc4) * 4);
+            bldsoff[i] = nl * YLD + kc4;
         } else {                        // W [K][N]: chunk c = tid + NTH i -> k row c & 31, 4 columns at 4 (c >> 5)
             const int c = tid + NTH * i;
             const int nl = (c >> 5) * 4, n = n0 + nl;
             bval[i] = (n < N) & (B_EXACT || nl < BN);                                  // N % 4 == 0 (host-checked)
             boff[i] = (unsigned)(((c & 31) * p.ldw + n) * 4);
+            bldsoff[i] = nl * YLD + (c & 31);
         }
     }
 
+    // ------------------------------------------------------------------------------------------ the general loader
     auto load_tile = [&](int k0, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
         const int kk = k0 + kc4;
         if (KIND == X3_CONV || KIND == X3_CONV_UPS) {
-            // uniform decode of the tile: a 3x3 tap (ky, kx) of source 1 / 2, or (l_tap == 9) the 1x1 extra source 1 / 2
+            // uniform decode of the tile: a 3x3 tap (ky, kx) of source 1 / 2, or (tap 9) the 1x1 extra source 1 / 2
+            int tap = 9, ch = k0 - K9;
+            if (k0 < K9) { tap = k0 / Ct; ch = k0 - tap * Ct; }
             rsrc_t rs = rA;
-            int cs = p.C1, chs = l_ch, ky = 0, kx = 0;
-            const bool tapm = l_tap < 9;
+            int cs = p.C1, chs = ch, ky = 0, kx = 0;
+            const bool tapm = tap < 9;
             bool second = false;
             if (tapm) {
-                ky = (l_tap * 11) >> 5; kx = l_tap - 3 * ky;
-                if (l_ch >= p.C1) { rs = rA2; cs = p.C2; chs = l_ch - p.C1; second = true; }
-            } else if (l_ch < p.CE1) { rs = rE1; cs = p.CE1; }
-            else { rs = rE2; cs = p.CE2; chs = l_ch - p.CE1; }
+                ky = (tap * 11) >> 5; kx = tap - 3 * ky;
+                if (ch >= p.C1) { rs = rA2; cs = p.C2; chs = ch - p.C1; second = true; }
+            } else if (ch < p.CE1) { rs = rE1; cs = p.CE1; }
+            else { rs = rE2; cs = p.CE2; chs = ch - p.CE1; }
             const int kin = k0 < kend ? 1 : 0;
             if (KIND == X3_CONV) {
-                // offset = centre-pixel offset of the row (precomputed per source) + a uniform term; validity = one mask bit
                 const int uni = tapm ? (((ky - pad_lo) * p.Wd + (kx - pad_lo)) * cs + chs) * 4 : chs * 4;
-                const unsigned bit = tapm ? (1u << l_tap) : 0u;
+                const unsigned bit = tapm ? (1u << tap) : 0u;
                 const unsigned cs4 = (unsigned)cs * 4u;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
@@ -224,8 +265,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
                     ra[i] = bload(rs, ok ? off : OOB);
                 }
             }
-            l_ch += YBK;                       // advance the decode by one K tile
-            if (l_tap < 9 && l_ch >= Ct) { l_ch -= Ct; ++l_tap; }
         } else if (KIND == X3_CONV_SLOW) {
             const float* src = nullptr;
             int cs = 0, chs = 0, ky = 0, kx = 0, mode = 0;       // mode 0: zero, 1: 3x3 tap, 2: 1x1 extra source
@@ -269,7 +308,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
                 ra[i] = v;
             }
         }
-        if (!TRANSB) {                  // W [N][K]: rows n0 + r0 + RSTEP i
+        if (BPRE) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = bload(rW, (bval[i] & (k0 + bq8[i] < kend)) ? boff[i] + (unsigned)(k0 * 2) : OOB);
+        } else if (!TRANSB) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = bload(rW, (bval[i] & (kk < kend)) ? boff[i] + (unsigned)(k0 * 4) : OOB);
         } else {
@@ -280,6 +322,59 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
             }
         }
     };
+
+    // ------------------------------------------------------------------------------------------ the fast loader
+    // state of the convolution's tile stream (tiles are requested in order): current segment = one tap of one source (or a
+    // 1x1 extra source): its descriptor, the rows' bases (2^31 where the tap falls outside the image), the running byte
+    // offset inside the segment, tiles left in it
+    unsigned afast[NA], bfast[NB];
+    rsrc_t f_rs = rA;
+    int f_tap = 0, f_ch = 0, f_left = 0, f_uni = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) afast[i] = aval[i] ? aoff[i] : OOBF;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bfast[i] = bval[i] ? boff[i] : OOBF;
+    auto seg_setup = [&]() {            // (f_tap, f_ch) -> f_rs, afast[], f_uni, f_left; uniform, runs once per segment
+        int cs, chs, src_c;
+        const bool tapm = f_tap < 9;
+        bool second = false;
+        if (tapm) {
+            if (f_ch >= p.C1) { f_rs = rA2; cs = p.C2; chs = f_ch - p.C1; second = true; src_c = p.C2; }
+            else { f_rs = rA; cs = p.C1; chs = f_ch; src_c = p.C1; }
+        } else if (f_ch < p.CE1) { f_rs = rE1; cs = p.CE1; chs = f_ch; src_c = p.CE1; }
+        else { f_rs = rE2; cs = p.CE2; chs = f_ch - p.CE1; src_c = p.CE2; }
+        f_left = (src_c - chs) / YBK;
+        f_uni = chs * 4;
+        const int ky = (f_tap * 11) >> 5, kx = f_tap - 3 * ky;
+        const int tapoff = tapm ? ((ky - pad_lo) * p.Wd + (kx - pad_lo)) * cs * 4 : 0;
+        const unsigned bit = tapm ? (1u << f_tap) : 0u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned base = tapm ? (second ? pixo2[i] : pixo1[i]) + (unsigned)tapoff
+                                       : (unsigned)(m0 + r0 + RSTEP * i) * (unsigned)cs * 4u;
+            const bool ok = tapm ? (tmask[i] & bit) != 0 : rc[i].ok != 0;
+            afast[i] = ok ? base + (unsigned)(kc4 * 4) : OOBF;
+        }
+    };
+    auto load_fast = [&](int k0, f32x4 (&ra)[NA], f32x4 (&rb)[NB]) {
+        if (KIND == X3_CONV) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = bload(f_rs, afast[i] + (unsigned)f_uni);
+            f_uni += YBK * 4;
+            f_ch += YBK;
+            if (--f_left == 0) {                   // next segment: the other source, the next tap, or the 1x1 sources
+                if (f_tap < 9 && f_ch >= Ct) { f_ch = 0; ++f_tap; }
+                seg_setup();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = bload(rA, afast[i] + (unsigned)(k0 * 4));
+        }
+        const unsigned kb = BPRE ? (unsigned)(k0 * 2) : TRANSB ? (unsigned)(k0 * p.ldw * 4) : (unsigned)(k0 * 4);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = bload(rW, bfast[i] + kb);
+    };
+
     // split + LDS write of ONE staged chunk (idx < NA: A chunk, else B chunk idx - NA) of the tile held in (ra, rb)
     auto store_chunk = [&](int buf, int idx, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
         half_t* ah = smem_y + buf * (2 * ROWS * YLD);
@@ -294,25 +389,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
             const int off = (r0 + RSTEP * i) * YLD + kc4;
             *(half4*)(ah + off) = h;
             *(half4*)(al + off) = l;
+        } else if (BPRE) {
+            const int i = idx - NA;
+            if (!B_EXACT && tid + NTH * i >= NBC) return;
+            *(f32x4*)(bh + bldsoff[i]) = rb[i];                  // 8 halves of one plane, already split
         } else if (!TRANSB) {
             const int i = idx - NA;
             if (!B_EXACT && r0 + RSTEP * i >= BN) return;
             half4 h, l;
             split4(rb[i], sb, h, l);
-            const int off = (r0 + RSTEP * i) * YLD + kc4;
-            *(half4*)(bh + off) = h;
-            *(half4*)(bl + off) = l;
+            *(half4*)(bh + bldsoff[i]) = h;
+            *(half4*)(bl + bldsoff[i]) = l;
         } else {
             const int i = idx - NA;
-            const int c = tid + NTH * i;
-            const int kr = c & 31, nl = (c >> 5) * 4;
-            if (!B_EXACT && nl >= BN) return;
+            if (!B_EXACT && ((tid + NTH * i) >> 5) * 4 >= BN) return;
             half4 h, l;
             split4(rb[i], sb, h, l);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bh[(nl + j) * YLD + kr] = h[j];
-                bl[(nl + j) * YLD + kr] = l[j];
+                bh[bldsoff[i] + j * YLD] = h[j];
+                bl[bldsoff[i] + j * YLD] = l[j];
             }
         }
     };
@@ -327,8 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
 #pragma unroll
         for (int a = 0; a < TM; ++a) acc[b][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // the MFMAs of the tile in LDS buffer `buf`, with the split + LDS write of the NEXT tile (registers ra, rb -> buffer
-    // buf ^ 1) spread between the TN column blocks: the conversions' VALU work issues in the shadow of the matrix pipe
+    // the MFMAs of the tile in LDS buffer `buf`, then the split + LDS write of the NEXT tile (registers ra, rb -> buffer buf ^ 1)
     auto mma_tile = [&](int buf, const f32x4 (&ra)[NA], const f32x4 (&rb)[NB]) {
         const half_t* ah = smem_y + buf * (2 * ROWS * YLD) + (wm * TM * 16 + lr) * YLD + 8 * lg;
         const half_t* al = ah + BM * YLD;
@@ -340,7 +435,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
             fah[a] = *(const half8_t*)(ah + a * 16 * YLD);
             fal[a] = *(const half8_t*)(al + a * 16 * YLD);
         }
-        constexpr int NC = NA + NB;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const half8_t fbh = *(const half8_t*)(bh + b * 16 * YLD);
@@ -351,28 +445,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
                 acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh, fal[a], acc[b][a], 0, 0, 0);
                 acc[b][a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh, fah[a], acc[b][a], 0, 0, 0);
             }
-            if (INTERLEAVE) {
-#pragma unroll
-                for (int c = b; c < NC; c += TN) store_chunk(buf ^ 1, c, ra, rb);
-            }
         }
-        if (!INTERLEAVE) store_tile(buf ^ 1, ra, rb);
+        store_tile(buf ^ 1, ra, rb);
     };
 
-    if (KIND == X3_CONV || KIND == X3_CONV_UPS) {            // decode of this workgroup's first K tile
-        const int k0 = kt0 * YBK;
-        if (k0 < K9) { l_tap = k0 / Ct; l_ch = k0 - l_tap * Ct; } else { l_tap = 9; l_ch = k0 - K9; }
-    }
-    // register set s holds tile t with (t & 1) == s; LDS buffer (t & 1) holds tile t
+    // register set s holds tile t with (t & 1) == s; LDS buffer (t & 1) holds tile t.  Tiles past the K range load zeros and
+    // multiply zeros (an odd tile count costs one idle pass).
     f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-    // tiles past the K range load zeros and multiply zeros: no branch in the loop (an odd tile count costs one idle pass)
     load_tile(kt0 * YBK, ra0, rb0);
     load_tile((kt0 + 1) * YBK, ra1, rb1);
     store_tile(0, ra0, rb0);
     __syncthreads();
     // NOTE the order inside a half step: the loads of tile kt + 2 overwrite register set (kt & 1), whose previous content
     // (tile kt) went to LDS during the previous half step; the tile converted now is kt + 1 from the OTHER set
-    for (int kt = 0; kt < nk; kt += 2) {
+    int kt = 0;
+    if (HASFAST && p.fast_ok) {
+        const int nfast = kend / YBK - kt0;                  // tiles [0, nfast) of this workgroup lie wholly inside its K range
+        if (KIND == X3_CONV && nfast > 3) {                  // the stream of the fast loader starts at tile 2
+            const int k0 = (kt0 + 2) * YBK;
+            if (k0 < K9) { f_tap = k0 / Ct; f_ch = k0 - f_tap * Ct; } else { f_tap = 9; f_ch = k0 - K9; }
+            seg_setup();
+        }
+        for (; kt + 3 < nfast; kt += 2) {
+            load_fast((kt0 + kt + 2) * YBK, ra0, rb0);
+            mma_tile(0, ra1, rb1);
+            __syncthreads();
+            load_fast((kt0 + kt + 3) * YBK, ra1, rb1);
+            mma_tile(1, ra0, rb0);
+            __syncthreads();
+        }
+    }
+    for (; kt < nk; kt += 2) {
         load_tile((kt0 + kt + 2) * YBK, ra0, rb0);
         mma_tile(0, ra1, rb1);
         __syncthreads();
@@ -442,13 +545,13 @@ extern "C" int ief_gemm_x3_bm(int M, int N) {
     return 128;       // a 64 x 80 tile (4 waves of 16 rows) without split-K measured slower than 128 x 80 with it: not instantiated
 }
 
-template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB>
+template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB, bool BPRE>
 static int launch_igemm_x3(const IefGemmF32Params& p, hipStream_t st) {
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int z = p.heads > 0 ? p.batch * p.heads : 1;
     const int splits = p.splits > 1 ? p.splits : 1;
-    hipLaunchKernelGGL((igemm_x3_kernel<WM, WN, TM, TN, KIND, TRANSB>), dim3(tiles, splits, z), dim3(64 * WM * WN), 0, st, p);
+    hipLaunchKernelGGL((igemm_x3_kernel<WM, WN, TM, TN, KIND, TRANSB, BPRE>), dim3(tiles, splits, z), dim3(64 * WM * WN), 0, st, p);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
@@ -462,6 +565,9 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
                     (!p.residual || (((uintptr_t)p.residual & 15) == 0 && (p.ldr & 3) == 0)) &&
                     (p.heads == 0 || (((p.sOb | p.sOh) & 3) == 0));
     p.vec_out = al ? 1 : 0;
+    // pre-split weight planes: [2][N][K] fp16 contiguous, 16-byte chunks of 8 halves
+    const bool bpre = p.Wp != nullptr;
+    if (bpre && (p.transb || p.heads > 0 || (p.K & 7) || ((uintptr_t)p.Wp & 15) || (!p.conv && p.ldw != p.K))) return IEF_EINVAL;
     // descriptor sizes (bytes reachable from each operand's base; batched: from the (batch row, head) base)
     const unsigned long long lim = 0xFFFFFFF0ull;
     unsigned long long bA, bW, bA2 = 0, bE1 = 0, bE2 = 0;
@@ -474,15 +580,25 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
         bA = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 4;
         p.al32 = 0;
     }
-    bW = p.transb ? ((unsigned long long)(p.K - 1) * p.ldw + p.N) * 4 : ((unsigned long long)(p.N - 1) * p.ldw + p.K) * 4;
+    bW = bpre ? 4ull * p.N * p.K
+              : p.transb ? ((unsigned long long)(p.K - 1) * p.ldw + p.N) * 4 : ((unsigned long long)(p.N - 1) * p.ldw + p.K) * 4;
     if (bA >= lim || bW >= lim || bA2 >= lim || bE1 >= lim || bE2 >= lim) return IEF_ESHAPE;      // 32-bit buffer offsets
     p.bytesA = (unsigned)bA; p.bytesW = (unsigned)bW; p.bytesA2 = (unsigned)bA2; p.bytesE1 = (unsigned)bE1; p.bytesE2 = (unsigned)bE2;
+    // the fast loader marks out-of-range rows with the base 2^31 and adds K offsets below 2^30 to it
+    const unsigned long long half = 0x40000000ull;
+    const unsigned long long kspan = p.transb ? 4ull * p.K * p.ldw : 4ull * p.K;
+    p.fast_ok = (bA < half && bW < half && bA2 < half && bE1 < half && bE2 < half && kspan < half) ? 1 : 0;
     const bool n80 = ief_gemm_x3_bn(p.N) == 80;
-#define X3_GO(KIND_, TRANSB_) (n80 ? launch_igemm_x3<4, 1, 2, 5, KIND_, TRANSB_>(p, st) \
-                                   : launch_igemm_x3<2, 2, 4, 2, KIND_, TRANSB_>(p, st))
-    if (p.conv) return !p.al32 ? X3_GO(X3_CONV_SLOW, false) : p.ups ? X3_GO(X3_CONV_UPS, false) : X3_GO(X3_CONV, false);
-    if (p.transb) return p.a_scalar ? X3_GO(X3_LIN_SLOW, true) : X3_GO(X3_LIN, true);
-    return p.a_scalar ? X3_GO(X3_LIN_SLOW, false) : X3_GO(X3_LIN, false);
+#define X3_GO(KIND_, TRANSB_, BPRE_) (n80 ? launch_igemm_x3<4, 1, 2, 5, KIND_, TRANSB_, BPRE_>(p, st) \
+                                          : launch_igemm_x3<2, 2, 4, 2, KIND_, TRANSB_, BPRE_>(p, st))
+    if (p.conv) {
+        if (!p.al32) return bpre ? X3_GO(X3_CONV_SLOW, false, true) : X3_GO(X3_CONV_SLOW, false, false);
+        if (p.ups) return bpre ? X3_GO(X3_CONV_UPS, false, true) : X3_GO(X3_CONV_UPS, false, false);
+        return bpre ? X3_GO(X3_CONV, false, true) : X3_GO(X3_CONV, false, false);
+    }
+    if (p.transb) return p.a_scalar ? X3_GO(X3_LIN_SLOW, true, false) : X3_GO(X3_LIN, true, false);
+    if (p.a_scalar) return bpre ? X3_GO(X3_LIN_SLOW, false, true) : X3_GO(X3_LIN_SLOW, false, false);
+    return bpre ? X3_GO(X3_LIN, false, true) : X3_GO(X3_LIN, false, false);
 #undef X3_GO
 }
 

@@ -92,9 +92,9 @@ class IefGemmF32Params(Structure):
         ("sAb", c_longlong), ("sAh", c_longlong), ("sWb", c_longlong), ("sWh", c_longlong), ("sOb", c_longlong), ("sOh", c_longlong),
         ("a_src", c_void_p), ("w_src", c_void_p), ("transb", c_int), ("a_scalar", c_int),
         ("splits", c_int), ("ws", c_void_p),
-        ("x3", c_int), ("sa", c_float), ("sb", c_float), ("vec_out", c_int), ("al32", c_int),
+        ("x3", c_int), ("sa", c_float), ("sb", c_float), ("vec_out", c_int), ("al32", c_int), ("fast_ok", c_int),
         ("bytesA", ctypes.c_uint), ("bytesW", ctypes.c_uint), ("bytesA2", ctypes.c_uint), ("bytesE1", ctypes.c_uint),
-        ("bytesE2", ctypes.c_uint),
+        ("bytesE2", ctypes.c_uint), ("Wp", c_void_p),
     ]
 
 
@@ -124,7 +124,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_x3_split_weights", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
     # activation gradients of the fp32-storage modes (csrc/backward_f32.hip)
     "ief_groupnorm_bwd_f32", "ief_layernorm_bwd_f32", "ief_geglu_il_bwd_f32", "ief_zero_insert2x_f32", "ief_pool2x2_sum_f32",
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
@@ -204,6 +204,7 @@ def load():
     lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_float, c_int, c_void_p]
     lib.ief_gemm_x3_bm.argtypes = [c_int, c_int]
+    lib.ief_x3_split_weights.argtypes = [c_void_p, c_void_p, c_longlong, c_float, c_void_p]
     lib.ief_groupnorm_bwd_f32.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.ief_layernorm_bwd_f32.argtypes = [c_void_p] * 5 + [c_longlong, c_int, c_float, c_void_p]
     lib.ief_geglu_il_bwd_f32.argtypes = [c_void_p] * 3 + [c_longlong, c_int, c_void_p]
@@ -634,10 +635,39 @@ class f32_contraction:
         return False
 
 
-def _set_x3(p, sa, sb) -> str:
-    """fill the split-operand fields of an IefGemmF32Params from the current mode; returns the kernel family's name"""
+_x3_planes = {}      # (data_ptr, shape) -> (weight tensor kept alive, its _version, planes fp16 [2, N, K])
+X3_PRESPLIT = os.environ.get("IEF_X3_PRESPLIT", "1") == "1"       # 0: split the weights in every launch, like the activations
+
+
+def x3_weight_planes(w, scale=None):
+    """the pre-split fp16 planes [2, N, K] of an fp32 WEIGHT tensor (hi = fp16(s w), lo = fp16(s w - hi)), made once per tensor
+    and kept: a weight is static, so splitting it in every launch and workgroup would spend vector instructions the GEMM's
+    steady-state loop has none to spare of.  None while a graph is being captured and the planes do not exist yet."""
+    scale = X3_SCALE_W if scale is None else scale
+    key = (w.data_ptr(), tuple(w.shape), float(scale))
+    hit = _x3_planes.get(key)
+    if hit is not None and hit[0] is w and hit[1] == w._version:
+        return hit[2]
+    if _capturing() or w.numel() % 4 or not w.is_contiguous():
+        return None
+    lib = load()
+    n = w.shape[0]
+    planes = torch.empty(2, n, w.numel() // n, dtype=torch.float16, device=w.device)
+    _check(lib.ief_x3_split_weights(w.data_ptr(), planes.data_ptr(), w.numel(), float(scale), _stream()), "ief_x3_split_weights")
+    _x3_planes[key] = (w, w._version, planes)
+    return planes
+
+
+def _set_x3(p, sa, sb, w=None) -> str:
+    """fill the split-operand fields of an IefGemmF32Params from the current mode; returns the kernel family's name.
+    w: the launch's B operand when it is a weight ([N, K...] contiguous fp32): its cached pre-split planes ride along"""
     if _F32_CONTRACT == "x3":
         p.x3, p.sa, p.sb = 1, sa, sb
+        if w is not None and X3_PRESPLIT and (w.numel() // w.shape[0]) % 8 == 0:
+            planes = x3_weight_planes(w, sb)
+            if planes is not None:
+                p._planes = planes          # keep alive until the launch is queued
+                p.Wp = planes.data_ptr()
         return "igemm_x3_kernel"
     return "igemm_f32_kernel"
 
@@ -934,7 +964,8 @@ def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out
     p.M, p.N, p.K, p.lda, p.ldw, p.ldo = M, N, K, lda, w.stride(0), ldo
     p.out_scale, p.transb = out_scale, 1 if transb else 0
     ws = _splits_f32(lib, p, M, N, K, a.device)     # noqa: F841  (keeps the slabs alive until the launch is queued)
-    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_ACT if transb else X3_SCALE_W)        # transb: activation x activation
+    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_ACT if transb else X3_SCALE_W,        # transb: activation x activation
+                 w if (not transb and w.is_contiguous()) else None)
     nbytes = 4.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))
     with _Timed(f"{kn}<false, {'true' if transb else 'false'}>" + (f" {M}x{N}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * N * K, nbytes):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32")
@@ -994,7 +1025,7 @@ def _conv3x3_f32(x, w, bias, x2, stride, upsample, rowvec, residual, out, extra,
     p.E1, p.E2, p.CE1, p.CE2 = _ptr(e1), _ptr(e2), CE1, CE2
     p.out_scale = 1.0
     ws = _splits_f32(lib, p, M, Cout, K, x.device)  # noqa: F841
-    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_W)
+    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_W, w)
     nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * (2 if residual is not None else 1))
     with _Timed(f"{kn}<true, false>" + (f" {M}x{Cout}x{K} s{p.splits}" if PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (conv)")

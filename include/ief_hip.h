@@ -266,10 +266,15 @@ typedef struct IefGemmF32Params {
     float sa, sb;
     /* set by the library (x3): every epilogue operand allows 16-byte accesses; conv channel counts are all multiples of
      * 32; bytes reachable from A / W / A2 / E1 / E2 (buffer descriptor sizes: each must stay below 4 GiB) */
-    int vec_out, al32;
+    int vec_out, al32, fast_ok;
     unsigned bytesA, bytesW, bytesA2, bytesE1, bytesE2;
+    /* x3: optional pre-split planes of a WEIGHT operand (made once per tensor by ief_x3_split_weights with scale sb): fp16
+     * [2][N][K] contiguous (hi plane, lo plane); W is then not read.  Not for transb / batched products. */
+    const void* Wp;
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
+/* planes[0][i] = fp16(scale w[i]), planes[1][i] = fp16(scale w[i] - planes[0][i]); n % 4 == 0 */
+int ief_x3_split_weights(const float* w, void* planes, long long n, float scale, void* stream);
 int ief_gemm_x3_bn(int N);    /* x3 != 0: output-tile width (80 or 64) for N columns; ief_gemm_x3_bm(M, N): its row count (128 or 64) */
 int ief_gemm_x3_bm(int M, int N);
 int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */

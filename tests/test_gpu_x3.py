@@ -83,6 +83,28 @@ def test_gemm_x3(M, N, K):
     assert rel_err(od[:, :N], (wide[:, 4:4 + K].double() @ w.double().t()).float()) < XTOL and od[:, N:].abs().max() == 0
 
 
+def test_gemm_x3_presplit_weight_planes_equal_on_the_fly_split(monkeypatch):
+    """a weight operand is split once per tensor into cached fp16 planes (`hip.x3_weight_planes`) instead of once per launch
+    and workgroup; same hi / lo values, same products: bit-identical outputs, linear and 3x3 (fast and general loaders: K
+    not a multiple of 32 ends in the general one)"""
+    a, w = f32(700, 328, seed=1), f32(320, 328, seed=2, scale=0.05)
+    x, wc = f32(2, 16, 16, 64, seed=3), f32(160, 3, 3, 64, seed=4, scale=0.04)
+    outs = {}
+    for pre in (True, False):
+        monkeypatch.setattr(hip, "X3_PRESPLIT", pre)
+        hip.profile_begin()
+        outs[pre] = (hip.gemm(dev(a), dev(w)), hip.conv3x3(dev(x), dev(wc)))
+        hip.profile_end()
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    wd = dev(w)
+    p1 = hip.x3_weight_planes(wd)
+    assert p1 is hip.x3_weight_planes(wd) and p1.shape == (2, 320, 328) and p1.dtype == torch.float16        # cached
+    hi, lo = p1[0].float(), p1[1].float()
+    assert ((hi + lo) / hip.X3_SCALE_W - wd).abs().max().item() <= 2 ** -21 * w.abs().max().item()
+    wd.mul_(2.0)                                                                                            # a changed tensor is re-split
+    assert hip.x3_weight_planes(wd) is not p1
+
+
 @pytest.mark.parametrize("sa,sw", [(1e-4, 1e-3), (1e-2, 1e-5), (300.0, 1.0), (1.0, 30.0)])
 def test_gemm_x3_operand_magnitudes(sa, sw):
     """operands far from unit scale: the lo halves of small elements fall into the fp16 subnormal range (whether the MFMA
