@@ -300,6 +300,7 @@ extern "C" int ief_gemm_f32(const IefGemmF32Params* pp, void* stream) {
     if (p.heads > 0 && p.batch <= 0) return IEF_ESHAPE;
     if (p.splits > 1 && (!p.ws || p.heads > 0 || p.splits > 64)) return IEF_EINVAL;
     if (p.heads == 0 && (p.a_src || p.w_src)) return IEF_ESHAPE;
+    if (p.geglu && !p.x3) return IEF_EINVAL;                   // the fused GEGLU epilogue exists in the split-operand kernel only
     hipStream_t st = (hipStream_t)stream;
     if (p.conv) {
         if (p.transb || p.heads > 0) return IEF_ESHAPE;

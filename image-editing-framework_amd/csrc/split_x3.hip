@@ -506,6 +506,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
         }
         return;
     }
+    if (p.geglu) {
+        // FeedForward.net[0] with its GEGLU fused (weight rows interleaved [8 hidden | 8 gate] per 16-column block, unet.py):
+        // lanes 0-31 of a block hold hidden columns 0-7 (4 per lane), lanes 32-63 the matching gate columns -- one exchange
+        // with lane + 32, then out[m][8 block + 4 lg .. + 3] = hidden * gelu(gate): the 2x wider pre-activation never reaches HBM
+        // (host-checked: N % 16 == 0, bias only, 16-byte aligned output rows)
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int m = m0 + (wm * TM + a) * 16 + lr;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + (wn * TN + b) * 16 + 4 * lg;
+                f32x4 v = acc[b][a] * inv;
+                if (p.bias && n < N) v += *(const f32x4*)(p.bias + n);
+                f32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = __shfl_xor(v[j], 32);
+                if (lg < 2 && m < M && n < N) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = v[j] * gelu_f(g[j]) * p.out_scale;
+                    *(f32x4*)(Out + (long long)m * p.ldo + (n0 + (wn * TN + b) * 16) / 2 + 4 * lg) = o;
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: (acc + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]) * out_scale, fp32
     const float* R = p.residual;
 #pragma unroll
@@ -566,6 +592,9 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
                     (p.heads == 0 || (((p.sOb | p.sOh) & 3) == 0));
     p.vec_out = al ? 1 : 0;
     // pre-split weight planes: [2][N][K] fp16 contiguous, 16-byte chunks of 8 halves
+    if (p.geglu && (p.conv || p.transb || p.heads > 0 || p.splits > 1 || (p.N & 15) || p.residual || p.rowvec || !al ||
+                    (((uintptr_t)p.Out | (uintptr_t)(p.bias ? p.bias : p.Out)) & 15) || (p.ldo & 3)))
+        return IEF_EINVAL;
     const bool bpre = p.Wp != nullptr;
     if (bpre && (p.transb || p.heads > 0 || (p.K & 7) || ((uintptr_t)p.Wp & 15) || (!p.conv && p.ldw != p.K))) return IEF_EINVAL;
     // descriptor sizes (bytes reachable from each operand's base; batched: from the (batch row, head) base)

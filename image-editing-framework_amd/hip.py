@@ -94,7 +94,7 @@ class IefGemmF32Params(Structure):
         ("splits", c_int), ("ws", c_void_p),
         ("x3", c_int), ("sa", c_float), ("sb", c_float), ("vec_out", c_int), ("al32", c_int), ("fast_ok", c_int),
         ("bytesA", ctypes.c_uint), ("bytesW", ctypes.c_uint), ("bytesA2", ctypes.c_uint), ("bytesE1", ctypes.c_uint),
-        ("bytesE2", ctypes.c_uint), ("Wp", c_void_p),
+        ("bytesE2", ctypes.c_uint), ("Wp", c_void_p), ("geglu", c_int),
     ]
 
 
@@ -636,6 +636,7 @@ class f32_contraction:
 
 
 _x3_planes = {}      # (data_ptr, shape) -> (weight tensor kept alive, its _version, planes fp16 [2, N, K])
+X3_FUSE_GEGLU = os.environ.get("IEF_X3_FUSE_GEGLU", "1") == "1"   # 0: FF1 writes its pre-activation, ief_geglu_il_f32 follows (A/B)
 X3_PRESPLIT = os.environ.get("IEF_X3_PRESPLIT", "1") == "1"       # 0: split the weights in every launch, like the activations
 
 
@@ -740,6 +741,9 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     if _is32(a):
         if ln is not None or row_stats:
             raise ValueError("gemm: LayerNorm folding / row statistics exist only on the fp16 path")
+        if geglu and _F32_CONTRACT == "x3" and residual is None and rowvec is None and w.shape[0] % 16 == 0 and X3_FUSE_GEGLU:
+            o = _gemm_f32(a, w, bias=bias, out=out, out_scale=out_scale, geglu=True)       # GEGLU in the GEMM's epilogue
+            return (o, None) if col_stats else o
         o = _gemm_f32(a, w, bias=bias, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch,
                       out=None if geglu else out, out_scale=out_scale)
         if geglu:
@@ -935,7 +939,7 @@ def _splits_f32(lib, p, M, N, K, device):
     return ws
 
 
-def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, transb=False):
+def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_scale=1.0, transb=False, geglu=False):
     """fp32 out[..., n] = (a . w[n] + bias[n] + rowvec[row // rows_per_batch, n] + residual[..., n]) * out_scale;
     transb: w is [K, N] (rows along K) instead of [N, K]"""
     lib = load()
@@ -946,12 +950,14 @@ def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out
     N = w.shape[1] if transb else w.shape[0]
     if (w.shape[0] if transb else w.shape[1]) != K:
         raise ValueError(f"gemm: K mismatch {tuple(w.shape)} vs {K}")
+    No_expect = N // 2 if geglu else N
     if out is None:
-        out = torch.empty(*a.shape[:-1], N, dtype=torch.float32, device=a.device)
+        out = torch.empty(*a.shape[:-1], No_expect, dtype=torch.float32, device=a.device)
     Mo, No, ldo = _rows_ld32(out, "out")
-    if (Mo, No) != (M, N):
+    if (Mo, No) != (M, No_expect):
         raise ValueError("gemm: out shape mismatch")
     p = IefGemmF32Params()
+    p.geglu = 1 if geglu else 0
     p.A, p.W, p.Out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
     if rowvec is not None:
@@ -963,7 +969,7 @@ def _gemm_f32(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out
         p.residual, p.ldr = residual.data_ptr(), ldr
     p.M, p.N, p.K, p.lda, p.ldw, p.ldo = M, N, K, lda, w.stride(0), ldo
     p.out_scale, p.transb = out_scale, 1 if transb else 0
-    ws = _splits_f32(lib, p, M, N, K, a.device)     # noqa: F841  (keeps the slabs alive until the launch is queued)
+    ws = None if geglu else _splits_f32(lib, p, M, N, K, a.device)     # noqa: F841  (keeps the slabs alive until the launch is queued)
     kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_ACT if transb else X3_SCALE_W,        # transb: activation x activation
                  w if (not transb and w.is_contiguous()) else None)
     nbytes = 4.0 * (M * K + N * K + M * N * (2 if residual is not None else 1))

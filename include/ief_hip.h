@@ -271,6 +271,9 @@ typedef struct IefGemmF32Params {
     /* x3: optional pre-split planes of a WEIGHT operand (made once per tensor by ief_x3_split_weights with scale sb): fp16
      * [2][N][K] contiguous (hi plane, lo plane); W is then not read.  Not for transb / batched products. */
     const void* Wp;
+    /* x3, linear only: GEGLU fused into the epilogue -- the weight's rows are interleaved [8 hidden | 8 gate] per 16 columns
+     * (the layout of ief_geglu_il_f32); Out is [M][N / 2] = hidden * gelu(gate) of (a . w + bias); no residual / rowvec / split-K */
+    int geglu;
 } IefGemmF32Params;
 int ief_gemm_f32(const IefGemmF32Params* p, void* stream);
 /* planes[0][i] = fp16(scale w[i]), planes[1][i] = fp16(scale w[i] - planes[0][i]); n % 4 == 0 */

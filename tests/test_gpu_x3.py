@@ -105,6 +105,22 @@ def test_gemm_x3_presplit_weight_planes_equal_on_the_fly_split(monkeypatch):
     assert hip.x3_weight_planes(wd) is not p1
 
 
+@pytest.mark.parametrize("M,Ch,K", [(4096, 1280, 320), (300, 640, 72), (64, 40, 32)])
+def test_gemm_x3_fused_geglu(M, Ch, K, monkeypatch):
+    """FeedForward.net[0] + GEGLU in ONE launch: weight rows interleaved [8 hidden | 8 gate] (the layout `unet.GEGLU` packs), the
+    epilogue pairs a hidden lane with its gate lane and writes hidden * gelu(gate) -- against fp64 and against the two-launch
+    form (GEMM, then ief_geglu_il_f32)"""
+    a, w, bias = f32(M, K, seed=1), f32(2 * Ch, K, seed=2, scale=K ** -0.5), f32(2 * Ch, seed=3, scale=0.1)
+    out = hip.gemm(dev(a), dev(w), bias=dev(bias), geglu=True)
+    pre = (a.double() @ w.double().t() + bias.double()).reshape(M, Ch // 8, 2, 8)
+    ref = (pre[:, :, 0] * F.gelu(pre[:, :, 1])).reshape(M, Ch)
+    e = rel_err(out, ref.float())
+    monkeypatch.setattr(hip, "X3_FUSE_GEGLU", False)
+    two = hip.gemm(dev(a), dev(w), bias=dev(bias), geglu=True)
+    print(f"fused GEGLU {M}x{2 * Ch}x{K}: {e:.2e} vs fp64; vs the two-launch form {rel_err(out, two):.2e}")
+    assert out.shape == (M, Ch) and e < XTOL and rel_err(out, two) < 1e-6
+
+
 @pytest.mark.parametrize("sa,sw", [(1e-4, 1e-3), (1e-2, 1e-5), (300.0, 1.0), (1.0, 30.0)])
 def test_gemm_x3_operand_magnitudes(sa, sw):
     """operands far from unit scale: the lo halves of small elements fall into the fp16 subnormal range (whether the MFMA
