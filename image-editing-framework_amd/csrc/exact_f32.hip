@@ -535,43 +535,63 @@ extern "C" int ief_softmax_rows_f32(float* x, long long rows, int L, void* strea
 // Prompt-to-Prompt cross-attention edit on materialised maps [B*heads][N][L] (L <= 96), in place on the target rows:
 //   P'[w] = c1[w] * sum_v P_src[v] * M[v][w] + c2[w] * P_tgt[w]       (`attention_base.py:118-121`, `attention_control.py:15-46`)
 // edit_src[b] = batch row holding the source maps (or < 0: row untouched), edit_slot[b] = which (M, c1, c2);
-// MT fp32 [slots][96][96] = M transposed and zero-padded, coef fp32 [slots][2][96].  One wave per map row.
+// MT fp32 [slots][96][96] = M transposed and zero-padded, coef fp32 [slots][2][96].
+// The product P_src M runs on the fp32-input MFMA (exact fp32 fma chains): a wave owns 32 map rows of one (target batch row,
+// head) and all 96 output columns (three 32 x 32 accumulators); A = the source rows straight from global memory (lane: row
+// lane & 31, k = 2 step + (lane >> 5)), B = M rows from an LDS copy of the slot's table (M[v][w] = MT[w][v]; padded columns
+// are zero).  One workgroup = 4 waves = 128 rows.
 __global__ __launch_bounds__(256) void p2p_cross_edit_f32_kernel(float* __restrict__ P, const int* __restrict__ edit_src,
                                                                  const int* __restrict__ edit_slot, const float* __restrict__ MT,
                                                                  const float* __restrict__ coef, int B, int heads, int N, int L) {
-    __shared__ float srow[4][96];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long rid = (long long)blockIdx.x * 4 + w;            // over B * heads * N
-    const long long total = (long long)B * heads * N;
-    const bool live = rid < total;
-    const long long rr = live ? rid : 0;
-    const int b = (int)(rr / ((long long)heads * N));
-    const long long hq = rr - (long long)b * heads * N;
-    const int sb = live ? edit_src[b] : -1;
-    if (sb >= 0) {
-        const float* ps = P + ((long long)sb * heads * N + hq) * L;
-        for (int i = lane; i < 96; i += 64) srow[w][i] = i < L ? ps[i] : 0.f;
-    }
-    __syncthreads();
-    if (sb < 0) return;
+    __shared__ float sm[96 * 97];                        // sm[v * 97 + w] = M[v][w]
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int sb = edit_src[b];
+    if (sb < 0) return;                                  // uniform over the workgroup
     const int slot = edit_slot[b];
-    float* pt = P + rr * L;
     const float* mt = MT + (long long)slot * 96 * 96;
+    for (int i = threadIdx.x; i < 96 * 96; i += 256) { const int w = i / 96, v = i - w * 96; sm[v * 97 + w] = mt[i]; }
+    __syncthreads();
+    const int q0 = blockIdx.x * 128 + wv * 32;
+    if (q0 >= N) return;
+    const int q = min(q0 + li, N - 1);                   // rows past N: computed on a duplicate, never stored
+    const float* ps = P + (((long long)sb * heads + h) * N + q) * L;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int ksteps = (L + 1) >> 1;
+    for (int s = 0; s < ksteps; ++s) {
+        const int v = 2 * s + lh;
+        const float a = v < L ? ps[v] : 0.f;
+        const float* mrow = sm + min(v, 95) * 97;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, mrow[t * 32 + li], acc[t], 0, 0, 0);
+    }
+    // accumulator: column (output token) 32 t + li, rows (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32
     const float* c1 = coef + (long long)slot * 2 * 96;
     const float* c2 = c1 + 96;
-    for (int col = lane; col < L; col += 64) {
-        const float* mrow = mt + col * 96;
-        float s = 0.f;
-        for (int v = 0; v < L; ++v) s += srow[w][v] * mrow[v];
-        pt[col] = c1[col] * s + c2[col] * pt[col];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int w = t * 32 + li;
+        if (w >= L) continue;
+        const float k1 = c1[w], k2 = c2[w];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (qq < N) {
+                float* pt = P + (((long long)b * heads + h) * N + qq) * L + w;
+                *pt = k1 * acc[t][r] + k2 * *pt;
+            }
+        }
     }
 }
 extern "C" int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* edit_slot, const float* MT, const float* coef,
                                       int B, int heads, int N, int L, void* stream) {
     if (!P || !edit_src || !edit_slot || !MT || !coef) return IEF_EINVAL;
     if (B <= 0 || heads <= 0 || N <= 0 || L <= 0 || L > 96) return IEF_ESHAPE;
-    const long long total = (long long)B * heads * N;
-    hipLaunchKernelGGL(p2p_cross_edit_f32_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P,
+    hipLaunchKernelGGL(p2p_cross_edit_f32_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, (hipStream_t)stream, P,
                        edit_src, edit_slot, MT, coef, B, heads, N, L);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
