@@ -1,6 +1,6 @@
-"""profiles/r02_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tests/profile_round.sh.
+"""profiles/<tag>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tests/profile_round.sh.
 
-    python profiles/make_pmc_traffic.py gpurun_out/prof_r02
+    python profiles/make_pmc_traffic.py gpurun_out/prof_r03 [r03]
 
 Per kernel of interest (tests/one_kernel.py launches it 4 times): the mean counter value of its dispatches, in KB as rocprofv3
 reports them.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
@@ -26,6 +26,18 @@ CASES = {
                     2 * (16384 * 320 * 2 + 320 * 2880)),
     "attn40": ("attn_flash", "attn_flash_sp_kernel<..> (self-attention, all head dims)",
                "B=4 heads=8 N=L=4096 d=40 (SD1.5 64x64 self-attention)", 2 * 4 * 8 * 4096 * 40 * 4),
+    # split-operand mode (fp32 activations; weights read as pre-split fp16 planes = 4 bytes per weight as well)
+    "conv64x3": ("igemm_x3_kernel", "igemm_x3_kernel<.., conv> (3x3 implicit-GEMM convolution)",
+                 "f16x3: conv3x3 B=4 64x64 320->320 (M=16384 N=320 K=2880), fp32 in / out", 4 * (16384 * 320 * 2 + 320 * 2880)),
+    "conv32x3": ("igemm_x3_kernel", "-", "f16x3: conv3x3 B=4 32x32 640->640 (M=4096 N=640 K=5760), split-K 2: the kernel alone; "
+                 "the reducer launch is listed beside it", 4 * (4096 * 640 * 2 + 640 * 5760)),
+    "gemmsqx3": ("igemm_x3_kernel", "igemm_x3_kernel<.., linear> (linear / 1x1)",
+                 "f16x3: square projection with bias + residual (M=16384 N=320 K=320), fp32 in / out",
+                 4 * (16384 * 320 * 3 + 320 * 320)),
+    "gemmffx3": ("igemm_x3_kernel", "-", "f16x3: FeedForward.net[0] shape without the fused GEGLU (M=4096 N=5120 K=640)",
+                 4 * (4096 * 640 + 5120 * 640 + 4096 * 5120)),
+    "attn40x3": ("attn_flash_x3", "attn_flash_x3_kernel<..> (self-attention, all head dims)",
+                 "f16x3: B=4 heads=8 N=L=4096 d=40, fp32 q / k / v / out", 4 * 4 * 8 * 4096 * 40 * 4),
 }
 
 
@@ -35,7 +47,7 @@ def mean_counter(d, needle):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                if needle in name or "splitk_epilogue" in name:
+                if needle in name or "splitk_epilogue" in name or "splitk_reduce" in name:
                     key = name.replace("void ", "").split("(")[0]
                     out.setdefault(key, []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in out.items()}
@@ -43,8 +55,11 @@ def mean_counter(d, needle):
 
 def main():
     root = sys.argv[1]
+    tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
     res = {"_how": __doc__.strip()}
     for case, (needle, family, shape, alg) in CASES.items():
+        if not os.path.isdir(os.path.join(root, f"pmc_{case}_fetch")):
+            continue
         fetch = mean_counter(os.path.join(root, f"pmc_{case}_fetch"), needle)
         write = mean_counter(os.path.join(root, f"pmc_{case}_write"), needle)
         for k in fetch:
@@ -56,7 +71,7 @@ def main():
                 e["hbm_over_algorithmic"] = round(e["hbm_bytes"] / alg, 2)
             res[f"{k} [{case}]"] = e
     here = os.path.dirname(os.path.abspath(__file__))
-    json.dump(res, open(os.path.join(here, "r02_pmc_traffic.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(here, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     for k, v in res.items():
         if not k.startswith("_"):
             print(k, {a: b for a, b in v.items() if a not in ("shape", "family")})

@@ -229,3 +229,121 @@ def test_sd15_edit50_vs_oracle_fixture(precision):
     gc.collect()
     torch.cuda.empty_cache()
     assert max(errs.values()) < b["lat"] and d_crop <= b["img"] and d_pool <= b["img"] and abs(u8).max() <= b["u8"]
+
+
+# ------------------------------------------------------------------------------------------- reverse passes at the timed sizes
+def test_sd15_null_text_inner_iterations_at_full_size(sd15):
+    """BASELINE.json configs[1] at the size `tests/bench_nti.py` times: SD1.5 shapes, 64x64 latents, UNet batch 1, the TUNED
+    reverse-pass plans (split-K, large tiles) that the small-net tests never select.  No CPU oracle fits (an autograd pass
+    through 860 M parameters per iteration), so properties: finite; one timestep of eight Adam steps lowers the objective
+    (`/root/reference/p2p/inversion/nti.py:26-29`); graph replay == eager launches bit for bit; and the context gradient
+    agrees with the same pass run on heuristic plans (plan table disabled: other tiles, other split-K) to fp16 rounding."""
+    from ief_amd import hip
+    from ief_amd.grad import UNetAdjoint
+    from ief_amd.nti import NullTextOptimizer
+    pipe, cfg = sd15, config.SD15
+    hw = cfg.sample_size
+    pipe.scheduler.set_timesteps(50)
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    x_T = torch.randn(1, 4, hw, hw, generator=g)
+    lats = [x_T + 0.05 * torch.randn(1, 4, hw, hw, generator=g) for _ in range(50)] + [x_T]
+    outs, losses = {}, {}
+    for use_graph in (True, False):
+        opt = NullTextOptimizer(pipe, ctx[1:], 7.5, (hw, hw), use_graph=use_graph)
+        opt.begin([l.to(DEV) for l in lats], ctx[:1])
+        opt.outer_begin(0)
+        ls = []
+        for _ in range(8):
+            opt.inner_step()
+            ls.append(opt.inner_loss())
+        opt.outer_end()
+        outs[use_graph], losses[use_graph] = opt.out[-1].cpu(), ls
+        opt.release()
+    assert all(torch.isfinite(torch.tensor(l)).all() for l in losses.values()) and torch.isfinite(outs[True]).all()
+    print(f"sd15 64x64 NTI objective over 8 Adam steps: {[f'{v:.4e}' for v in losses[True]]}")
+    assert losses[True][-1] < losses[True][0], "eight Adam steps must lower the null-text objective"
+    assert torch.equal(outs[True], outs[False]) and losses[True] == losses[False]
+    # the same gradient on heuristic plans
+    de = torch.randn(1, 4, hw, hw, generator=g)
+    de = (de / de.abs().max()).to(DEV)
+    temb = pipe.unet.time_rows(torch.tensor([601.0], device=DEV))
+    ctx16 = pipe.unet._act(ctx[:1].to(DEV))
+    grads = []
+    saved = hip._plan_table()
+    for table in (saved, {}):
+        hip._plans = table
+        adj = UNetAdjoint(pipe.unet)
+        adj.forward(x_T.to(DEV), temb, ctx16)
+        grads.append(adj.backward(de.contiguous()).float().cpu())
+    hip._plans = saved
+    e = rel_err(grads[0], grads[1])
+    print(f"sd15 64x64 B=1 context gradient, tuned vs heuristic plans: {e:.3e} (max |grad| {grads[1].abs().max():.3e})")
+    assert e < 2e-2
+
+
+def test_sdxl_pix2pix_zero_gradient_step_at_full_size():
+    """BASELINE.json configs[4] at full size: the SDXL family at 128x128 latents (1024x1024 px), UNet batch 2 — one
+    Pix2Pix-zero reference step and one edit step (`/root/reference/pix2pix-zero/model/sd_utils.py:160-180`) through the
+    product's own engine on the tuned plans: the reference pass writes the 70 `attn2` maps, the edit pass runs forward keeping
+    the adjoint's inputs, the map objective at every cross-attention module, the reverse pass down to the latents, the SGD
+    step, the second forward and the DDIM update.  No CPU oracle fits (autograd through 2.6 G parameters); properties:
+    finite, objective > 0, the SGD step along the gradient LOWERS the objective (a first-order property the gradient must
+    have), and graph replay == eager launches bit for bit (fixed summation orders)."""
+    from ief_amd.pix2pix_zero.model.sd_utils import _Engine
+    cfg = config.SDXL
+    pipe = StableDiffusionPipeline.from_pretrained("synthetic:sdxl")
+    unet = pipe.unet
+    hw = cfg.sample_size
+    pipe.scheduler.set_timesteps(50)
+    t = pipe.scheduler.timesteps.tolist()[20]
+    g = torch.Generator().manual_seed(7)
+    lat0 = torch.randn(1, 4, hw, hw, generator=g).to(DEV)
+    ctx_ref = (torch.randn(2, 77, cfg.cross_attention_dim, generator=g)).to(DEV)
+    ctx_edit = (ctx_ref + 0.5 * torch.randn(2, 77, cfg.cross_attention_dim, generator=g).to(DEV)).contiguous()
+    size = float(hw * 8)
+    added = {"text_embeds": (torch.randn(2, cfg.pooled_text_dim, generator=g) * 0.5).to(DEV),
+             "time_ids": torch.tensor([[size, size, 0.0, 0.0, size, size]] * 2, device=DEV)}
+    rows = unet.time_rows(torch.tensor([float(t)], device=DEV), unet.aug_embedding(added)).reshape(2, -1)
+    coef = torch.tensor([*pipe.scheduler.step_coeffs(t), 7.5, 0.0], device=DEV)
+    for m in unet.attention_modules():
+        m.cache_kv = False
+    res = {}
+    for use_graph in (True, False):
+        E = _Engine(pipe, hw, hw, 1, 0.1, use_graph, temb_rows=2)
+        assert len(E.cross) == 70
+        E.temb.copy_(rows), E.coef.copy_(coef)
+        E.set_ctx(ctx_ref)
+        for m, st in zip(E.cross, E.stage):
+            m.map_out = st
+        E.lat.copy_(lat0)
+        E.ref_step()                                    # the maps of the reference prompt at this step
+        for m in E.cross:
+            m.map_out = None
+        E.set_ctx(ctx_edit)
+        E.lat.copy_(lat0)
+        E.edit_step()
+        l0 = E.step_loss.item()
+        lat1, x1 = E.lat.clone(), E.x_in.clone()        # x_in now holds x - lr * grad
+        if use_graph:
+            E.adj.forward(x1, E.temb, E.ctx16)
+            E.adj.backward(E.zero_eps)
+            l1 = E.adj.loss_parts.sum().item()
+            E.x_in.copy_(lat0.expand_as(E.x_in))
+            E.adj.forward(E.x_in, E.temb, E.ctx16)
+            gmax = E.adj.backward(E.zero_eps).abs().max().item()
+            print(f"sdxl 128x128 B=2 Pix2Pix-zero objective {l0:.5e} -> {l1:.5e} after the SGD step along the gradient "
+                  f"(max |scaled grad| {gmax:.3e})")
+            assert l0 > 0 and l1 < l0
+        res[use_graph] = (l0, lat1.cpu())
+        assert torch.isfinite(lat1).all() and (lat1 - lat0).abs().max() > 0
+        del E
+        gc.collect()
+        torch.cuda.empty_cache()
+    for m in unet.attention_modules():
+        m.cache_kv = True
+        m._kv_key, m._kv = None, None
+    del pipe
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert res[True][0] == res[False][0] and torch.equal(res[True][1], res[False][1])
