@@ -32,40 +32,7 @@
 #include "ief_common.h"
 #include "ief_params.h"
 
-#define YBK 32
-#define YLD 48          // halves per LDS row: 32 of the K tile + 16 of padding (96 B)
-
-typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
-struct RowCoordY { int b, oy, ox, ok; };
-
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bload(rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
-}
-
-// s x -> (hi, lo) for four consecutive k: v_pk_mul, v_cvt_pk_f16_f32 (round to nearest), then lo = fp16(s x - hi) with the
-// subtraction as ONE v_fma_mix_f32 per element (it reads the fp16 half directly: no conversion back) -- 10 VALU per chunk
-__device__ __forceinline__ void split4(const f32x4 v, const float s, half4& hi, half4& lo) {
-    const f32x4 x = v * s;
-    const half2_t h0 = __builtin_convertvector(f32x2{x[0], x[1]}, half2_t);
-    const half2_t h1 = __builtin_convertvector(f32x2{x[2], x[3]}, half2_t);
-    float r0, r1, r2, r3;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x[0]), "v"(h0));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x[1]), "v"(h0));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(x[2]), "v"(h1));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(x[3]), "v"(h1));
-    const half2_t l0 = __builtin_convertvector(f32x2{r0, r1}, half2_t);
-    const half2_t l1 = __builtin_convertvector(f32x2{r2, r3}, half2_t);
-    hi = half4{h0[0], h0[1], h1[0], h1[1]};
-    lo = half4{l0[0], l0[1], l1[0], l1[1]};
-}
-
-enum { X3_LIN = 0, X3_LIN_SLOW = 1, X3_CONV = 2, X3_CONV_UPS = 3, X3_CONV_SLOW = 4 };
+#include "x3_common.h"
 
 // fp32 weights -> the two fp16 planes [2][n] the GEMM's B operand is staged from when it is a WEIGHT (static: split once per
 // tensor by the host wrapper, not once per launch and workgroup): planes[0] = hi = fp16(s w), planes[1] = lo = fp16(s w - hi)
@@ -91,7 +58,8 @@ extern "C" int ief_x3_split_weights(const float* w, void* planes, long long n, f
 // BPRE: the B operand comes as pre-split fp16 planes (p.Wp: [2][N][K] contiguous, ief_x3_split_weights); otherwise it is
 // fp32 and split while staged, like A (the batched attention products: both operands are activations).
 template <int WM, int WN, int TM, int TN, int KIND, bool TRANSB, bool BPRE>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3_kernel(const IefGemmF32Params p) {
+__global__ __launch_bounds__(64 * WM * WN, (2 * 2 * 16 * (WM * TM + WN * TN) * YLD * 2 > 80 * 1024) ? (WM * WN) / 4 : (WM * WN) / 2)
+void igemm_x3_kernel(const IefGemmF32Params p) {
     constexpr bool CONV = KIND >= X3_CONV;
     constexpr bool HASFAST = KIND == X3_LIN || KIND == X3_CONV;      // kinds with the predicate-free main-loop loader
     constexpr int NTH = 64 * WM * WN;
@@ -111,8 +79,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
     const int lr = lane & 15, lg = lane >> 4;
     const int ntn = (p.N + BN - 1) / BN;
     const int ntiles = ((p.M + BM - 1) / BM) * ntn;
+    // tile order: each XCD (its own L2) takes a contiguous run of logical ids (xcd_remap); inside a run, groups of X3_GROUP_M
+    // row blocks are walked column by column, so the ~64 workgroups resident on an XCD cover a near-square patch of the
+    // output: an A row block and a weight column block are each fetched into that L2 once per patch instead of the whole
+    // weight once per row block (PMC: FeedForward.net[0] 4.9x its algorithmic bytes in row-major order)
     const int bid = xcd_remap(blockIdx.x, ntiles);
-    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int grp = bid / (X3_GROUP_M * ntn), within = bid - grp * (X3_GROUP_M * ntn);
+    const int gsz = min(X3_GROUP_M, ntm - grp * X3_GROUP_M);
+    const int tn = within / gsz, tm = grp * X3_GROUP_M + (within - tn * gsz);
     const int m0 = tm * BM, n0 = tn * BN;
     const float* A = p.A;
     const float* W = p.W;
@@ -565,6 +540,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 4) void igemm_x3
 }
 
 // column-tile width for N output columns: 80 where it divides N (every SD width is a multiple of 320), else 64
+// 128 x 160 tiles on 8 waves (one workgroup per CU) for the launches they cover; 0 switches them off (A/B runs: IEF_X3_WIDE=0)
+static int g_x3_wide = 1;
+extern "C" void ief_gemm_x3_set_variant(int v) { g_x3_wide = v; }
+// which launches take the wide tile.  Measured on the SD1.5 batch-4 shapes (gpurun, HIP events per launch): every 3x3
+// convolution gains 8-12 % (fewer L1 fills and LDS stores per MFMA: an activation row block is staged for 160 columns
+// instead of 80), linears gain where N <= 1280 or K >= 1280 and lose 5-30 % on the wide, shallow ones (FeedForward.net[0]
+// at the 64x64 level: 32 column tiles of a 10-tile K loop, where two independent workgroups per CU hide each other's
+// prologue and epilogue)
+static bool x3_wide_ok(int conv, int N, int K) { return g_x3_wide && N % 160 == 0 && (conv || N <= 1280 || K >= 1280); }
+// column-tile width the host's split-K policy counts tiles with
+extern "C" int ief_gemm_x3_bn_k(int conv, int N, int K) { return x3_wide_ok(conv, N, K) ? 160 : (N % 80 == 0) ? 80 : 64; }
 extern "C" int ief_gemm_x3_bn(int N) { return (N % 80 == 0) ? 80 : 64; }
 extern "C" int ief_gemm_x3_bm(int M, int N) {
     (void)M; (void)N;
@@ -617,7 +603,9 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
     const unsigned long long half = 0x40000000ull;
     const unsigned long long kspan = p.transb ? 4ull * p.K * p.ldw : 4ull * p.K;
     p.fast_ok = (bA < half && bW < half && bA2 < half && bE1 < half && bE2 < half && kspan < half) ? 1 : 0;
-    const bool n80 = ief_gemm_x3_bn(p.N) == 80;
+    if (x3_wide_ok(p.conv, p.N, p.K) && bpre && !p.a_scalar && (!p.conv || (p.al32 && !p.ups)))
+        return p.conv ? launch_igemm_x3<4, 2, 2, 5, X3_CONV, false, true>(p, st) : launch_igemm_x3<4, 2, 2, 5, X3_LIN, false, true>(p, st);
+    const bool n80 = p.N % 80 == 0;
 #define X3_GO(KIND_, TRANSB_, BPRE_) (n80 ? launch_igemm_x3<4, 1, 2, 5, KIND_, TRANSB_, BPRE_>(p, st) \
                                           : launch_igemm_x3<2, 2, 4, 2, KIND_, TRANSB_, BPRE_>(p, st))
     if (p.conv) {
@@ -658,13 +646,17 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     half_t* Vl = Vh + DT * 32 * VLD;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+    // (head, query block) from the XCD-contiguous logical id: the query blocks of one head run on ONE XCD, whose L2 then
+    // holds that head's K / V once (plain (x, y) order spreads them over all eight: PMC 4.5x the algorithmic bytes)
+    const int nqb = gridDim.x;
+    const int lid = xcd_remap(blockIdx.x + nqb * blockIdx.y, nqb * gridDim.y);
+    const int bh = lid / nqb, qb = lid - bh * nqb, b = bh / p.heads, h = bh - b * p.heads;
     const int bq = p.q_src ? p.q_src[b] : b, bk = p.k_src ? p.k_src[b] : b, bv = p.v_src ? p.v_src[b] : b;
     const float* Q = p.Q + (long long)bq * p.sQb + (long long)h * D;
     const float* Kp = p.K + (long long)bk * p.sKb + (long long)h * D;
     const float* Vp = p.V + (long long)bv * p.sVb + (long long)h * D;
     float* O = p.Out + (long long)b * p.sOb + (long long)h * D;
-    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int q0 = qb * 128 + wid * 32;
     const int qi = q0 + li;
     // zero the LDS once: padding columns of K (d >= D) and padding rows of V^T stay zero (staging never writes them)
     for (int c = tid; c < (int)(sizeof(smem_f) / 16); c += 256) ((f32x4*)smem_f)[c] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -124,7 +124,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_x3_split_weights", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_gemm_x3_bn_k", "ief_gemm_x3_set_variant", "ief_x3_split_weights", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
     # activation gradients of the fp32-storage modes (csrc/backward_f32.hip)
     "ief_groupnorm_bwd_f32", "ief_layernorm_bwd_f32", "ief_geglu_il_bwd_f32", "ief_zero_insert2x_f32", "ief_pool2x2_sum_f32",
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
@@ -204,6 +204,10 @@ def load():
     lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_float, c_int, c_void_p]
     lib.ief_gemm_x3_bm.argtypes = [c_int, c_int]
+    lib.ief_gemm_x3_bn_k.argtypes = [c_int, c_int, c_int]
+    if os.environ.get("IEF_X3_WIDE"):          # 0: keep every launch on the 128 x 80 tile (A/B runs)
+        lib.ief_gemm_x3_set_variant.argtypes = [c_int]
+        lib.ief_gemm_x3_set_variant(int(os.environ["IEF_X3_WIDE"]))
     lib.ief_x3_split_weights.argtypes = [c_void_p, c_void_p, c_longlong, c_float, c_void_p]
     lib.ief_groupnorm_bwd_f32.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.ief_layernorm_bwd_f32.argtypes = [c_void_p] * 5 + [c_longlong, c_int, c_float, c_void_p]
@@ -922,11 +926,14 @@ def _splits_f32(lib, p, M, N, K, device):
     x3 = _F32_CONTRACT == "x3"
     nk = -(-K // 32)
     if x3:      # 128 x 80 tiles, two workgroups per CU: split below 1.5 per CU, towards 2 per CU (measured: without the split the
-        # 32x32 / 16x16 levels run 1.5-2x slower than the reducer launches cost)
-        tiles = -(-M // lib.ief_gemm_x3_bm(M, N)) * -(-N // lib.ief_gemm_x3_bn(N))
-        if tiles >= X3_SPLIT_BELOW or nk < 8:
+        # 32x32 / 16x16 levels run 1.5-2x slower than the reducer launches cost); 128 x 160 tiles, one 8-wave workgroup per CU:
+        # split below one per two CUs, towards one per CU
+        bn = lib.ief_gemm_x3_bn_k(1 if p.conv else 0, N, K)
+        tiles = -(-M // lib.ief_gemm_x3_bm(M, N)) * -(-N // bn)
+        below, target = (X3_SPLIT_BELOW_WIDE, X3_SPLIT_TARGET_WIDE) if bn == 160 else (X3_SPLIT_BELOW, X3_SPLIT_TARGET)
+        if tiles >= below or nk < 8:
             return None
-        splits = max(1, min(-(-X3_SPLIT_TARGET // tiles), nk // 4, 16))
+        splits = max(1, min(-(-target // tiles), nk // 4, 16))
     else:
         tiles = -(-M // 128) * -(-N // lib.ief_gemm_f32_bn(N))
         if tiles >= 256 or nk < 8:
@@ -1299,6 +1306,8 @@ def _batched32(p, t, heads, d, which):
 
 X3_SPLIT_BELOW = int(os.environ.get("IEF_X3_SPLIT_BELOW", "384"))      # split-K policy of the x3 GEMM (A/B runs)
 X3_SPLIT_TARGET = int(os.environ.get("IEF_X3_SPLIT_TARGET", "512"))
+X3_SPLIT_BELOW_WIDE = int(os.environ.get("IEF_X3_SPLIT_BELOW_WIDE", "129"))
+X3_SPLIT_TARGET_WIDE = int(os.environ.get("IEF_X3_SPLIT_TARGET_WIDE", "256"))
 GN3_F32 = os.environ.get("IEF_GN3_F32", "1") == "1"          # 0: the one-launch fp32 GroupNorm (A/B runs)
 FLASH_F32 = os.environ.get("IEF_FLASH_F32", "1") == "1"      # 0: always materialise the fp32 maps (A/B runs)
 

@@ -17,7 +17,7 @@ from ief_amd.dist import broadcast_tensors, shard_indices  # noqa: E402
 
 def _declared():
     src = open(os.path.join(ROOT, "include", "ief_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|long long|const char\*)\s+(ief_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|long long|void|const char\*)\s+(ief_\w+)\s*\(", src, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

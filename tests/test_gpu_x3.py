@@ -61,7 +61,7 @@ def test_gemm_x3_identity_asymmetric():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 72), (16384, 320, 320), (77, 1280, 768), (1024, 40, 1024),
-                                   (4, 1280, 320), (515, 64, 4), (130, 2560, 5120)])
+                                   (4, 1280, 320), (515, 64, 4), (130, 2560, 5120), (4096, 160, 64), (1000, 480, 96)])
 def test_gemm_x3(M, N, K):
     a, w = f32(M, K, seed=1), f32(N, K, seed=2, scale=K ** -0.5)
     bias, res = f32(N, seed=3, scale=0.1), f32(M, N, seed=4)
@@ -105,7 +105,7 @@ def test_gemm_x3_presplit_weight_planes_equal_on_the_fly_split(monkeypatch):
     assert hip.x3_weight_planes(wd) is not p1
 
 
-@pytest.mark.parametrize("M,Ch,K", [(4096, 1280, 320), (300, 640, 72), (64, 40, 32)])
+@pytest.mark.parametrize("M,Ch,K", [(4096, 1280, 320), (300, 640, 72), (64, 40, 32), (333, 160, 64)])
 def test_gemm_x3_fused_geglu(M, Ch, K, monkeypatch):
     """FeedForward.net[0] + GEGLU in ONE launch: weight rows interleaved [8 hidden | 8 gate] (the layout `unet.GEGLU` packs), the
     epilogue pairs a hidden lane with its gate lane and writes hidden * gelu(gate) -- against fp64 and against the two-launch
@@ -119,6 +119,28 @@ def test_gemm_x3_fused_geglu(M, Ch, K, monkeypatch):
     two = hip.gemm(dev(a), dev(w), bias=dev(bias), geglu=True)
     print(f"fused GEGLU {M}x{2 * Ch}x{K}: {e:.2e} vs fp64; vs the two-launch form {rel_err(out, two):.2e}")
     assert out.shape == (M, Ch) and e < XTOL and rel_err(out, two) < 1e-6
+
+
+def test_gemm_x3_wide_tile_equals_the_narrow_tile():
+    """the launches that take the 128 x 160 tile on 8 waves (`ief_gemm_x3_bn_k`) run the same MFMA sequence per output
+    element as on the 128 x 80 tile: bit-identical results, linear (+ fused GEGLU) and 3x3 with concat and 1x1 extra sources"""
+    import ctypes
+    lib = hip.load()
+    lib.ief_gemm_x3_set_variant.argtypes = [ctypes.c_int]
+    assert lib.ief_gemm_x3_bn_k(0, 320, 256) == 160 and lib.ief_gemm_x3_bn_k(1, 160, 960) == 160 and lib.ief_gemm_x3_bn_k(0, 200, 64) == 64
+    a, w, bias = f32(1000, 256, seed=1), f32(320, 256, seed=2, scale=0.06), f32(320, seed=3, scale=0.1)
+    x, x2 = f32(2, 16, 16, 64, seed=4), f32(2, 16, 16, 32, seed=5)
+    wc = f32(160, 9 * 96 + 96, seed=6, scale=0.03)
+    outs = []
+    try:
+        for wide in (1, 0):
+            lib.ief_gemm_x3_set_variant(wide)
+            outs.append((hip.gemm(dev(a), dev(w), bias=dev(bias)), hip.gemm(dev(a), dev(w), bias=dev(bias), geglu=True),
+                         hip.conv3x3(dev(x), dev(wc), x2=dev(x2), extra=(dev(x), dev(x2)))))
+    finally:
+        lib.ief_gemm_x3_set_variant(1)
+    for got, ref in zip(*outs):
+        assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("sa,sw", [(1e-4, 1e-3), (1e-2, 1e-5), (300.0, 1.0), (1.0, 30.0)])
@@ -145,7 +167,11 @@ def test_gemm_nt_x3(M, N, K):
     (2, 16, 64, 0, 128, 1, False, False, False), (1, 32, 320, 0, 320, 1, False, False, False),
     (2, 16, 128, 64, 128, 1, False, True, False), (2, 16, 64, 0, 64, 2, False, False, False),
     (2, 8, 128, 0, 128, 1, True, False, False), (1, 16, 128, 0, 128, 2, False, False, True),
-    (4, 8, 64, 64, 64, 1, False, False, False), (1, 8, 32, 0, 36, 1, False, False, False)])
+    (4, 8, 64, 64, 64, 1, False, False, False), (1, 8, 32, 0, 36, 1, False, False, False),
+    # Cout % 160 == 0: the 128 x 160 tile on 8 waves -- concat + 1x1 extra sources, stride 2, one-sided padding
+    (2, 16, 128, 64, 160, 1, False, True, False), (2, 16, 64, 0, 160, 2, False, False, False),
+    (1, 16, 128, 0, 320, 2, False, False, True), (4, 8, 64, 64, 160, 1, False, False, False),
+    (1, 12, 32, 0, 160, 1, False, False, False)])
 def test_conv3x3_x3(B, H, C1, C2, Cout, stride, ups, extra, hi):
     x, x2 = f32(B, H, H, C1, seed=1), (f32(B, H, H, C2, seed=2) if C2 else None)
     Ct = C1 + C2
