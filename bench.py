@@ -108,14 +108,14 @@ def build_pipe(cfg_name, dev, rank, world, precision="f16"):
     else:
         sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(cfg).items()}
     unet = UNet2DConditionModel(cfg, sd, device=dev, precision=precision)
-    if world > 1:
-        from ief_amd.dist import broadcast_tensors
-        broadcast_tensors(unet.packed_tensors(), src=0)   # RCCL over xGMI, a few flat buckets
-        torch.cuda.synchronize()
     pipe = StableDiffusionPipeline(unet, WordPieceTokenizer(cfg.text_max_length),
                                    SyntheticTextEncoder(cfg.cross_attention_dim).to(dev),
                                    AutoencoderKL(SD_VAE if cfg_name in ("sd15", "sd21") else TINY_VAE, device=dev, precision=precision),
                                    DDIMScheduler(), cfg, sd if rank == 0 else None)
+    if world > 1:
+        from ief_amd.dist import broadcast_pipeline
+        broadcast_pipeline(pipe, src=0)   # RCCL over xGMI: UNet, VAE and text encoder as a few flat buckets (the drivers' collective)
+        torch.cuda.synchronize()
     return pipe, cfg
 
 
