@@ -800,7 +800,8 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 
 __global__ __launch_bounds__(256) void gn3_finalize_kernel(const float* __restrict__ pmean, const float* __restrict__ pm2, int C, int HW,
                                                            int P, int nch, int groups, float eps, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+                                                           const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ gstats) {
     __shared__ float sn[4], sm[4], sq[4];
     const int b = blockIdx.x / groups, g = blockIdx.x - b * groups, cpg = C / groups, tid = threadIdx.x, lane = tid & 63;
     float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -830,6 +831,7 @@ __global__ __launch_bounds__(256) void gn3_finalize_kernel(const float* __restri
 #pragma unroll
     for (int w = 1; w < 4; ++w) chan_merge(n, mean, m2, sn[w], sm[w], sq[w]);
     const float rstd = 1.0f / sqrtf(m2 / n + eps);
+    if (gstats && tid == 0) { gstats[(long long)blockIdx.x * 2] = mean; gstats[(long long)blockIdx.x * 2 + 1] = rstd; }     // the reverse pass reads these
     for (int j = tid; j < cpg; j += 256) {
         const int c = g * cpg + j;
         const float sc = rstd * gamma[c];
@@ -894,9 +896,169 @@ extern "C" int ief_groupnorm_silu_f32_ws(const float* x, const float* x2, int C1
     hipLaunchKernelGGL(gn3_stats_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, pmean, pm2);
     IEF_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn3_finalize_kernel, dim3(B * groups), dim3(256), 0, st, pmean, pm2, C, HW, P, nch, groups, eps, gamma, beta,
-                       scale, shift);
+                       scale, shift, (float*)nullptr);
     IEF_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn3_apply_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, scale, shift, out, silu);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// ---- GroupNorm (+SiLU) BACKWARD in the same row-streaming form (the one-workgroup-per-(image, group) kernel of
+// backward_f32.hip runs 32 workgroups at UNet batch 1 and walks 40-byte slices: 197 us per call in the null-text loop).
+//   xh = (x - mean) rstd, z = xh gamma + beta, g = dy silu'(z) gamma, dx = rstd (g - mean(g) - xh mean(g xh)) + add
+// Five launches: statistics of x (gn3_stats + gn3_finalize, as the forward), per-run per-channel sums of g and g xh, their
+// per-group means (fixed order), the result.  A channel quad may straddle two groups (10 channels per group at C = 320): every
+// component carries its own group's (mean, rstd, moments).
+#define GN3B_U 6
+static inline void gn3b_chunks(int HW, int C, int* nch, int* P) {
+    const int CQ = C >> 2, CQB = CQ < 256 ? CQ : 256, PY = 256 / CQB;
+    int p = GN3B_U * PY;
+    if (p > HW) p = HW;
+    *P = p;
+    *nch = (HW + p - 1) / p;
+}
+extern "C" long long ief_groupnorm_bwd_f32_ws_floats(int B, int HW, int C) {
+    int nch, P;
+    gn3b_chunks(HW, C, &nch, &P);
+    return ief_groupnorm_f32_ws_floats(B, HW, C) + 2ll * B * nch * C + 4ll * B * C;
+}
+__device__ __forceinline__ float dsilu_z(float z) {
+    const float sg = 1.0f / (1.0f + expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+// MODE 0: partial sums of g and g xh per (image, run, channel); MODE 1: the result (mom = per-group means of g and g xh)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
+                                                      const float* __restrict__ dy, const float* __restrict__ add, int HW, int P,
+                                                      const float* __restrict__ gstats, const float* __restrict__ mom, int groups,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                      float* __restrict__ p1, float* __restrict__ p2, float* __restrict__ dx,
+                                                      float* __restrict__ dx2) {
+    __shared__ f32x4 red[256];
+    const int C = C1 + C2, CQ = C >> 2, cpg = C / groups;
+    const int CQB = CQ < 256 ? CQ : 256, PY = 256 / CQB;
+    const int tid = threadIdx.x, cq = tid % CQB, py = tid / CQB;
+    const bool lane_ok = py < PY;
+    const int chunk = blockIdx.x, b = blockIdx.y, nch = gridDim.x;
+    const int p0 = chunk * P, pn = min(P, HW - p0);
+    for (int qb = 0; qb * CQB < CQ; ++qb) {
+        const int q = qb * CQB + cq;
+        const bool ok = lane_ok && q < CQ;
+        const int c = ok ? q * 4 : 0;
+        int cs = 4;
+        const float* src = gn3_src(x, x2, C1, C2, b, HW, c, &cs) + (long long)p0 * cs;
+        const float* dsrc = dy + ((long long)b * HW + p0) * C + c;
+        f32x4 mu, rs, m1 = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c + j) / cpg;
+            mu[j] = gstats[((long long)b * groups + g) * 2];
+            rs[j] = gstats[((long long)b * groups + g) * 2 + 1];
+            if (MODE == 1) { m1[j] = mom[((long long)b * groups + g) * 2]; m2[j] = mom[((long long)b * groups + g) * 2 + 1]; }
+        }
+        const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+        f32x4 v[GN3B_U], d[GN3B_U];
+#pragma unroll
+        for (int u = 0; u < GN3B_U; ++u) {
+            const int pp = py + u * PY;
+            const bool in = ok && pp < pn;
+            v[u] = in ? *(const f32x4*)(src + (long long)pp * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[u] = in ? *(const f32x4*)(dsrc + (long long)pp * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < GN3B_U; ++u) {
+            const int pp = py + u * PY;
+            if (!(ok && pp < pn)) continue;
+            const f32x4 xh = (v[u] - mu) * rs;
+            f32x4 gv = d[u] * ga;
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] *= dsilu_z(xh[j] * ga[j] + be[j]);
+            }
+            if (MODE == 0) { s1 += gv; s2 += gv * xh; }
+            else {
+                f32x4 r = rs * (gv - m1 - xh * m2);
+                if (add) r += *(const f32x4*)(add + ((long long)b * HW + p0 + pp) * C + c);
+                float* dst = c < C1 ? dx + ((long long)b * HW + p0 + pp) * C1 + c : dx2 + ((long long)b * HW + p0 + pp) * C2 + (c - C1);
+                *(f32x4*)dst = r;
+            }
+        }
+        if (MODE == 0) {
+            __syncthreads();
+            red[tid] = s1;
+            __syncthreads();
+            f32x4 t1 = {0.f, 0.f, 0.f, 0.f};
+            if (ok && py == 0) for (int y = 0; y < PY; ++y) t1 += red[y * CQB + cq];       // fixed order
+            __syncthreads();
+            red[tid] = s2;
+            __syncthreads();
+            if (ok && py == 0) {
+                f32x4 t2 = {0.f, 0.f, 0.f, 0.f};
+                for (int y = 0; y < PY; ++y) t2 += red[y * CQB + cq];
+                const long long o = ((long long)b * nch + chunk) * C + c;
+                *(f32x4*)(p1 + o) = t1;
+                *(f32x4*)(p2 + o) = t2;
+            }
+        }
+    }
+}
+// per (image, group): mom = (sum p1, sum p2) / (HW cpg), runs x channels in a fixed order
+__global__ __launch_bounds__(256) void gn3_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int C, int HW,
+                                                               int nch, int groups, float* __restrict__ mom) {
+    __shared__ float sa[4], sb[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups, cpg = C / groups, tid = threadIdx.x, lane = tid & 63;
+    const int cl = tid % cpg, r0 = tid / cpg, rstep = 256 / cpg;
+    float a = 0.f, q = 0.f;
+    if (r0 < rstep) {
+        const float* pa = p1 + (long long)b * nch * C + g * cpg + cl;
+        const float* pq = p2 + (long long)b * nch * C + g * cpg + cl;
+        for (int ch = r0; ch < nch; ch += rstep) { a += pa[(long long)ch * C]; q += pq[(long long)ch * C]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
+    if (lane == 0) { sa[tid >> 6] = a; sb[tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        const float inv = 1.0f / ((float)HW * (float)cpg);
+        mom[(long long)blockIdx.x * 2] = ((sa[0] + sa[1]) + (sa[2] + sa[3])) * inv;
+        mom[(long long)blockIdx.x * 2 + 1] = ((sb[0] + sb[1]) + (sb[2] + sb[3])) * inv;
+    }
+}
+extern "C" int ief_groupnorm_bwd_f32_ws(const float* x, const float* x2, int C1, int C2, const float* dy, const float* add, float* dx,
+                                        float* dx2, const float* gamma, const float* beta, int B, int HW, int groups, float eps,
+                                        int silu, float* ws, long long ws_floats, void* stream) {
+    if (!x || !dy || !dx || !gamma || !beta || !ws || (C2 > 0 && (!x2 || !dx2))) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups || (C1 & 3) || (C2 & 3)) return IEF_ESHAPE;
+    const int C = C1 + C2;
+    if (C / groups > 256) return IEF_ESHAPE;
+    if (ws_floats < ief_groupnorm_bwd_f32_ws_floats(B, HW, C)) return IEF_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)ws | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)(dx2 ? dx2 : dx) |
+         (uintptr_t)(add ? add : dy) | (uintptr_t)gamma | (uintptr_t)beta) & 15) return IEF_EALIGN;
+    int nch, P, nchb, Pb;
+    gn3_chunks(HW, C, &nch, &P);
+    gn3b_chunks(HW, C, &nchb, &Pb);
+    float* pmean = ws;
+    float* pm2 = pmean + (long long)B * nch * C;
+    float* scale = pm2 + (long long)B * nch * C;
+    float* shift = scale + (long long)B * C;
+    float* q1 = shift + (long long)B * C;
+    float* q2 = q1 + (long long)B * nchb * C;
+    float* gstats = q2 + (long long)B * nchb * C;
+    float* mom = gstats + 2ll * B * groups;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn3_stats_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, pmean, pm2);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_finalize_kernel, dim3(B * groups), dim3(256), 0, st, pmean, pm2, C, HW, P, nch, groups, eps, gamma, beta,
+                       scale, shift, gstats);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_bwd_kernel<0>, dim3(nchb, B), dim3(256), 0, st, x, x2, C1, C2, dy, add, HW, Pb, gstats, (const float*)nullptr,
+                       groups, gamma, beta, silu, q1, q2, dx, dx2);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_bwd_finalize_kernel, dim3(B * groups), dim3(256), 0, st, q1, q2, C, HW, nchb, groups, mom);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_bwd_kernel<1>, dim3(nchb, B), dim3(256), 0, st, x, x2, C1, C2, dy, add, HW, Pb, gstats, mom, groups, gamma,
+                       beta, silu, q1, q2, dx, dx2);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

@@ -108,9 +108,12 @@ class FusedDenoiser:
     def rebind(self, context, guidance_scale, uncond_list, added_cond_kwargs=None):
         """point a captured loop at the next image: new tables, new cross-attention K/V, the new controller's plan"""
         self._fill(context, guidance_scale, uncond_list, added_cond_kwargs)
-        if self.ctx_table is None:          # K/V of the fixed context live in tensors the graph reads: refresh in place
-            for m, kv in self._keep:
-                hip.gemm(self.ctx, m.w_kv, out=kv)
+        if self.ctx_table is None:          # K/V of the fixed context live in tensors the graph reads: refresh in place, by the
+            # same kernels the forward used (the model's contraction mode: "x3" and "f32" differ in the last bits, and an
+            # image must not depend on whether its loop was captured for it or re-pointed at it)
+            with hip.f32_contraction(getattr(self.unet, "contract", "f32")):
+                for m, kv in self._keep:
+                    hip.gemm(self.ctx, m.w_kv, out=kv)
         fresh = self.unet._plan
         if self.plan is not None:
             self.plan.load_from(fresh, self.B)

@@ -124,7 +124,7 @@ EXPORTS = [
     # reference-precision (fp32) mode
     "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
-    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_gemm_x3_bn_k", "ief_gemm_x3_set_variant", "ief_x3_split_weights", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws",
+    "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_gemm_x3_bn_k", "ief_gemm_x3_set_variant", "ief_x3_split_weights", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws", "ief_groupnorm_bwd_f32_ws_floats", "ief_groupnorm_bwd_f32_ws",
     # activation gradients of the fp32-storage modes (csrc/backward_f32.hip)
     "ief_groupnorm_bwd_f32", "ief_layernorm_bwd_f32", "ief_geglu_il_bwd_f32", "ief_zero_insert2x_f32", "ief_pool2x2_sum_f32",
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
@@ -224,6 +224,10 @@ def load():
     lib.ief_groupnorm_f32_ws_floats.restype = c_longlong
     lib.ief_groupnorm_silu_f32_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                               c_float, c_int, c_void_p, c_longlong, c_void_p]
+    lib.ief_groupnorm_bwd_f32_ws_floats.argtypes = [c_int, c_int, c_int]
+    lib.ief_groupnorm_bwd_f32_ws_floats.restype = c_longlong
+    lib.ief_groupnorm_bwd_f32_ws.argtypes = [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int,
+                                             c_void_p, c_longlong, c_void_p]
     lib.ief_layernorm_f32.argtypes = [c_void_p] * 4 + [c_longlong, c_int, c_float, c_void_p]
     lib.ief_add_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]
     lib.ief_silu_f32.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p]
@@ -1790,6 +1794,15 @@ def groupnorm_bwd(x, dy, gamma, beta, groups, eps, silu=False, x2=None, add=None
             raise ValueError("groupnorm_bwd: x / x2 / dy / add must be contiguous, dy and add [B, HW, C1+C2]")
         dx = torch.empty_like(x)
         dx2 = torch.empty_like(x2) if x2 is not None else None
+        al16 = all(t is None or t.data_ptr() % 16 == 0 for t in (x, x2, dy, add, gamma, beta))
+        if GN3_F32 and al16 and C1 % 4 == 0 and C2 % 4 == 0 and (C1 + C2) // groups <= 256:
+            nws = lib.ief_groupnorm_bwd_f32_ws_floats(B, HW, C1 + C2)
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            with _Timed("gn3_bwd_f32 (5 launches)", 0.0):
+                _check(lib.ief_groupnorm_bwd_f32_ws(x.data_ptr(), _ptr(x2), C1, C2, dy.data_ptr(), _ptr(add), dx.data_ptr(), _ptr(dx2),
+                                                    _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups,
+                                                    eps, 1 if silu else 0, ws.data_ptr(), nws, _stream()), "ief_groupnorm_bwd_f32_ws")
+            return (dx, dx2) if x2 is not None else dx
         with _Timed("gn_bwd_f32_kernel", 0.0):
             _check(lib.ief_groupnorm_bwd_f32(x.data_ptr(), _ptr(x2), C1, C2, dy.data_ptr(), _ptr(add), dx.data_ptr(), _ptr(dx2),
                                              _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups,

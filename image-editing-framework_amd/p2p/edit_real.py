@@ -26,8 +26,9 @@ parser.add_argument("--source_prompt", type=str, default="a gray horse in the fi
 parser.add_argument("--target_prompt", type=str, default="a whie horse in the field")
 parser.add_argument("--source_image", type=str, default="./test.jpg")
 parser.add_argument("--inversion_type", type=str, default="null-text")
-# not a reference flag: "f32" = the reference's own precision (fp32 weights / activations; ddim inversion only)
-parser.add_argument("--precision", type=str, default="f16", choices=["f16", "f32", "f16x3"])
+# not a reference flag; default = the mode that meets the reference's fp32 results to 1e-3 (see edit_syn.py); every inversion
+# type runs in every mode (the null-text reverse pass in fp32 for "f16x3" / "f32")
+parser.add_argument("--precision", type=str, default=os.environ.get("IEF_PRECISION", "f16x3"), choices=["f16", "f32", "f16x3"])
 
 
 def edit_latent(pipe, editor, x_T, source_prompt, target_prompt, edit_type, device, extra=None, num_inference_steps=50,

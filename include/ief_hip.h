@@ -309,6 +309,12 @@ int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, floa
 long long ief_groupnorm_f32_ws_floats(int B, int HW, int C);
 int ief_groupnorm_silu_f32_ws(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma, const float* beta,
                               int B, int HW, int groups, float eps, int silu, float* ws, long long ws_floats, void* stream);
+/* dx (, dx2) of the GroupNorm (+SiLU) above given dy; `add` (nullable) is summed into the result; row-streaming, five launches;
+ * same shape rules as ief_groupnorm_silu_f32_ws, every pointer 16-byte aligned; ws: ief_groupnorm_bwd_f32_ws_floats floats */
+long long ief_groupnorm_bwd_f32_ws_floats(int B, int HW, int C);
+int ief_groupnorm_bwd_f32_ws(const float* x, const float* x2, int C1, int C2, const float* dy, const float* add, float* dx, float* dx2,
+                             const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu, float* ws,
+                             long long ws_floats, void* stream);
 int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C, float eps,
                       void* stream);
 int ief_add_f32(const float* a, const float* b, float* out, long long n, void* stream);

@@ -25,8 +25,10 @@ def main():
     ap.add_argument("--latent", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--precision", default="f16", choices=["f16", "f16x3", "f32"],
+                    help="f16x3 / f32: the reverse pass at the reference's precision (fp32 storage, csrc/backward_f32.hip)")
     a = ap.parse_args()
-    pipe = StableDiffusionPipeline.from_pretrained(f"synthetic:{a.config}")
+    pipe = StableDiffusionPipeline.from_pretrained(f"synthetic:{a.config}", precision=a.precision)
     cfg = pipe.cfg
     hw = a.latent or cfg.sample_size
     pipe.scheduler.set_timesteps(50)
@@ -54,7 +56,7 @@ def main():
         opt.run(lats, ctx[:1], 10, 0.0)
         torch.cuda.synchronize()
         full_s = time.time() - t0
-    print(json.dumps({"workload": f"NTI {a.config} latent {hw}x{hw}", "inner_iteration_ms": round(inner_ms, 3),
+    print(json.dumps({"workload": f"NTI {a.config} latent {hw}x{hw}", "precision": a.precision, "inner_iteration_ms": round(inner_ms, 3),
                       "plain_forward_B1_ms": round(fwd_ms, 3), "full_50x10_s": round(full_s, 2),
                       "inner_iterations_per_s": round(1000.0 / inner_ms, 2)}))
 

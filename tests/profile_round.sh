@@ -2,9 +2,9 @@
 # One round's profiles on the GPU box (run through gpurun from the repo root): rocprofv3 kernel-trace summaries of the
 # headline bench command in every precision mode at 512x512 (and the headline mode at 1024x1024), FETCH_SIZE / WRITE_SIZE
 # passes of the dominant kernels, and the default `python bench.py` line.  Everything lands under gpurun_out/prof_<tag>/ ;
-# copy what is to be judged into profiles/.     usage: bash tests/profile_round.sh r03 [pmc|trace|bench ...]
+# copy what is to be judged into profiles/.     usage: bash tests/profile_round.sh r03 [trace|nti|pmc|bench ...]
 TAG=${1:-r03}; shift
-WHAT=${*:-trace pmc bench}
+WHAT=${*:-trace nti pmc bench}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -20,6 +20,13 @@ if [[ " $WHAT " == *" trace "* ]]; then
   echo "k1024 f16x3 rc=$?"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k1024_f16 -- python3 $ROOT/bench.py $HEAD --precision f16 --latent 128 --steps 10 > $OUT/k1024_f16.log 2>&1
   echo "k1024 f16 rc=$?"
+fi
+if [[ " $WHAT " == *" nti "* ]]; then      # the null-text inner iteration (forward + reverse pass + Adam), SD1.5 64x64, UNet batch 1
+  for mode in f16 f16x3; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/nti_$mode -- python3 $ROOT/tests/bench_nti.py --skip-full --iters 20 --precision $mode > $OUT/nti_$mode.log 2>&1
+    echo "nti $mode rc=$?"
+    tail -n 1 $OUT/nti_$mode.log
+  done
 fi
 if [[ " $WHAT " == *" pmc "* ]]; then
   for k in conv64x3 conv32x3 gemmsqx3 gemmffx3 attn40x3 gemmsq conv64 conv32 attn40; do

@@ -347,3 +347,25 @@ def test_full_edit_images_x3_within_1e3(tinyx3):
     print(f"x3 10-step edit: latents rel err {e_lat:.3e}; images in [0,1] max |diff| {d_img:.3e}; uint8 max diff {diff.max()}, "
           f"identical pixels {(diff == 0).mean():.4f}")
     assert e_lat < 3e-4 and d_img <= 1e-3 and diff.max() <= 1
+
+
+def test_pooled_loop_rerun_is_bit_identical_to_its_first_run(tinyx3):
+    """a captured loop re-pointed at the next image (`denoise.acquire` -> `rebind`) refreshes the cross-attention K / V the
+    graph reads; they must come from the SAME contraction kernels the forward used when the loop was captured ("x3" here, not
+    the library default), else an image depends on whether it was the first of its shape in the process -- which made the
+    two-rank PIE driver differ from the one-rank run by a grey level"""
+    from ief_amd.denoise import acquire, drop_pool
+    pipe = tinyx3
+    hw = pipe.unet.config.sample_size
+    pipe.scheduler.set_timesteps(50)
+    g = torch.Generator().manual_seed(3)
+    ctx = dev(torch.randn(1, 77, pipe.unet.config.cross_attention_dim, generator=g) * 0.3)
+    x0 = dev(torch.randn(1, 4, hw, hw, generator=g))
+    drop_pool()
+    outs = []
+    for _ in range(3):
+        loop = acquire(pipe, ctx, 1, (hw, hw), None, mode="invert")
+        outs.append(loop.run(x0, num_steps=4).cpu())
+        loop.release()
+    drop_pool()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
