@@ -1664,6 +1664,37 @@ def _transpose_maps_f32(x):
     return out
 
 
+def _attn_apply_t_f32(maps, x, heads, out=None):
+    """out [B, L, heads*d] = maps[b, h]^T [L x N] @ x[b, h] [N x d] per (batch row, head) WITHOUT transposing the maps: the product
+    is taken as (x^T maps)^T -- x^T [d x N] is the small A operand, the maps [N x L] are read in place as the [K][N] operand,
+    and only the [d x L] result is transposed back (the explicit [R, N, L] -> [R, L, N] copy moved 2 x 537 MB per 64x64
+    self-attention layer and gradient)"""
+    lib = load()
+    _act32(maps, "maps"), _act32(x, "x")
+    B, N, Cx = x.shape
+    d = Cx // heads
+    L = maps.shape[2]
+    if tuple(maps.shape) != (B * heads, N, L) or not maps.is_contiguous():
+        raise ValueError("attn_apply_t: maps must be contiguous [B*heads, N, L]")
+    xt = x.reshape(B, N, heads, d).permute(0, 2, 3, 1).contiguous()                    # [B, heads, d, N]
+    tmp = torch.empty(B * heads, d, L, dtype=torch.float32, device=x.device)
+    p = IefGemmF32Params()
+    p.A, p.W, p.Out = xt.data_ptr(), maps.data_ptr(), tmp.data_ptr()
+    p.M, p.N, p.K = d, L, N
+    p.sAb, p.sAh, p.lda = heads * d * N, d * N, N
+    p.sWb, p.sWh, p.ldw = heads * N * L, N * L, L
+    p.sOb, p.sOh, p.ldo = heads * d * L, d * L, L
+    p.batch, p.heads, p.out_scale, p.transb = B, heads, 1.0, 1
+    kn = _set_x3(p, X3_SCALE_ACT, X3_SCALE_PROB)
+    with _Timed(f"{kn}<apply^T {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
+        _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention apply, transposed maps)")
+    res = tmp.reshape(B, heads, d, L).permute(0, 3, 1, 2).reshape(B, L, heads * d)
+    if out is None:
+        return res.contiguous()
+    out.copy_(res)
+    return out
+
+
 def _softmax_bwd_f32_(probs, dprobs, scale):
     """in place on dprobs: dS = scale * P o (dP - rowsum(dP o P))"""
     lib = load()
@@ -1685,8 +1716,12 @@ def _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv):
     if want_dq:
         dq = _attn_apply_f32(ds, k, heads, out=dq)                        # dQ = dS K   (out: the caller's column slice, if any)
     if want_dkv:
-        dk = _attn_apply_f32(_transpose_maps_f32(ds), q, heads, out=dk)            # dK = dS^T Q
-        dv = _attn_apply_f32(_transpose_maps_f32(probs), do, heads, out=dv)        # dV = P^T dO
+        if ds.shape[2] % 4 == 0 and ds.shape[1] % 4 == 0:      # 16-byte rows of the [K][N] operand: every self-attention level
+            dk = _attn_apply_t_f32(ds, q, heads, out=dk)                                # dK = dS^T Q
+            dv = _attn_apply_t_f32(probs, do, heads, out=dv)                            # dV = P^T dO
+        else:                                                  # 77 keys: the maps are small, transpose them
+            dk = _attn_apply_f32(_transpose_maps_f32(ds), q, heads, out=dk)
+            dv = _attn_apply_f32(_transpose_maps_f32(probs), do, heads, out=dv)
     return dq, dk, dv
 
 
