@@ -122,7 +122,7 @@ EXPORTS = [
     "ief_nti_loss_grad_f32", "ief_nti_adam_f32", "ief_gemm_tile_bn", "ief_gather_rows_f16",
     "ief_attn_map_loss_bwd_f16", "ief_axpy_f32", "ief_map_loss_blocks", "ief_groupnorm_cstat_f16", "ief_gemm_tile_bm",
     # reference-precision (fp32) mode
-    "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
+    "ief_gemm_f32", "ief_softmax_rows_f32", "ief_p2p_cross_edit_f32", "ief_attn_cross_p2p_f32", "ief_groupnorm_silu_f32", "ief_layernorm_f32",
     "ief_add_f32", "ief_silu_f32", "ief_geglu_il_f32", "ief_timestep_embedding_f32", "ief_gather_rows_f32",
     "ief_conv_in_f32act", "ief_conv_out_f32act", "ief_image_u8", "ief_gemm_f32_bn", "ief_attn_flash_f32", "ief_gemm_x3_bn", "ief_gemm_x3_bm", "ief_gemm_x3_bn_k", "ief_gemm_x3_set_variant", "ief_x3_split_weights", "ief_groupnorm_f32_ws_floats", "ief_groupnorm_silu_f32_ws", "ief_groupnorm_bwd_f32_ws_floats", "ief_groupnorm_bwd_f32_ws",
     # activation gradients of the fp32-storage modes (csrc/backward_f32.hip)
@@ -201,6 +201,7 @@ def load():
     lib.ief_softmax_rows_f32.argtypes = [c_void_p, c_longlong, c_int, c_void_p]
     lib.ief_attn_flash_f32.argtypes = [POINTER(IefAttnF32Params), c_void_p]
     lib.ief_p2p_cross_edit_f32.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_void_p]
+    lib.ief_attn_cross_p2p_f32.argtypes = [POINTER(IefAttnF32Params)] + [c_void_p] * 5
     lib.ief_groupnorm_silu_f32.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_float, c_int, c_void_p]
     lib.ief_gemm_x3_bm.argtypes = [c_int, c_int]
@@ -1449,6 +1450,34 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     return out
 
 
+X3_FUSE_CROSS = os.environ.get("IEF_X3_FUSE_CROSS", "1") == "1"      # 0: materialised cross maps (scores, softmax, edit, apply: A/B runs)
+
+
+def _attn_cross_p2p_x3(q, k, v, heads, scale, edit_src, edit_slot, mt32, coef, out=None):
+    """`ief_attn_cross_p2p_f32`: the edited cross-attention layer of the f16x3 mode in one launch (maps stay in registers)"""
+    lib = load()
+    B, N, C = q.shape
+    L, d = k.shape[1], C // heads
+    _dev32(mt32, "mt32"), _dev32(coef, "coef")
+    if tuple(mt32.shape[-2:]) != (96, 96) or coef.shape[-1] != 96 or not mt32.is_contiguous() or not coef.is_contiguous():
+        raise ValueError("attn_cross_p2p: mt must be contiguous [slots,96,96] fp32, coef [slots,2,96] fp32")
+    if out is None:
+        out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+    p = IefAttnF32Params()
+    p.Q, p.K, p.V, p.Out = _act32(q, "q").data_ptr(), _act32(k, "k").data_ptr(), _act32(v, "v").data_ptr(), _act32(out, "out").data_ptr()
+    p.B, p.heads, p.N, p.L, p.d, p.scale = B, heads, N, L, d, scale
+    p.sQb, _, p.ldq = _batched32(p, q, heads, d, "q")
+    p.sKb, _, p.ldk = _batched32(p, k, heads, d, "k")
+    p.sVb, _, p.ldv = _batched32(p, v, heads, d, "v")
+    p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
+    p.x3 = 1
+    nedit = 2.0 * B * heads * N * 96 * 96
+    with _Timed(f"attn_cross_p2p_x3_kernel<{d}>", 4.0 * B * heads * N * L * d + nedit, 4.0 * B * heads * d * (2 * N + 2 * L)):
+        _check(lib.ief_attn_cross_p2p_f32(byref(p), _devi32(edit_src, "edit_src").data_ptr(), _devi32(edit_slot, "edit_slot").data_ptr(),
+                                          mt32.data_ptr(), coef.data_ptr(), _stream()), "ief_attn_cross_p2p_f32")
+    return out
+
+
 def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None, coef=None, out=None):
     """Cross-attention (<= 96 keys) with the fused Prompt-to-Prompt map edit (see include/ief_hip.h).
     fp32 operands: materialised maps, `mt` must then be the fp32 table."""
@@ -1457,6 +1486,8 @@ def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None
             o = _attn_flash_f32(q, k, v, heads, scale, out=out)
             if o is not None:
                 return o
+        elif _F32_CONTRACT == "x3" and X3_FUSE_CROSS and k.shape[1] <= 96 and q.shape[2] // heads in (40, 64, 80, 160):
+            return _attn_cross_p2p_x3(q, k, v, heads, scale, edit_src, edit_slot, mt, coef, out)
         probs = _attn_scores_f32(q, k, heads, scale)
         if edit_src is not None:
             p2p_cross_edit_(probs, q.shape[0], heads, edit_src, edit_slot, mt, coef)

@@ -302,6 +302,11 @@ int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
  * [slots][96][96] (M transposed, zero padded), coef fp32 [slots][2][96]; edit_src / edit_slot as IefCrossParams */
 int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* edit_slot, const float* MT, const float* coef, int B,
                            int heads, int N, int L, void* stream);
+/* the four launches above (scores, softmax, edit, apply) as ONE: cross-attention over L <= 96 keys with the map edit applied to
+ * maps that stay in registers; split-operand arithmetic (p->x3 is not consulted), d in {40, 64, 80, 160}, no batch-row indirection
+ * (q_src / k_src / v_src NULL); edit_src NULL: plain attention (csrc/cross_p2p_x3.hip) */
+int ief_attn_cross_p2p_f32(const IefAttnF32Params* p, const int* edit_src, const int* edit_slot, const float* MT, const float* coef,
+                           void* stream);
 int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma, const float* beta,
                            int B, int HW, int groups, float eps, int silu, void* stream);
 /* the same operator in three row-streaming launches (per-run channel statistics, Chan merge per group, apply); C1, C2

@@ -369,3 +369,48 @@ def test_pooled_loop_rerun_is_bit_identical_to_its_first_run(tinyx3):
         loop.release()
     drop_pool()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("heads,N,L,d", [(8, 256, 77, 40), (2, 200, 77, 80), (2, 64, 77, 160), (4, 130, 40, 64), (1, 1024, 96, 40)])
+def test_cross_attention_p2p_edit_fused_x3(heads, N, L, d, monkeypatch):
+    """`ief_attn_cross_p2p_f32`: scores, softmax, P' = c1 (P_src M) + c2 P_tgt (`/root/reference/p2p/model/attention_base.py:118-121`)
+    and P'.V of an edited cross-attention layer in ONE launch with the maps in registers -- against fp64 and against the
+    four-launch materialised form; two edited rows with different tables, a table entry that is not an fp16 number, query
+    counts that are not multiples of 128, 40 / 77 / 96 keys"""
+    B, C = 4, heads * d
+    q, k, v = f32(B, N, C, seed=1), f32(B, L, C, seed=2, scale=1.5), f32(B, L, C, seed=3)
+    g = torch.Generator().manual_seed(0)
+    mt, coef = torch.zeros(2, 96, 96), torch.zeros(2, 2, 96)
+    Ms, cs = [], []
+    for s in range(2):
+        mapper = torch.randint(-1, L, (L,), generator=g)
+        a = (mapper != -1).float()
+        M = torch.zeros(L, L)
+        M[mapper % L, torch.arange(L)] = 1.0
+        M[5, 5], M[5, 6] = 1.0 / 3.0, 2.0 / 3.0
+        gate = (torch.rand(L, generator=g) > 0.3).float() * (0.25 + 0.75 * torch.rand(L, generator=g))
+        c1, c2 = gate * a, 1 - gate * a
+        mt[s, :L, :L] = M.t()
+        coef[s, 0, :L], coef[s, 1, :L] = c1, c2
+        Ms.append(M.double()), cs.append((c1.double(), c2.double()))
+    es, sl = torch.tensor([-1, 0, -1, 2], dtype=torch.int32), torch.tensor([0, 1, 0, 0], dtype=torch.int32)
+    qh = q.double().reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    P = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1)
+    Pe = P.clone()
+    for b in range(B):
+        if es[b] >= 0:
+            c1, c2 = cs[sl[b]]
+            Pe[b] = c1 * (P[es[b]] @ Ms[sl[b]]) + c2 * P[b]
+    ref = (Pe @ vh).permute(0, 2, 1, 3).reshape(B, N, C).float()
+    args = (dev(q), dev(k), dev(v), heads, d ** -0.5, dev(es), dev(sl), dev(mt), dev(coef))
+    hip.profile_begin()
+    out = hip.attn_cross_p2p(*args)
+    names = [n for n, _, _ in hip.profile_end()]
+    assert names == [f"attn_cross_p2p_x3_kernel<{d}>"], names
+    monkeypatch.setattr(hip, "X3_FUSE_CROSS", False)
+    mat = hip.attn_cross_p2p(*args)
+    e, em = rel_err(out, ref), rel_err(mat, ref)
+    print(f"cross-attention + P2P edit fused N={N} L={L} d={d}: {e:.2e} vs fp64 (materialised form {em:.2e})")
+    assert out.dtype == torch.float32 and e < XTOL and em < XTOL
