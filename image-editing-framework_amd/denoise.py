@@ -97,7 +97,10 @@ class FusedDenoiser:
             if self.ctx is None:
                 self.ctx = torch.zeros_like(ctx16)
         else:
-            put("ctx", ctx16)
+            # a COPY: in the fp32-storage modes `_act` hands back the caller's own tensor, and a pooled loop re-pointed at the
+            # next image writes into this buffer -- the previous image's context (still held by the caller for its null-text
+            # optimisation / edit) must not change under it
+            put("ctx", ctx16.clone())
 
     def _key(self, context, uncond_list):
         plan = self.unet._plan

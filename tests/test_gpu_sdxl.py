@@ -474,9 +474,18 @@ def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
         drive(folder, one)
         drive(folder, many, "--invert_batch", "3", "--in_flight", "2")
         same(one, many)
+    # null-text: in flight (every mode) the values are the per-image run's bit for bit.  A BATCHED inversion is bit-identical
+    # per row only on the fp16-storage path (its kernels' tiles and split-K do not depend on the batch); in the fp32-storage
+    # modes a row of a batch-2 launch differs from the batch-1 launch in the last bits (3e-6 on the latents: split-K follows
+    # the row count), which the null-text optimisation of a RANDOM-weight net amplifies without bound -- so the batched
+    # schedule is pinned where it is exact
     one, many = tmp_path / "nti_one", tmp_path / "nti_many"
     drive("p2p", one, "--inversion_type", "null-text")
-    drive("p2p", many, "--inversion_type", "null-text", "--invert_batch", "2", "--in_flight", "2")
+    drive("p2p", many, "--inversion_type", "null-text", "--in_flight", "2")
+    same(one, many)
+    one, many = tmp_path / "nti16_one", tmp_path / "nti16_many"
+    drive("p2p", one, "--inversion_type", "null-text", "--precision", "f16")
+    drive("p2p", many, "--inversion_type", "null-text", "--precision", "f16", "--invert_batch", "2", "--in_flight", "2")
     same(one, many)
 
 
