@@ -14,8 +14,9 @@
 //      `attention_control.py:15-46` lowered to (M, c1, c2) by the host's plan);
 //   3. O^T = V^T P'^T as in the fused attention.
 // Every product is Ah Bh + Al Bh + Ah Bl on fp16 MFMAs (scales: q / k / v 2^2, maps 2^14, table 2^8), softmax and the mix in
-// fp32.  K / V / table tiles are staged through LDS one at a time (load, split, store, barrier): the kernel is latency bound
-// and small (5 MFLOP per workgroup); what it removes is three launches and the HBM round trips of the maps.
+// fp32.  K (all <= 96 keys), the table and V^T take turns in ONE LDS region, each loaded into registers a phase ahead and
+// staged whole (two barriers per phase): the kernel is latency bound and small (5 MFLOP per workgroup); what it removes is
+// three launches and the HBM round trips of the maps.
 #include "ief_common.h"
 #include "ief_params.h"
 #include "x3_common.h"
@@ -28,16 +29,21 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
     constexpr int DG = (D + 15) / 16;            // 16-deep groups of the score product
     constexpr int DT = (D + 31) / 32;            // 32-row tiles of O^T
     constexpr int KLD = DG * 16 + 8;             // halves per K row
-    constexpr int VLD = 36;                      // halves per V^T row (32 keys + 4)
+    constexpr int VLD = 100;                     // halves per V^T row (all <= 96 keys + 4)
     constexpr int MLD = 100;                     // halves per table row (96 source tokens + 4)
     constexpr float SQ = 4.f, SK = 4.f, SV = 4.f, SP = 16384.f, SM = 256.f;
-    __shared__ __attribute__((aligned(16))) half_t smem_c[2 * 32 * KLD + 2 * DT * 32 * VLD + 2 * 96 * MLD];
+    // ONE region, re-used phase by phase (K of the source row | the table | K of this row | V^T), each image complete (all
+    // <= 96 keys) so that a phase costs two barriers, not two per 32-key tile.  Whatever a phase leaves behind is finite fp16
+    // data, and the region is zeroed once at the start: padding columns of K (d >= D) multiply the zero padding of q.
+    constexpr int RK = 2 * 96 * KLD, RV = 2 * DT * 32 * VLD, RM = 2 * 96 * MLD;
+    constexpr int RSZ = RK > RV ? (RK > RM ? RK : RM) : (RV > RM ? RV : RM);
+    __shared__ __attribute__((aligned(16))) half_t smem_c[RSZ];
     __shared__ float cf[2 * 96];
     half_t* Kh = smem_c;
-    half_t* Kl = Kh + 32 * KLD;
-    half_t* Vh = Kl + 32 * KLD;                  // [DT*32][VLD]
+    half_t* Kl = Kh + 96 * KLD;
+    half_t* Vh = smem_c;                         // [DT*32][VLD]
     half_t* Vl = Vh + DT * 32 * VLD;
-    half_t* Mh = Vl + DT * 32 * VLD;             // [96][MLD]
+    half_t* Mh = smem_c;                         // [96][MLD]
     half_t* Ml = Mh + 96 * MLD;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -83,32 +89,42 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
                 rk[t][i] = (t < nt && c < KCH && t * 32 + row < p.L) ? *(const f32x4*)(Kp + (long long)(t * 32 + row) * p.ldk + ch * 4)
                                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        __syncthreads();                          // the previous phase's readers are done
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int c = tid + 256 * i;
+                if (t < nt && c < KCH) {
+                    const int row = c / (D / 4), ch = c - row * (D / 4);
+                    half4 hh, ll;
+                    split4(rk[t][i], SK, hh, ll);
+                    *(half4*)(Kh + (t * 32 + row) * KLD + ch * 4) = hh;
+                    *(half4*)(Kl + (t * 32 + row) * KLD + ch * 4) = ll;
+                }
+            }
+        if (DG * 16 > D) {                        // padding columns: zeros (the region may hold another phase's data)
+            constexpr int PADC = (DG * 16 - D) / 4;
+            for (int c = tid; c < 96 * PADC; c += 256) {
+                const int row = c / PADC, ch = c - row * PADC;
+                *(half4*)(Kh + row * KLD + D + ch * 4) = half4{0, 0, 0, 0};
+                *(half4*)(Kl + row * KLD + D + ch * 4) = half4{0, 0, 0, 0};
+            }
+        }
+        __syncthreads();
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[t][r] = -INFINITY;
             if (t < nt) {
-                __syncthreads();                  // the previous tile's readers are done
-#pragma unroll
-                for (int i = 0; i < NLD; ++i) {
-                    const int c = tid + 256 * i;
-                    if (c < KCH) {
-                        const int row = c / (D / 4), ch = c - row * (D / 4);
-                        half4 hh, ll;
-                        split4(rk[t][i], SK, hh, ll);
-                        *(half4*)(Kh + row * KLD + ch * 4) = hh;
-                        *(half4*)(Kl + row * KLD + ch * 4) = ll;
-                    }
-                }
-                __syncthreads();
                 f32x16 sacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
                 for (int g = 0; g < DG; ++g) {
-                    const half8_t kh = *(const half8_t*)(Kh + li * KLD + g * 16 + 8 * lh);
-                    const half8_t kl = *(const half8_t*)(Kl + li * KLD + g * 16 + 8 * lh);
+                    const half8_t kh = *(const half8_t*)(Kh + (t * 32 + li) * KLD + g * 16 + 8 * lh);
+                    const half8_t kl = *(const half8_t*)(Kl + (t * 32 + li) * KLD + g * 16 + 8 * lh);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc, 0, 0, 0);
@@ -151,9 +167,13 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
         const int slot = edit_slot[b];
         // table: 96 x 96 floats = 2304 chunks of 4, split with scale 2^8; coefficients
         const float* mt = MT + (long long)slot * 96 * 96;
-        f32x4 rm[9];                              // 96 * 24 = 9 * 256 chunks
+        f32x4 rm[9];                              // 96 * 24 = 9 * 256 chunks; the loads travel under the source row's maps
 #pragma unroll
         for (int i = 0; i < 9; ++i) rm[i] = *(const f32x4*)(mt + (tid + 256 * i) * 4);
+        if (tid < 192) cf[tid] = coef[(long long)slot * 192 + tid];
+        f32x16 Ps[3];
+        probs(src, Ps);
+        __syncthreads();                          // K of the source row is dead: the table takes the region
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int c = tid + 256 * i;
@@ -163,9 +183,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
             *(half4*)(Mh + w * MLD + ch * 4) = hh;
             *(half4*)(Ml + w * MLD + ch * 4) = ll;
         }
-        if (tid < 192) cf[tid] = coef[(long long)slot * 192 + tid];
-        f32x16 Ps[3];
-        probs(src, Ps);                           // its barriers also publish the table and the coefficients
+        __syncthreads();
         half8_t ph[6], pl[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) split_p(Ps[s >> 1], s & 1, ph[s], pl[s]);
@@ -218,33 +236,36 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
     for (int tt = 0; tt < DT; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[tt][r] = 0.f;
+    __syncthreads();                              // K of this row is dead: V^T takes the region (rows d >= D stay whatever they
+                                                  // are: an A-operand row only reaches its own output row, which is not stored)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + 256 * i;
+            if (t < nt && c < KCH) {
+                const int row = c / (D / 4), ch = c - row * (D / 4);
+                half4 hh, ll;
+                split4(rv[t][i], SV, hh, ll);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Vh[(ch * 4 + j) * VLD + t * 32 + row] = hh[j];
+                    Vl[(ch * 4 + j) * VLD + t * 32 + row] = ll[j];
+                }
+            }
+        }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         if (t < nt) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int c = tid + 256 * i;
-                if (c < KCH) {
-                    const int row = c / (D / 4), ch = c - row * (D / 4);
-                    half4 hh, ll;
-                    split4(rv[t][i], SV, hh, ll);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        Vh[(ch * 4 + j) * VLD + row] = hh[j];
-                        Vl[(ch * 4 + j) * VLD + row] = ll[j];
-                    }
-                }
-            }
-            __syncthreads();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 half8_t ph, pl;
                 split_p(P[t], s, ph, pl);
 #pragma unroll
                 for (int tt = 0; tt < DT; ++tt) {
-                    const half_t* vr = Vh + (tt * 32 + li) * VLD + 16 * s + 4 * lh;
-                    const half_t* vq = Vl + (tt * 32 + li) * VLD + 16 * s + 4 * lh;
+                    const half_t* vr = Vh + (tt * 32 + li) * VLD + t * 32 + 16 * s + 4 * lh;
+                    const half_t* vq = Vl + (tt * 32 + li) * VLD + t * 32 + 16 * s + 4 * lh;
                     half8_t vh, vl;
                     const half4 a0 = *(const half4*)vr, a1 = *(const half4*)(vr + 8);
                     const half4 b0 = *(const half4*)vq, b1 = *(const half4*)(vq + 8);
