@@ -129,11 +129,16 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc, 0, 0, 0);
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc, 0, 0, 0);
                 }
+                if ((t + 1) * 32 > p.L) {         // wave-uniform: only the tile that crosses L masks
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    P[t][r] = key < p.L ? sacc[r] * sc2 : -INFINITY;
-                    mx = fmaxf(mx, P[t][r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        P[t][r] = key < p.L ? sacc[r] * sc2 : -INFINITY;
+                        mx = fmaxf(mx, P[t][r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { P[t][r] = sacc[r] * sc2; mx = fmaxf(mx, P[t][r]); }
                 }
             }
         }
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { P[t][r] = exp2f(P[t][r] - mx); ls += P[t][r]; }      // exp2(-inf) = 0
+            for (int r = 0; r < 16; ++r) { P[t][r] = __builtin_amdgcn_exp2f(P[t][r] - mx); ls += P[t][r]; }      // bare v_exp_f32; exp2(-inf) = 0
         ls += __shfl_xor(ls, 32);
         const float inv = 1.0f / ls;
 #pragma unroll

@@ -735,26 +735,37 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc, 0, 0, 0);
         }
-        // ---- online softmax over the key rows of this tile (register r <-> key (r&3) + 8 (r>>2) + 4 lh)
+        // ---- online softmax over the key rows of this tile (register r <-> key (r&3) + 8 (r>>2) + 4 lh).  The loop is bound by
+        // vector issue, not by the 21 MFMAs (289 vector instructions per tile before the three trims below, ~150 after): keys
+        // are masked only in the tile that crosses L, exp2 is the bare v_exp_f32 (arguments <= 0: the library form's
+        // denormal-range rescue costs five instructions per call and guards results that round to 0 here anyway), and the
+        // accumulators are rescaled only when some lane's running maximum moved (alpha == 1 exactly otherwise)
         float mx = -INFINITY;
+        if ((t + 1) * 32 > p.L) {                 // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sacc[r] = key < p.L ? sacc[r] * sc2 : -INFINITY;
-            mx = fmaxf(mx, sacc[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sacc[r] = key < p.L ? sacc[r] * sc2 : -INFINITY;
+                mx = fmaxf(mx, sacc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] *= sc2; mx = fmaxf(mx, sacc[r]); }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
         float ls = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = exp2f(sacc[r] - m_new); ls += sacc[r]; }
+        for (int r = 0; r < 16; ++r) { sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new); ls += sacc[r]; }
         l_run = l_run * alpha + ls;
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+        }
         m_run = m_new;
-#pragma unroll
-        for (int tt = 0; tt < DT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
         // ---- O^T += V^T P^T, two 16-key steps; P split with scale 2^14
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
