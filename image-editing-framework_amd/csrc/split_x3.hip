@@ -541,8 +541,8 @@ void igemm_x3_kernel(const IefGemmF32Params p) {
 
 // column-tile width for N output columns: 80 where it divides N (every SD width is a multiple of 320), else 64
 // 128 x 160 tiles on 8 waves (one workgroup per CU) for the launches they cover; 0 switches them off (A/B runs: IEF_X3_WIDE=0)
-static int g_x3_wide = 1;
-extern "C" void ief_gemm_x3_set_variant(int v) { g_x3_wide = v; }
+static int g_x3_wide = 1, g_flash_ks2 = 1;
+extern "C" void ief_gemm_x3_set_variant(int v) { g_x3_wide = v & 1; g_flash_ks2 = (v & 2) ? 0 : 1; }     // bit 1: 32-key flash tiles
 // which launches take the wide tile.  Measured on the SD1.5 batch-4 shapes (gpurun, HIP events per launch): every 3x3
 // convolution gains 8-12 % (fewer L1 fills and LDS stores per MFMA: an activation row block is staged for 160 columns
 // instead of 80), linears gain where N <= 1280 or K >= 1280 and lose 5-30 % on the wide, shallow ones (FeedForward.net[0]
@@ -632,17 +632,20 @@ int ief_gemm_x3_dispatch(const IefGemmF32Params& pin, hipStream_t st) {
 // K and V tiles are fetched one tile ahead into registers through buffer descriptors (keys past L read zeros and are masked
 // to -inf), split once per workgroup and written to LDS (K rows of 16 DG + 8 halves, V^T rows of 36 halves: conflict-free
 // fragment reads).  Head dims are padded to 16 for the scores (d = 40: 48) and to 32 for O^T (d = 40: 64).
-template <int D>
+// KS: 32-key sub-tiles staged and consumed per barrier pair (2: one online-softmax update, one rescale and two barriers per
+// 64 keys instead of per 32)
+template <int D, int KS>
 __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(const IefAttnF32Params p) {
     constexpr int DG = (D + 15) / 16;            // 16-deep groups of the score product
     constexpr int DT = (D + 31) / 32;            // 32-row tiles of O^T
     constexpr int KLD = DG * 16 + 8;             // halves per K row (bytes = 16 mod 32: conflict-free b128 fragments)
-    constexpr int VLD = 36;                      // halves per V^T row (32 keys + 4)
+    constexpr int KT = 32 * KS;                  // keys per iteration
+    constexpr int VLD = KT + 4;                  // halves per V^T row
     constexpr float SQ = 4.f, SK = 4.f, SV = 4.f, SP = 16384.f;
-    __shared__ __attribute__((aligned(16))) half_t smem_f[2 * 32 * KLD + 2 * DT * 32 * VLD];
+    __shared__ __attribute__((aligned(16))) half_t smem_f[2 * KT * KLD + 2 * DT * 32 * VLD];
     half_t* Kh = smem_f;
-    half_t* Kl = Kh + 32 * KLD;
-    half_t* Vh = Kl + 32 * KLD;                  // [DT*32][VLD]
+    half_t* Kl = Kh + KT * KLD;
+    half_t* Vh = Kl + KT * KLD;                  // [DT*32][VLD]
     half_t* Vl = Vh + DT * 32 * VLD;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sc2 = p.scale * 1.44269504088896341f / (SQ * SK);      // scores in log2 units
-    constexpr int KCH = 32 * (D / 4);            // 16-byte chunks of one K (or V) tile
+    constexpr int KCH = KT * (D / 4);            // 16-byte chunks of one K (or V) tile
     constexpr int NLD = (KCH + 255) / 256;
     const rsrc_t rK = make_rsrc(Kp, (unsigned)(((long long)(p.L - 1) * p.ldk + D) * 4));
     const rsrc_t rV = make_rsrc(Vp, (unsigned)(((long long)(p.L - 1) * p.ldv + D) * 4));
@@ -716,24 +719,27 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
             }
         }
     };
-    const int nt = (p.L + 31) / 32;
+    const int nt = (p.L + KT - 1) / KT;
     load_kv(0);
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                          // everybody is done with the previous tile (first pass: the zero fill)
         store_kv();
         __syncthreads();
-        load_kv((t + 1) * 32);                    // past L: zeros, never stored
-        // ---- S^T tile: 32 keys x 32 queries
-        f32x16 sacc;
+        load_kv((t + 1) * KT);                    // past L: zeros, never stored
+        // ---- S^T tiles: KS x (32 keys x 32 queries)
+        f32x16 sacc[KS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        for (int u = 0; u < KS; ++u) {
 #pragma unroll
-        for (int g = 0; g < DG; ++g) {
-            const half8_t kh = *(const half8_t*)(Kh + li * KLD + g * 16 + 8 * lh);
-            const half8_t kl = *(const half8_t*)(Kl + li * KLD + g * 16 + 8 * lh);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc, 0, 0, 0);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < DG; ++g) {
+                const half8_t kh = *(const half8_t*)(Kh + (u * 32 + li) * KLD + g * 16 + 8 * lh);
+                const half8_t kl = *(const half8_t*)(Kl + (u * 32 + li) * KLD + g * 16 + 8 * lh);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g], sacc[u], 0, 0, 0);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc[u], 0, 0, 0);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc[u], 0, 0, 0);
+            }
         }
         // ---- online softmax over the key rows of this tile (register r <-> key (r&3) + 8 (r>>2) + 4 lh).  The loop is bound by
         // vector issue, not by the 21 MFMAs (289 vector instructions per tile before the three trims below, ~150 after): keys
@@ -741,23 +747,28 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
         // denormal-range rescue costs five instructions per call and guards results that round to 0 here anyway), and the
         // accumulators are rescaled only when some lane's running maximum moved (alpha == 1 exactly otherwise)
         float mx = -INFINITY;
-        if ((t + 1) * 32 > p.L) {                 // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                sacc[r] = key < p.L ? sacc[r] * sc2 : -INFINITY;
-                mx = fmaxf(mx, sacc[r]);
+        for (int u = 0; u < KS; ++u) {
+            if (t * KT + (u + 1) * 32 > p.L) {    // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KT + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    sacc[u][r] = key < p.L ? sacc[u][r] * sc2 : -INFINITY;
+                    mx = fmaxf(mx, sacc[u][r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sacc[u][r] *= sc2; mx = fmaxf(mx, sacc[u][r]); }
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] *= sc2; mx = fmaxf(mx, sacc[r]); }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
         float ls = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new); ls += sacc[r]; }
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(sacc[u][r] - m_new); ls += sacc[u][r]; }
         l_run = l_run * alpha + ls;
         if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
 #pragma unroll
@@ -766,30 +777,33 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
                 for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
         }
         m_run = m_new;
-        // ---- O^T += V^T P^T, two 16-key steps; P split with scale 2^14
+        // ---- O^T += V^T P^T, two 16-key steps per sub-tile; P split with scale 2^14
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            half8_t ph, pl;
+        for (int u = 0; u < KS; ++u) {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const f32x4 v = {sacc[8 * s + 4 * c2], sacc[8 * s + 4 * c2 + 1], sacc[8 * s + 4 * c2 + 2], sacc[8 * s + 4 * c2 + 3]};
-                half4 hh, ll;
-                split4(v, SP, hh, ll);
+            for (int s = 0; s < 2; ++s) {
+                half8_t ph, pl;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
-            }
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const f32x4 v = {sacc[u][8 * s + 4 * c2], sacc[u][8 * s + 4 * c2 + 1], sacc[u][8 * s + 4 * c2 + 2], sacc[u][8 * s + 4 * c2 + 3]};
+                    half4 hh, ll;
+                    split4(v, SP, hh, ll);
 #pragma unroll
-            for (int tt = 0; tt < DT; ++tt) {
-                const half_t* vr = Vh + (tt * 32 + li) * VLD + 16 * s + 4 * lh;
-                const half_t* vq = Vl + (tt * 32 + li) * VLD + 16 * s + 4 * lh;
-                half8_t vh, vl;
-                const half4 a0 = *(const half4*)vr, a1 = *(const half4*)(vr + 8);
-                const half4 b0 = *(const half4*)vq, b1 = *(const half4*)(vq + 8);
+                    for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
-                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[tt], 0, 0, 0);
-                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[tt], 0, 0, 0);
-                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[tt], 0, 0, 0);
+                for (int tt = 0; tt < DT; ++tt) {
+                    const half_t* vr = Vh + (tt * 32 + li) * VLD + u * 32 + 16 * s + 4 * lh;
+                    const half_t* vq = Vl + (tt * 32 + li) * VLD + u * 32 + 16 * s + 4 * lh;
+                    half8_t vh, vl;
+                    const half4 a0 = *(const half4*)vr, a1 = *(const half4*)(vr + 8);
+                    const half4 b0 = *(const half4*)vq, b1 = *(const half4*)(vq + 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[tt], 0, 0, 0);
+                }
             }
         }
     }
@@ -815,12 +829,16 @@ int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st) {
     const unsigned long long lim = 0xFFFFFFF0ull;
     if (((unsigned long long)(p.L - 1) * p.ldk + p.d) * 4 >= lim || ((unsigned long long)(p.L - 1) * p.ldv + p.d) * 4 >= lim) return IEF_ESHAPE;
     dim3 grid((p.N + 127) / 128, p.B * p.heads);
+    // 64 keys per barrier pair where there are that many (self-attention); the 77-key cross maps keep 32 (3 tiles, not 2 x 64)
+    const bool ks2 = g_flash_ks2 && p.L >= 128;
+#define FLASH_GO(D_) do { if (ks2) hipLaunchKernelGGL((attn_flash_x3_kernel<D_, 2>), grid, dim3(256), 0, st, p); \
+                          else hipLaunchKernelGGL((attn_flash_x3_kernel<D_, 1>), grid, dim3(256), 0, st, p); } while (0)
     switch (p.d) {
-        case 32: hipLaunchKernelGGL(attn_flash_x3_kernel<32>, grid, dim3(256), 0, st, p); break;
-        case 40: hipLaunchKernelGGL(attn_flash_x3_kernel<40>, grid, dim3(256), 0, st, p); break;
-        case 64: hipLaunchKernelGGL(attn_flash_x3_kernel<64>, grid, dim3(256), 0, st, p); break;
-        case 80: hipLaunchKernelGGL(attn_flash_x3_kernel<80>, grid, dim3(256), 0, st, p); break;
-        case 160: hipLaunchKernelGGL(attn_flash_x3_kernel<160>, grid, dim3(256), 0, st, p); break;
+        case 32: FLASH_GO(32); break;
+        case 40: FLASH_GO(40); break;
+        case 64: FLASH_GO(64); break;
+        case 80: FLASH_GO(80); break;
+        case 160: FLASH_GO(160); break;
         default: return IEF_ESHAPE;
     }
     IEF_LAUNCH_CHECK();
