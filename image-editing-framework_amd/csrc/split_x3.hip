@@ -28,7 +28,7 @@
 //       counts are multiples of 32 (a K tile is ONE tap of ONE source: per row the tile's offset is a precomputed pixel
 //       offset + a uniform term, its validity one bit of a 9-bit tap mask), 3 the same with the nearest-2x upsample folded
 //       in, 4 any other convolution (per-lane tap decode).
-//   attn_flash_x3_kernel<D>             fused attention without materialised maps (below)
+//   attn_flash_x3_kernel<D, KS>         fused attention without materialised maps (below)
 #include "ief_common.h"
 #include "ief_params.h"
 
