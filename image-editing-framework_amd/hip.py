@@ -206,7 +206,7 @@ def load():
                                            c_float, c_int, c_void_p]
     lib.ief_gemm_x3_bm.argtypes = [c_int, c_int]
     lib.ief_gemm_x3_bn_k.argtypes = [c_int, c_int, c_int]
-    if os.environ.get("IEF_X3_WIDE"):          # 0: keep every launch on the 128 x 80 tile (A/B runs)
+    if os.environ.get("IEF_X3_WIDE"):          # A/B runs: bit 0 clear = keep every launch on the 128 x 80 tile; bit 1 set = 32-key flash tiles
         lib.ief_gemm_x3_set_variant.argtypes = [c_int]
         lib.ief_gemm_x3_set_variant(int(os.environ["IEF_X3_WIDE"]))
     lib.ief_x3_split_weights.argtypes = [c_void_p, c_void_p, c_longlong, c_float, c_void_p]

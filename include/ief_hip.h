@@ -283,7 +283,7 @@ int ief_gemm_x3_bm(int M, int N);
 /* the width the launch (conv != 0: 3x3 convolution) actually takes: 160 (8 waves, one workgroup per CU) where that tile is
    the faster one, else ief_gemm_x3_bn(N); the host's split-K policy counts tiles with it */
 int ief_gemm_x3_bn_k(int conv, int N, int K);
-void ief_gemm_x3_set_variant(int wide);   /* 0: never the 160-wide tile (A/B measurements) */
+void ief_gemm_x3_set_variant(int bits);   /* A/B measurements: bit 0 clear = never the 160-wide tile; bit 1 set = 32-key tiles in the fused attention */
 int ief_gemm_f32_bn(int N);   /* output-tile width (64 or 128) the library uses for N columns; the M tile is 128 rows */
 /* fused fp32 attention (maps never written): out[b] = softmax(scale q[q_src[b]] k[k_src[b]]^T) v[v_src[b]]; q [B][N][heads*d]
  * (row stride ldq, batch stride sQb; likewise k, v over L keys and out); d in {32, 40, 64, 80, 160}; *_src NULL = identity */
