@@ -582,3 +582,22 @@ def test_reference_masactrl_registration_walks_our_tree(cpu_unet):
         for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
             sys.modules.pop(k)
         sys.modules.update(saved)
+
+
+def test_x3_tile_geometry_rule_is_host_side_and_callable_without_a_gpu():
+    """`ief_gemm_x3_bn_k` (what the split-K policy of the split-operand mode counts tiles with) is plain host code: every 3x3
+    convolution whose width is a multiple of 160 takes the 128 x 160 tile, linears only where N <= 1280 or K >= 1280, everything
+    else the 80- or 64-wide tile; `ief_gemm_x3_set_variant(0)` switches the wide tile off"""
+    import ctypes
+    lib = hip.load()
+    lib.ief_gemm_x3_set_variant.argtypes = [ctypes.c_int]
+    f = lib.ief_gemm_x3_bn_k
+    assert f(1, 320, 2880) == 160 and f(1, 1280, 11520) == 160 and f(1, 4, 2880) == 64
+    assert f(0, 320, 320) == 160 and f(0, 1280, 5120) == 160 and f(0, 10240, 1280) == 160
+    assert f(0, 2560, 320) == 80 and f(0, 5120, 640) == 80 and f(0, 77, 40) == 64 and f(0, 240, 64) == 80
+    lib.ief_gemm_x3_set_variant(0)
+    try:
+        assert f(1, 320, 2880) == 80 and f(0, 320, 320) == 80
+    finally:
+        lib.ief_gemm_x3_set_variant(1)
+    assert lib.ief_gemm_x3_bm(16384, 320) == 128
