@@ -98,6 +98,11 @@ class ControlPlan:
             self.mt32 = mt.to(device=dev, dtype=torch.float32).contiguous()      # the reference-precision kernels' copy
             self.coef_table = coef_table.to(device=dev, dtype=torch.float32).contiguous()
             self.coef_cur = torch.zeros(slots, 2, XL, dtype=torch.float32, device=dev)
+            # the edited maps P' = c1 T + c2 P reach max (|c1| + |c2|) (AttentionReweight: c1 = alpha * equalizer): the
+            # split-operand kernels size the hi / lo split of P' from it (hip.map_split_scale); the scale is a launch
+            # argument, hence part of the signature a pooled step graph is matched on
+            ct = coef_table.detach().float()
+            self.coef_bound = float((ct[:, :, 0].abs() + ct[:, :, 1].abs()).max()) if ct.numel() else 1.0
             off = 0 if cond_only else Bp          # first conditional row (= the source prompt's) of this UNet batch
             es = torch.full((B,), -1, dtype=torch.int32)
             sl = torch.zeros(B, dtype=torch.int32)
@@ -157,7 +162,8 @@ class ControlPlan:
         """everything about this plan that is BAKED into a captured step graph (which kernels run, on which modules,
         with tables of which shape); two plans with equal signatures differ only in table contents"""
         if self.kind == "p2p":
-            return ("p2p", self.num_prompts, self.num_steps, self.self_max_tokens, tuple(self.mt.shape), self.cond_only)
+            return ("p2p", self.num_prompts, self.num_steps, self.self_max_tokens, tuple(self.mt.shape), self.cond_only,
+                    hip.map_split_scale(self.coef_bound))
         if self.kind == "masactrl":
             return ("masactrl", tuple(sorted(self.masa_layers)), (max(self.masa_steps) + 2) if self.masa_steps else 1)
         if self.kind == "pnp":
@@ -176,6 +182,7 @@ class ControlPlan:
             self.mt.copy_(other.mt)
             self.mt32.copy_(other.mt32)
             self.coef_table.copy_(other.coef_table)
+            self.coef_bound = other.coef_bound       # same split scale (the signatures matched), possibly another bound below it
             self.self_table.copy_(other.self_table)
             self.self_window = other.self_window
         elif self.kind == "masactrl":
@@ -274,5 +281,8 @@ class ControlPlan:
     def cross_edit(self, B: int, attn):
         if self.kind == "p2p" and self.applies(B):
             mt = self.mt32 if attn.to_q.weight.dtype == torch.float32 else self.mt
-            return dict(edit_src=self.edit_src, edit_slot=self.edit_slot, mt=mt, coef=self.coef_cur)
+            args = dict(edit_src=self.edit_src, edit_slot=self.edit_slot, mt=mt, coef=self.coef_cur)
+            if attn.to_q.weight.dtype == torch.float32:
+                args["coef_bound"] = self.coef_bound
+            return args
         return {}

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
     constexpr int KLD = DG * 16 + 8;             // halves per K row
     constexpr int VLD = 100;                     // halves per V^T row (all <= 96 keys + 4)
     constexpr int MLD = 100;                     // halves per table row (96 source tokens + 4)
-    constexpr float SQ = 4.f, SK = 4.f, SV = 4.f, SP = 16384.f, SM = 256.f;
+    constexpr float SQ = 1.f, SK = 1.f, SV = 1.f, SP = 16384.f, SM = 256.f;   // activations: scale 1; source maps (<= 1): 2^14; table: 2^8
+    const float SPE = p.p_scale > 0.f ? p.p_scale : SP;      // the EDITED maps P' = c1 T + c2 P can exceed 1 (AttentionReweight): host-chosen scale
     // ONE region, re-used phase by phase (K of the source row | the table | K of this row | V^T), each image complete (all
     // <= 96 keys) so that a phase costs two barriers, not two per 32-key tile.  Whatever a phase leaves behind is finite fp16
     // data, and the region is zeroed once at the start: padding columns of K (d >= D) multiply the zero padding of q.
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
             for (int r = 0; r < 16; ++r) P[t][r] *= inv;
     };
     // registers 8 s .. 8 s + 7 of a map tile -> the hi / lo fp16 B operand of one 16-deep k step
-    auto split_p = [&](const f32x16& P, int s, half8_t& ph, half8_t& pl) {
+    auto split_p = [&](const f32x16& P, int s, half8_t& ph, half8_t& pl, float sp) {
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const f32x4 v = {P[8 * s + 4 * c2], P[8 * s + 4 * c2 + 1], P[8 * s + 4 * c2 + 2], P[8 * s + 4 * c2 + 3]};
             half4 hh, ll;
-            split4(v, SP, hh, ll);
+            split4(v, sp, hh, ll);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
         }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
         __syncthreads();
         half8_t ph[6], pl[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) split_p(Ps[s >> 1], s & 1, ph[s], pl[s]);
+        for (int s = 0; s < 6; ++s) split_p(Ps[s >> 1], s & 1, ph[s], pl[s], SP);
 #pragma unroll
         for (int wt = 0; wt < 3; ++wt) {
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 half8_t ph, pl;
-                split_p(P[t], s, ph, pl);
+                split_p(P[t], s, ph, pl, SPE);
 #pragma unroll
                 for (int tt = 0; tt < DT; ++tt) {
                     const half_t* vr = Vh + (tt * 32 + li) * VLD + t * 32 + 16 * s + 4 * lh;
@@ -283,8 +284,9 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
             }
         }
     }
-    const float inv = 1.0f / (SV * SP);
-    float* O = p.Out + (long long)b * p.sOb + (long long)h * D;
+    const float inv = 1.0f / (SV * SPE);
+    float* O = p.Out ? p.Out + (long long)b * p.sOb + (long long)h * D : nullptr;
+    half_t* OP = p.OutP ? p.OutP + (long long)b * p.sOPb + (long long)h * D : nullptr;
     if (qi < p.N) {
 #pragma unroll
         for (int tt = 0; tt < DT; ++tt)
@@ -293,7 +295,14 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_cross_p2p_x3_kerne
                 const int d = tt * 32 + 8 * g + 4 * lh;       // registers 4g .. 4g+3 <-> d .. d+3
                 if (d < D) {
                     const f32x4 v = {o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv};
-                    *(f32x4*)(O + (long long)qi * p.ldo + d) = v;
+                    if (O) *(f32x4*)(O + (long long)qi * p.ldo + d) = v;
+                    if (OP) {
+                        half4 hh, ll;
+                        split4(v, 1.0f, hh, ll);
+                        half_t* op = OP + (long long)qi * p.ldp + d;
+                        *(half4*)op = hh;
+                        *(half4*)(op + p.planeO) = ll;
+                    }
                 }
             }
     }
@@ -306,11 +315,13 @@ extern "C" int ief_attn_cross_p2p_f32(const IefAttnF32Params* pp, const int* edi
                                       const float* coef, void* stream) {
     if (!pp) return IEF_EINVAL;
     const IefAttnF32Params& p = *pp;
-    if (!p.Q || !p.K || !p.V || !p.Out || p.q_src || p.k_src || p.v_src) return IEF_EINVAL;
+    if (!p.Q || !p.K || !p.V || (!p.Out && !p.OutP) || p.q_src || p.k_src || p.v_src) return IEF_EINVAL;
+    if (p.OutP && ((p.ldp & 3) || (p.sOPb & 3) || (p.planeO & 3) || ((uintptr_t)p.OutP & 7))) return IEF_EALIGN;
+    if (p.p_scale != 0.f && !(p.p_scale >= 1.f && p.p_scale <= 16384.f)) return IEF_EINVAL;
     if (edit_src && (!edit_slot || !MT || !coef)) return IEF_EINVAL;
     if (p.B <= 0 || p.heads <= 0 || p.N <= 0 || p.L <= 0 || p.L > 96) return IEF_ESHAPE;
     if ((p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.ldo & 3) || (p.sQb & 3) || (p.sKb & 3) || (p.sVb & 3) || (p.sOb & 3) ||
-        (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.Out | (uintptr_t)(MT ? MT : p.Q)) & 15)) return IEF_EALIGN;
+        (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)(p.Out ? p.Out : p.Q) | (uintptr_t)(MT ? MT : p.Q)) & 15)) return IEF_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((p.N + 127) / 128, p.B * p.heads);
     switch (p.d) {

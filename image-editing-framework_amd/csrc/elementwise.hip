@@ -286,6 +286,7 @@ extern "C" int ief_struct_size(int which) {
         case 4: return (int)sizeof(IefMapLossParams);
         case 5: return (int)sizeof(IefGemmF32Params);
         case 6: return (int)sizeof(IefAttnF32Params);
+        case 7: return (int)sizeof(IefGemmX3pParams);
         default: return -1;
     }
 }

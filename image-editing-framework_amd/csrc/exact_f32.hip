@@ -22,6 +22,7 @@
 // (lane half h takes k = 4h..4h+3), which lets a lane fetch its four operands of four MFMAs with one 16-byte LDS read.
 #include "ief_common.h"
 #include "ief_params.h"
+#include "x3_common.h"
 
 #define XBM 128
 #define XBK 32
@@ -457,8 +458,10 @@ __global__ __launch_bounds__(256) void attn_flash_f32_kernel(const IefAttnF32Par
 int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st);      // split_x3.hip
 
 extern "C" int ief_attn_flash_f32(const IefAttnF32Params* pp, void* stream) {
-    if (!pp || !pp->Q || !pp->K || !pp->V || !pp->Out) return IEF_EINVAL;
+    if (!pp || !pp->Q || !pp->K || !pp->V || (!pp->Out && !pp->OutP)) return IEF_EINVAL;
     const IefAttnF32Params p = *pp;
+    if (p.OutP && !p.x3) return IEF_EINVAL;              // operand planes are written by the split-operand kernel only
+    if (!p.x3 && (!p.Out || (p.ldo & 3) || (p.sOb & 3))) return IEF_EINVAL;
     if (p.B <= 0 || p.heads <= 0 || p.N <= 0 || p.L <= 0) return IEF_ESHAPE;
     if ((p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.sQb & 3) || (p.sKb & 3) || (p.sVb & 3)) return IEF_EALIGN;
     dim3 grid((p.N + 127) / 128, p.B * p.heads);
@@ -840,9 +843,12 @@ __global__ __launch_bounds__(256) void gn3_finalize_kernel(const float* __restri
     }
 }
 
+// outp != nullptr: the result leaves as the two fp16 planes of the split-operand mode (hi = fp16(y), lo = fp16(y - hi); the lo
+// plane `plane` elements after hi) -- the GroupNorm is the PRODUCER of its consumer GEMM's / convolution's operand planes
+// (csrc/gemm_x3p.hip); out may then be null
 __global__ __launch_bounds__(256) void gn3_apply_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2, int HW,
                                                         int P, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                        float* __restrict__ out, int silu) {
+                                                        float* __restrict__ out, int silu, half_t* __restrict__ outp, long long plane) {
     const int C = C1 + C2, CQ = C >> 2;
     const int CQB = CQ < 256 ? CQ : 256, PY = 256 / CQB;
     const int tid = threadIdx.x, cq = tid % CQB, py = tid / CQB;
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(256) void gn3_apply_kernel(const float* __restrict_
         if (q >= CQ) continue;
         int cs = 0;
         const float* src = gn3_src(x, x2, C1, C2, b, HW, q * 4, &cs) + (long long)p0 * cs;
-        float* dst = out + ((long long)b * HW + p0) * C + q * 4;
+        const long long doff = ((long long)b * HW + p0) * C + q * 4;
         f32x4 v[GN3_U];
 #pragma unroll
         for (int u = 0; u < GN3_U; ++u) {
@@ -871,7 +877,14 @@ __global__ __launch_bounds__(256) void gn3_apply_kernel(const float* __restrict_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) y[j] = silu_x(y[j]);
                 }
-                *(f32x4*)(dst + (long long)pp * C) = y;
+                if (out) *(f32x4*)(out + doff + (long long)pp * C) = y;
+                if (outp) {
+                    half4 h, l;
+                    split4(y, 1.0f, h, l);
+                    half_t* o = outp + doff + (long long)pp * C;
+                    *(half4*)o = h;
+                    *(half4*)(o + plane) = l;
+                }
             }
         }
     }
@@ -898,7 +911,33 @@ extern "C" int ief_groupnorm_silu_f32_ws(const float* x, const float* x2, int C1
     hipLaunchKernelGGL(gn3_finalize_kernel, dim3(B * groups), dim3(256), 0, st, pmean, pm2, C, HW, P, nch, groups, eps, gamma, beta,
                        scale, shift, (float*)nullptr);
     IEF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn3_apply_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, scale, shift, out, silu);
+    hipLaunchKernelGGL(gn3_apply_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, scale, shift, out, silu, (half_t*)nullptr, 0ll);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+// the same three launches with the result written as operand planes (and, optionally, as fp32 too)
+extern "C" int ief_groupnorm_silu_x3p_ws(const float* x, const float* x2, int C1, int C2, float* out, ief_half* outp, long long plane,
+                                         const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu,
+                                         float* ws, long long ws_floats, void* stream) {
+    if (!x || !outp || !gamma || !beta || !ws || (C2 > 0 && !x2)) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups || (C1 & 3) || (C2 & 3) || (plane & 3)) return IEF_ESHAPE;
+    const int C = C1 + C2;
+    if (C / groups > 256) return IEF_ESHAPE;
+    if (ws_floats < ief_groupnorm_f32_ws_floats(B, HW, C)) return IEF_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)ws | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)(out ? out : x)) & 15) || ((uintptr_t)outp & 7)) return IEF_EALIGN;
+    int nch, P;
+    gn3_chunks(HW, C, &nch, &P);
+    float* pmean = ws;
+    float* pm2 = pmean + (long long)B * nch * C;
+    float* scale = pm2 + (long long)B * nch * C;
+    float* shift = scale + (long long)B * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn3_stats_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, pmean, pm2);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_finalize_kernel, dim3(B * groups), dim3(256), 0, st, pmean, pm2, C, HW, P, nch, groups, eps, gamma, beta,
+                       scale, shift, (float*)nullptr);
+    IEF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn3_apply_kernel, dim3(nch, B), dim3(256), 0, st, x, x2, C1, C2, HW, P, scale, shift, out, silu, (half_t*)outp, plane);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
@@ -1109,7 +1148,8 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                long long rows, int C, float eps) {
+                                                                long long rows, int C, float eps, half_t* __restrict__ outp = nullptr,
+                                                                long long plane = 0) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* r = x + row * C;
@@ -1136,8 +1176,32 @@ __global__ __launch_bounds__(256) void layernorm_f32_vec_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int qd = lane + 64 * j;
-        if (qd < CQ) *(f32x4*)(o + qd * 4) = (v[j] - mean) * rstd * *(const f32x4*)(gamma + qd * 4) + *(const f32x4*)(beta + qd * 4);
+        if (qd < CQ) {
+            const f32x4 y = (v[j] - mean) * rstd * *(const f32x4*)(gamma + qd * 4) + *(const f32x4*)(beta + qd * 4);
+            if (out) *(f32x4*)(o + qd * 4) = y;
+            if (outp) {          // operand planes of the split-operand mode (the consumer GEMM stages them by LDS-DMA)
+                half4 h, l;
+                split4(y, 1.0f, h, l);
+                half_t* op = outp + row * C + qd * 4;
+                *(half4*)op = h;
+                *(half4*)(op + plane) = l;
+            }
+        }
     }
+}
+extern "C" int ief_layernorm_x3p(const float* x, ief_half* outp, long long plane, const float* gamma, const float* beta, long long rows,
+                                 int C, float eps, void* stream) {
+    if (!x || !outp || !gamma || !beta) return IEF_EINVAL;
+    if (rows <= 0 || C <= 0 || (C & 3) || C > 2560 || (plane & 3)) return IEF_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) || ((uintptr_t)outp & 7)) return IEF_EALIGN;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    float* none = nullptr;
+    if (C <= 512) hipLaunchKernelGGL(layernorm_f32_vec_kernel<2>, grid, dim3(256), 0, st, x, none, gamma, beta, rows, C, eps, (half_t*)outp, plane);
+    else if (C <= 1280) hipLaunchKernelGGL(layernorm_f32_vec_kernel<5>, grid, dim3(256), 0, st, x, none, gamma, beta, rows, C, eps, (half_t*)outp, plane);
+    else hipLaunchKernelGGL(layernorm_f32_vec_kernel<10>, grid, dim3(256), 0, st, x, none, gamma, beta, rows, C, eps, (half_t*)outp, plane);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
 }
 extern "C" int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C,
                                  float eps, void* stream) {

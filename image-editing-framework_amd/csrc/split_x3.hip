@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     constexpr int KLD = DG * 16 + 8;             // halves per K row (bytes = 16 mod 32: conflict-free b128 fragments)
     constexpr int KT = 32 * KS;                  // keys per iteration
     constexpr int VLD = KT + 4;                  // halves per V^T row
-    constexpr float SQ = 4.f, SK = 4.f, SV = 4.f, SP = 16384.f;
+    constexpr float SQ = 1.f, SK = 1.f, SV = 1.f, SP = 16384.f;     // activations: scale 1 (the fp16 range itself); maps <= 1: 2^14
     __shared__ __attribute__((aligned(16))) half_t smem_f[2 * KT * KLD + 2 * DT * 32 * VLD];
     half_t* Kh = smem_f;
     half_t* Kl = Kh + KT * KLD;
@@ -658,7 +658,8 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     const float* Q = p.Q + (long long)bq * p.sQb + (long long)h * D;
     const float* Kp = p.K + (long long)bk * p.sKb + (long long)h * D;
     const float* Vp = p.V + (long long)bv * p.sVb + (long long)h * D;
-    float* O = p.Out + (long long)b * p.sOb + (long long)h * D;
+    float* O = p.Out ? p.Out + (long long)b * p.sOb + (long long)h * D : nullptr;
+    half_t* OP = p.OutP ? p.OutP + (long long)b * p.sOPb + (long long)h * D : nullptr;
     const int q0 = qb * 128 + wid * 32;
     const int qi = q0 + li;
     // zero the LDS once: padding columns of K (d >= D) and padding rows of V^T stay zero (staging never writes them)
@@ -817,7 +818,14 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
                 const int d = tt * 32 + 8 * g + 4 * lh;       // registers 4g .. 4g+3 <-> d .. d+3
                 if (d < D) {
                     const f32x4 v = {o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv};
-                    *(f32x4*)(O + (long long)qi * p.ldo + d) = v;
+                    if (O) *(f32x4*)(O + (long long)qi * p.ldo + d) = v;
+                    if (OP) {                 // operand planes for to_out's GEMM (csrc/gemm_x3p.hip)
+                        half4 hh, ll;
+                        split4(v, 1.0f, hh, ll);
+                        half_t* op = OP + (long long)qi * p.ldp + d;
+                        *(half4*)op = hh;
+                        *(half4*)(op + p.planeO) = ll;
+                    }
                 }
             }
     }
@@ -825,7 +833,8 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
 
 // called by ief_attn_flash_f32 (exact_f32.hip) after its argument checks when p.x3 != 0
 int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st) {
-    if ((p.ldo & 3) || (p.sOb & 3) || ((uintptr_t)p.Out & 15)) return IEF_EALIGN;
+    if (p.Out && ((p.ldo & 3) || (p.sOb & 3) || ((uintptr_t)p.Out & 15))) return IEF_EALIGN;
+    if (p.OutP && ((p.ldp & 3) || (p.sOPb & 3) || (p.planeO & 3) || ((uintptr_t)p.OutP & 7))) return IEF_EALIGN;
     const unsigned long long lim = 0xFFFFFFF0ull;
     if (((unsigned long long)(p.L - 1) * p.ldk + p.d) * 4 >= lim || ((unsigned long long)(p.L - 1) * p.ldv + p.d) * 4 >= lim) return IEF_ESHAPE;
     dim3 grid((p.N + 127) / 128, p.B * p.heads);

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_longlo
 import torch
 
 # IEF_HIP_LIB / IEF_PLAN_FILE: A/B two builds of the library (and their tuned tables) on one GPU box
-ABI_VERSION = 3   # include/ief_hip.h IEF_ABI_VERSION
+ABI_VERSION = 4   # include/ief_hip.h IEF_ABI_VERSION
 _LIB_PATH = os.environ.get("IEF_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libief_hip.so")
 _lib = None
 
@@ -107,6 +107,24 @@ class IefAttnF32Params(Structure):
         ("scale", c_float),
         ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p),
         ("x3", c_int),
+        ("OutP", c_void_p), ("planeO", c_longlong), ("sOPb", c_longlong), ("ldp", c_int), ("p_scale", c_float),
+    ]
+
+
+class IefGemmX3pParams(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("planeA", c_longlong), ("A2", c_void_p), ("planeA2", c_longlong),
+        ("E1", c_void_p), ("planeE1", c_longlong), ("E2", c_void_p), ("planeE2", c_longlong),
+        ("W", c_void_p), ("planeW", c_longlong),
+        ("Out", c_void_p), ("OutP", c_void_p), ("planeO", c_longlong),
+        ("bias", c_void_p), ("rowvec", c_void_p), ("residual", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_int), ("ldw", c_int), ("ldo", c_int), ("ldp", c_int), ("ldr", c_int),
+        ("conv", c_int), ("H", c_int), ("Wd", c_int), ("C1", c_int), ("C2", c_int), ("Ho", c_int), ("Wo", c_int),
+        ("stride", c_int), ("ups", c_int), ("batch_images", c_int), ("pad_hi_only", c_int), ("CE1", c_int), ("CE2", c_int),
+        ("rows_per_batch", c_int), ("out_scale", c_float), ("inv_scale", c_float),
+        ("tile", c_int), ("splits", c_int), ("ws", c_void_p), ("geglu", c_int), ("zeros", c_void_p),
+        ("rstat_out", c_void_p), ("cstat_out", c_void_p),
     ]
 
 
@@ -129,6 +147,8 @@ EXPORTS = [
     "ief_groupnorm_bwd_f32", "ief_layernorm_bwd_f32", "ief_geglu_il_bwd_f32", "ief_zero_insert2x_f32", "ief_pool2x2_sum_f32",
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
     "ief_map_loss_rows_f32", "ief_nti_adam_f32g",
+    # ABI 4: split-operand contractions on pre-split planes (csrc/gemm_x3p.hip)
+    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p",
 ]
 
 
@@ -238,11 +258,18 @@ def load():
     lib.ief_conv_in_f32act.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p]
     lib.ief_conv_out_f32act.argtypes = [c_void_p] * 4 + [c_int] * 5 + [c_void_p]
     lib.ief_image_u8.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.ief_gemm_x3p.argtypes = [POINTER(IefGemmX3pParams), c_void_p]
+    lib.ief_gemm_x3p_tile_bm.argtypes = [c_int]
+    lib.ief_gemm_x3p_tile_bn.argtypes = [c_int]
+    lib.ief_x3_split_act.argtypes = [c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_int, c_float, c_void_p]
+    lib.ief_groupnorm_silu_x3p_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
+                                              c_int, c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]
+    lib.ief_layernorm_x3p.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p]
     if lib.ief_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")
     lib.ief_struct_size.argtypes = [c_int]
     for which, st in ((0, IefGemmParams), (1, IefAttnParams), (2, IefCrossParams), (3, IefAttnBwdParams), (4, IefMapLossParams),
-                      (5, IefGemmF32Params), (6, IefAttnF32Params)):
+                      (5, IefGemmF32Params), (6, IefAttnF32Params), (7, IefGemmX3pParams)):
         if lib.ief_struct_size(which) != ctypes.sizeof(st):
             raise HipExtensionMissing(f"{st.__name__}: ctypes layout ({ctypes.sizeof(st)} B) != library "
                                       f"({lib.ief_struct_size(which)} B); rebuild libief_hip.so")
@@ -624,7 +651,11 @@ def _dev16(t, name):
 # A model sets it for the duration of its own calls (`with hip.f32_contraction(mode)`): one Python thread drives the
 # library, and a captured graph keeps the kernels that were chosen while it was recorded.
 _F32_CONTRACT = "f32"
-X3_SCALE_ACT, X3_SCALE_W, X3_SCALE_PROB = 4.0, 256.0, 16384.0      # powers of two: fp16(s x) keeps hi and lo normal
+# powers of two.  Activations: 1 — the fp16 range itself (|x| < 65504, as on the fp16-storage path; a larger scale would narrow it:
+# 4 capped activations at 16376) and the scale the pre-split operand planes carry (planes.py); gfx950's MFMA keeps fp16 subnormal
+# inputs, so the lo half of a small element only loses ABSOLUTE resolution (2^-25), far below the 2^-22 relative error of the
+# large elements that dominate a dot product.  Weights 2^8 (|w| < 255), softmax maps 2^14 (<= 1).
+X3_SCALE_ACT, X3_SCALE_W, X3_SCALE_PROB = 1.0, 256.0, 16384.0
 
 
 class f32_contraction:
@@ -1317,27 +1348,36 @@ GN3_F32 = os.environ.get("IEF_GN3_F32", "1") == "1"          # 0: the one-launch
 FLASH_F32 = os.environ.get("IEF_FLASH_F32", "1") == "1"      # 0: always materialise the fp32 maps (A/B runs)
 
 
-def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None):
-    """fused fp32 attention (`ief_attn_flash_f32`): no map is written; None when the head dim has no instantiation"""
+def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, out_planes=False):
+    """fused fp32 attention (`ief_attn_flash_f32`): no map is written; None when the head dim has no instantiation.
+    out_planes (split-operand mode only): the result leaves as operand planes for to_out's GEMM (`planes.Planes`)"""
     lib = load()
     B, N, C = q.shape
     L, d = k.shape[1], C // heads
     if not FLASH_F32 or d not in (32, 40, 64, 80, 160):
         return None
-    if out is None:
-        out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
     p = IefAttnF32Params()
-    p.Q, p.K, p.V, p.Out = _act32(q, "q").data_ptr(), _act32(k, "k").data_ptr(), _act32(v, "v").data_ptr(), _act32(out, "out").data_ptr()
+    p.Q, p.K, p.V = _act32(q, "q").data_ptr(), _act32(k, "k").data_ptr(), _act32(v, "v").data_ptr()
+    op = None
+    if out_planes:
+        if _F32_CONTRACT != "x3":
+            raise ValueError("attn_flash: operand planes exist in the split-operand mode only")
+        from . import planes as _pl
+        op, _ = _pl.attn_out_args(p, B, N, C, q.device)
+    else:
+        if out is None:
+            out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+        p.Out = _act32(out, "out").data_ptr()
+        p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
     p.B, p.heads, p.N, p.L, p.d, p.scale = B, heads, N, L, d, scale
     p.sQb, _, p.ldq = _batched32(p, q, heads, d, "q")
     p.sKb, _, p.ldk = _batched32(p, k, heads, d, "k")
     p.sVb, _, p.ldv = _batched32(p, v, heads, d, "v")
-    p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
     p.x3 = 1 if _F32_CONTRACT == "x3" else 0
     with _Timed(f"attn_flash_{'x3' if p.x3 else 'f32'}_kernel<{d}>", 4.0 * B * heads * N * L * d, 4.0 * B * heads * d * (2 * N + 2 * L)):
         _check(lib.ief_attn_flash_f32(byref(p), _stream()), "ief_attn_flash_f32")
-    return out
+    return op if out_planes else out
 
 
 def _attn_scores_f32(q, k, heads, scale, q_src=None, k_src=None, out=None, softmax=True):
@@ -1382,8 +1422,9 @@ def attn_scores(q, k, heads, scale):
     return (to_f16(sim), to_f16(probs)) if half else (sim, probs)
 
 
-def _attn_apply_f32(probs, v, heads, v_src=None, out=None):
-    """out [B, N, heads*d] = probs [B*heads, N, L] @ v [B, L, heads*d] per (batch row, head), fp32"""
+def _attn_apply_f32(probs, v, heads, v_src=None, out=None, map_scale=None):
+    """out [B, N, heads*d] = probs [B*heads, N, L] @ v [B, L, heads*d] per (batch row, head), fp32.
+    map_scale: split scale of the maps (default 2^14: entries <= 1; edited maps can exceed 1, `map_split_scale`)"""
     lib = load()
     _act32(probs, "probs"), _act32(v, "v")
     if not probs.is_contiguous():
@@ -1403,7 +1444,7 @@ def _attn_apply_f32(probs, v, heads, v_src=None, out=None):
     p.sOb, p.sOh, p.ldo = _batched32(p, _act32(out, "out"), heads, d, "out")
     p.batch, p.heads, p.out_scale, p.transb = B, heads, 1.0, 1
     p.w_src = _ptr(_devi32(v_src, "v_src"))
-    kn = _set_x3(p, X3_SCALE_PROB, X3_SCALE_ACT)         # maps are <= 1: a large scale keeps the lo halves of small entries normal
+    kn = _set_x3(p, X3_SCALE_PROB if map_scale is None else map_scale, X3_SCALE_ACT)    # maps <= 1: a large scale keeps the lo halves of small entries normal
     with _Timed(f"{kn}<apply {d}>", 2.0 * B * heads * N * L * d, 4.0 * B * heads * (N * d + L * d + N * L)):
         _check(lib.ief_gemm_f32(byref(p), _stream()), "ief_gemm_f32 (attention apply)")
     return out
@@ -1421,17 +1462,21 @@ def p2p_cross_edit_(probs, B, heads, edit_src, edit_slot, mt32, coef):
     return probs
 
 
-def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None, variant=0):
+def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, lse=None, variant=0, out_planes=False):
     """out[b] = softmax(q[q_src[b]] k[k_src[b]]^T * scale) v[v_src[b]]; q [B,N,h*d], k/v [B,L,h*d] (strided views ok).
     lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes.
     fp32 operands (reference-precision mode): the maps are materialised in HBM, as the reference does."""
     if _is32(q):
         if lse is not None:
             raise ValueError("attn_flash: lse output exists only on the fp16 path (the fp32 backward recomputes the maps)")
-        o = _attn_flash_f32(q, k, v, heads, scale, q_src, k_src, v_src, out)
+        o = _attn_flash_f32(q, k, v, heads, scale, q_src, k_src, v_src, out, out_planes=out_planes)
         if o is not None:
             return o
-        return _attn_apply_f32(_attn_scores_f32(q, k, heads, scale, q_src, k_src), v, heads, v_src, out)
+        o = _attn_apply_f32(_attn_scores_f32(q, k, heads, scale, q_src, k_src), v, heads, v_src, out)
+        if out_planes:
+            from . import planes as _pl
+            return _pl.split(o)
+        return o
     lib = load()
     if out is None:
         out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)
@@ -1453,45 +1498,71 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
 X3_FUSE_CROSS = os.environ.get("IEF_X3_FUSE_CROSS", "1") == "1"      # 0: materialised cross maps (scores, softmax, edit, apply: A/B runs)
 
 
-def _attn_cross_p2p_x3(q, k, v, heads, scale, edit_src, edit_slot, mt32, coef, out=None):
-    """`ief_attn_cross_p2p_f32`: the edited cross-attention layer of the f16x3 mode in one launch (maps stay in registers)"""
+def map_split_scale(coef_bound: float) -> float:
+    """power-of-two scale for the hi / lo split of EDITED maps P' = c1 T + c2 P whose entries reach `coef_bound` = max_w (|c1| +
+    |c2|) (maps <= 1 otherwise): the largest 2^k <= 2^14 with 2^k * coef_bound inside the fp16 range.  AttentionReweight lowers to
+    c1 = alpha * equalizer (`/root/reference/p2p/model/attention_control.py:42-46`): with the fixed 2^14 an equalizer of 5 on a
+    peaky source map overflowed to inf / NaN"""
+    b = max(1.0, float(coef_bound))
+    s = X3_SCALE_PROB
+    while s > 1.0 and s * b > 32768.0:        # a factor 2 of head-room below 65504
+        s *= 0.5
+    return s
+
+
+def _attn_cross_p2p_x3(q, k, v, heads, scale, edit_src, edit_slot, mt32, coef, out=None, out_planes=False, coef_bound=1.0):
+    """`ief_attn_cross_p2p_f32`: the edited cross-attention layer of the f16x3 mode in one launch (maps stay in registers).
+    coef_bound: max_w (|c1| + |c2|) over the plan's coefficient tables (sizes the split of the edited maps)"""
     lib = load()
     B, N, C = q.shape
     L, d = k.shape[1], C // heads
     _dev32(mt32, "mt32"), _dev32(coef, "coef")
     if tuple(mt32.shape[-2:]) != (96, 96) or coef.shape[-1] != 96 or not mt32.is_contiguous() or not coef.is_contiguous():
         raise ValueError("attn_cross_p2p: mt must be contiguous [slots,96,96] fp32, coef [slots,2,96] fp32")
-    if out is None:
-        out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
     p = IefAttnF32Params()
-    p.Q, p.K, p.V, p.Out = _act32(q, "q").data_ptr(), _act32(k, "k").data_ptr(), _act32(v, "v").data_ptr(), _act32(out, "out").data_ptr()
+    p.Q, p.K, p.V = _act32(q, "q").data_ptr(), _act32(k, "k").data_ptr(), _act32(v, "v").data_ptr()
+    op = None
+    if out_planes:
+        from . import planes as _pl
+        op, _ = _pl.attn_out_args(p, B, N, C, q.device)
+    else:
+        if out is None:
+            out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+        p.Out = _act32(out, "out").data_ptr()
+        p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
     p.B, p.heads, p.N, p.L, p.d, p.scale = B, heads, N, L, d, scale
     p.sQb, _, p.ldq = _batched32(p, q, heads, d, "q")
     p.sKb, _, p.ldk = _batched32(p, k, heads, d, "k")
     p.sVb, _, p.ldv = _batched32(p, v, heads, d, "v")
-    p.sOb, _, p.ldo = _batched32(p, out, heads, d, "out")
+    p.p_scale = map_split_scale(coef_bound)
     p.x3 = 1
     nedit = 2.0 * B * heads * N * 96 * 96
     with _Timed(f"attn_cross_p2p_x3_kernel<{d}>", 4.0 * B * heads * N * L * d + nedit, 4.0 * B * heads * d * (2 * N + 2 * L)):
         _check(lib.ief_attn_cross_p2p_f32(byref(p), _devi32(edit_src, "edit_src").data_ptr(), _devi32(edit_slot, "edit_slot").data_ptr(),
                                           mt32.data_ptr(), coef.data_ptr(), _stream()), "ief_attn_cross_p2p_f32")
-    return out
+    return op if out_planes else out
 
 
-def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None, coef=None, out=None):
+def attn_cross_p2p(q, k, v, heads, scale, edit_src=None, edit_slot=None, mt=None, coef=None, out=None, out_planes=False,
+                   coef_bound=1.0):
     """Cross-attention (<= 96 keys) with the fused Prompt-to-Prompt map edit (see include/ief_hip.h).
-    fp32 operands: materialised maps, `mt` must then be the fp32 table."""
+    fp32 operands: materialised maps, `mt` must then be the fp32 table.  out_planes (split-operand mode): the result as operand
+    planes for to_out's GEMM; coef_bound: max (|c1| + |c2|) of the plan (sizes the split of the edited maps)."""
     if _is32(q):
         if edit_src is None:
-            o = _attn_flash_f32(q, k, v, heads, scale, out=out)
+            o = _attn_flash_f32(q, k, v, heads, scale, out=out, out_planes=out_planes)
             if o is not None:
                 return o
         elif _F32_CONTRACT == "x3" and X3_FUSE_CROSS and k.shape[1] <= 96 and q.shape[2] // heads in (40, 64, 80, 160):
-            return _attn_cross_p2p_x3(q, k, v, heads, scale, edit_src, edit_slot, mt, coef, out)
+            return _attn_cross_p2p_x3(q, k, v, heads, scale, edit_src, edit_slot, mt, coef, out, out_planes, coef_bound)
         probs = _attn_scores_f32(q, k, heads, scale)
         if edit_src is not None:
             p2p_cross_edit_(probs, q.shape[0], heads, edit_src, edit_slot, mt, coef)
-        return _attn_apply_f32(probs, v, heads, None, out)
+        o = _attn_apply_f32(probs, v, heads, None, out, map_scale=map_split_scale(coef_bound) if edit_src is not None else None)
+        if out_planes:
+            from . import planes as _pl
+            return _pl.split(o)
+        return o
     lib = load()
     if out is None:
         out = torch.empty(q.shape[0], q.shape[1], q.shape[2], dtype=torch.float16, device=q.device)

@@ -1,0 +1,354 @@
+"""Pre-split operand planes of the f16x3 mode and the launches that consume / produce them (`csrc/gemm_x3p.hip`).
+
+An fp32 activation x of the split-operand mode travels between kernels as TWO fp16 planes, `hi = fp16(x)`,
+`lo = fp16(x - hi)` (4 bytes per element, like fp32): its producer writes them, so the GEMM that consumes it stages both
+operands by LDS-DMA and spends no vector instruction on the split (include/ief_hip.h, ABI 4).  `Planes` is the host-side
+handle of such a pair: one fp16 tensor `[2, *shape]` (index 0 = hi, 1 = lo), last dimension contiguous; column slices and
+reshapes stay views.  There is no CPU path: `Planes.to_f32()` exists for tests and debugging only.
+"""
+import os
+from ctypes import byref
+
+import torch
+
+from . import hip
+from .hip import IefGemmX3pParams, _check, _dev32, _ptr, _stream, _Timed, _zeros
+
+ACT_SCALE = 1.0          # activations: hi = fp16(x) — the fp16 range itself (65504), as on the fp16-storage path
+W_SCALE = hip.X3_SCALE_W
+
+
+class Planes:
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        if not (isinstance(t, torch.Tensor) and t.dtype == torch.float16 and t.dim() >= 2 and t.shape[0] == 2 and t.stride(-1) == 1):
+            raise TypeError("Planes: expected an fp16 tensor [2, ...] with a contiguous last dimension")
+        if not t.is_cuda:
+            raise TypeError("Planes: device tensor expected (no CPU path)")
+        self.t = t
+
+    @staticmethod
+    def empty(*shape, device):
+        return Planes(torch.empty(2, *shape, dtype=torch.float16, device=device))
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @property
+    def hi(self):
+        return self.t[0]
+
+    @property
+    def lo(self):
+        return self.t[1]
+
+    @property
+    def plane(self):
+        """element offset from a hi element to its lo element"""
+        return self.t.stride(0)
+
+    def dim(self):
+        return self.t.dim() - 1
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        return Planes(self.t[(slice(None),) + idx])
+
+    def reshape(self, *shape):
+        return Planes(self.t.reshape(2, *shape))
+
+    def is_contiguous(self):
+        return self.t[0].is_contiguous()
+
+    def to_f32(self):
+        return self.t[0].float() + self.t[1].float()
+
+    def rows_ld(self, name="planes"):
+        """(rows, cols, ld) with the leading dims collapsing to rows of one stride"""
+        h = self.t[0]
+        cols = h.shape[-1]
+        ld = h.stride(-2) if h.dim() >= 2 else cols
+        rows = 1
+        for s in h.shape[:-1]:
+            rows *= s
+        for d in range(h.dim() - 2):
+            if h.shape[d] > 1 and h.stride(d) != h.stride(d + 1) * h.shape[d + 1]:
+                raise ValueError(f"{name}: leading dimensions must collapse to rows of one stride")
+        return rows, cols, ld
+
+
+def split(x, out=None, scale=ACT_SCALE):
+    """fp32 [..., C] (rows of one stride) -> Planes (the standalone splitter: producers normally write planes themselves)"""
+    lib = hip.load()
+    rows, C, ldx = hip._rows_ld32(x, "x")
+    if out is None:
+        out = Planes.empty(*x.shape, device=x.device)
+    _, _, ldp = out.rows_ld("out")
+    _check(lib.ief_x3_split_act(x.data_ptr(), out.t.data_ptr(), out.plane, rows, C, ldx, ldp, float(scale), _stream()), "ief_x3_split_act")
+    return out
+
+
+def weight_planes(w):
+    """Planes view [N, K] of an fp32 weight's cached pre-split planes (scale 2^8)"""
+    t = hip.x3_weight_planes(w, W_SCALE)
+    if t is None:
+        raise RuntimeError("weight planes missing while capturing: run one eager forward first")
+    return t
+
+
+# ---- plan: tile id and split-K per (M, N, K); tuned table first (tuned_plans_x3.json), heuristic otherwise
+_PLAN_FILE = os.environ.get("IEF_PLAN_FILE_X3") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans_x3.json")
+_plans = None
+TILE_FORCE = int(os.environ.get("IEF_X3P_TILE", "0"))        # A/B runs: force one tile id
+
+
+def _plan_table():
+    global _plans
+    if _plans is None:
+        _plans = {}
+        if os.path.exists(_PLAN_FILE) and os.environ.get("IEF_NO_PLAN_TABLE", "0") != "1":
+            import json
+            with open(_PLAN_FILE) as f:
+                _plans = {k: tuple(v) for k, v in json.load(f).items()}
+    return _plans
+
+
+def save_plans(path=None):
+    import json
+    with open(path or _PLAN_FILE, "w") as f:
+        json.dump({k: list(v) for k, v in sorted(_plan_table().items())}, f, indent=0)
+
+
+_TILES = {1: (128, 160), 2: (128, 160), 3: (128, 80), 4: (256, 160), 5: (64, 160), 6: (128, 64), 11: (256, 80), 12: (256, 80)}
+
+
+def heuristic_plan(M, N, K, conv=False):
+    nk = K // 32
+    if N % 80 and N % 64 == 0:
+        tile = 6
+    elif N % 160:
+        tile = 3
+    elif M <= 64:
+        tile = 5
+    else:
+        t1 = -(-M // 128) * (N // 160)
+        tile = 4 if t1 >= 1024 and M % 256 == 0 else 1
+    bm, bn = _TILES[tile]
+    tiles = -(-M // bm) * -(-N // bn)
+    splits = 1
+    if tiles < 160 and nk >= 16:
+        splits = max(1, min(-(-256 // tiles), nk // 8, 16))
+    return tile, splits
+
+
+def pick_plan(M, N, K, conv=False, variant=""):
+    hit = _plan_table().get(f"{'conv' if conv else 'gemm'}|{M}|{N}|{K}{variant}")
+    if hit is None:
+        hit = heuristic_plan(M, N, K, conv)
+    if TILE_FORCE and (TILE_FORCE < 10 or conv):
+        return TILE_FORCE, hit[1]
+    return hit[0], hit[1]
+
+
+def supported(N, K):
+    """shapes the planes kernels take (everything else stays on the in-kernel split of csrc/split_x3.hip)"""
+    return (N % 80 == 0 or N % 64 == 0) and K % 32 == 0
+
+
+def _out_args(p, M, No, out, out_planes, device, lead_shape):
+    """fill Out / OutP of a launch; returns (fp32 tensor | None, Planes | None)"""
+    o32 = op = None
+    if out is True or isinstance(out, torch.Tensor) or (out is None and out_planes in (None, False)):
+        o32 = out if isinstance(out, torch.Tensor) else torch.empty(*lead_shape, No, dtype=torch.float32, device=device)
+        Mo, Nn, ldo = hip._rows_ld32(o32, "out")
+        if (Mo, Nn) != (M, No):
+            raise ValueError("x3p: out shape mismatch")
+        p.Out, p.ldo = o32.data_ptr(), ldo
+    if out_planes not in (None, False):
+        op = out_planes if isinstance(out_planes, Planes) else Planes.empty(*lead_shape, No, device=device)
+        Mp, Np, ldp = op.rows_ld("out_planes")
+        if (Mp, Np) != (M, No):
+            raise ValueError("x3p: out_planes shape mismatch")
+        p.OutP, p.planeO, p.ldp = op.t.data_ptr(), op.plane, ldp
+    return o32, op
+
+
+def _ret(o32, op):
+    if o32 is not None and op is not None:
+        return o32, op
+    return o32 if op is None else op
+
+
+def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_planes=None, out_scale=1.0,
+         geglu=False, tile=0, splits=0):
+    """(a . w^T + bias + rowvec + residual) * out_scale with a: Planes [..., K], w: fp32 weight [N, K] (its planes are cached).
+    out: an fp32 tensor to write / True (allocate one) / None (allocate one unless planes are asked for) / False (none);
+    out_planes: True / a Planes to receive the result's planes.  Returns the fp32 tensor, the Planes, or (fp32, Planes)."""
+    lib = hip.load()
+    if not isinstance(a, Planes):
+        raise TypeError("planes.gemm: a must be Planes")
+    M, K, lda = a.rows_ld("a")
+    N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K:
+        raise ValueError(f"planes.gemm: K mismatch {tuple(w.shape)} vs {K}")
+    wp = weight_planes(w)
+    p = IefGemmX3pParams()
+    p.A, p.planeA, p.lda = a.t.data_ptr(), a.plane, lda
+    p.W, p.planeW, p.ldw = wp.data_ptr(), wp.stride(0), K
+    No = N // 2 if geglu else N
+    o32, op = _out_args(p, M, No, out, out_planes, a.device, a.shape[:-1])
+    p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
+    if rowvec is not None:
+        p.rowvec, p.rows_per_batch = _dev32(rowvec, "rowvec").data_ptr(), rows_per_batch
+    if residual is not None:
+        Mr, Nr, ldr = hip._rows_ld32(residual, "residual")
+        if (Mr, Nr) != (M, N):
+            raise ValueError("planes.gemm: residual shape mismatch")
+        p.residual, p.ldr = residual.data_ptr(), ldr
+    p.M, p.N, p.K = M, N, K
+    p.out_scale, p.inv_scale = out_scale, 1.0 / (ACT_SCALE * W_SCALE)
+    p.geglu, p.zeros = 1 if geglu else 0, _zeros(a.device)
+    if tile:
+        p.tile, p.splits = tile, max(1, splits)
+    else:
+        p.tile, p.splits = pick_plan(M, N, K)
+    if geglu:
+        p.splits = 1
+    ws = None
+    if p.splits > 1:
+        ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)       # noqa: F841 (alive until queued)
+        p.ws = ws.data_ptr()
+    nbytes = 4.0 * (M * K + N * K + M * No * ((1 if o32 is not None else 0) + (1 if op is not None else 0)) + (M * N if residual is not None else 0))
+    with _Timed(f"igemm_x3p_kernel<false> t{p.tile}" + (f" {M}x{N}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * N * K, nbytes):
+        _check(lib.ief_gemm_x3p(byref(p), _stream()), "ief_gemm_x3p")
+    return _ret(o32, op)
+
+
+def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, out_planes=None,
+            extra=None, pad_hi_only=False, tile=0, splits=0):
+    """3x3 / pad 1 convolution over NHWC Planes x [B,H,W,C1] (+ x2 channel concat); w fp32 [Cout,3,3,C1+C2] or fused
+    [Cout, 9 (C1+C2) + CE1 + CE2] with extra=(Planes e1, Planes e2 | None); residual fp32; outputs as `gemm`"""
+    lib = hip.load()
+    if not isinstance(x, Planes) or (x2 is not None and not isinstance(x2, Planes)):
+        raise TypeError("planes.conv3x3: x / x2 must be Planes")
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()) or not w.is_contiguous():
+        raise ValueError("planes.conv3x3: x, x2, w must be contiguous")
+    B, Hp, Wp, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cout = w.shape[0]
+    e1 = e2 = None
+    CE1 = CE2 = 0
+    if extra is not None:
+        e1, e2 = extra
+        CE1 = e1.shape[-1]
+        CE2 = 0 if e2 is None else e2.shape[-1]
+        for e in (e1, e2):
+            if e is not None and (not isinstance(e, Planes) or not e.is_contiguous() or tuple(e.shape[:3]) != (B, Hp, Wp)):
+                raise ValueError("planes.conv3x3: extra sources must be contiguous NHWC Planes at the output resolution")
+    K = 9 * (C1 + C2) + CE1 + CE2
+    if w.numel() != Cout * K:
+        raise ValueError(f"planes.conv3x3: weight {tuple(w.shape)} does not match K = {K}")
+    H, Wd = (Hp * 2, Wp * 2) if upsample else (Hp, Wp)
+    pad_total = 1 if pad_hi_only else 2
+    Ho, Wo = (H + pad_total - 3) // stride + 1, (Wd + pad_total - 3) // stride + 1
+    M = B * Ho * Wo
+    wp = weight_planes(w)
+    p = IefGemmX3pParams()
+    p.A, p.planeA = x.t.data_ptr(), x.plane
+    if x2 is not None:
+        p.A2, p.planeA2 = x2.t.data_ptr(), x2.plane
+    if e1 is not None:
+        p.E1, p.planeE1 = e1.t.data_ptr(), e1.plane
+    if e2 is not None:
+        p.E2, p.planeE2 = e2.t.data_ptr(), e2.plane
+    p.W, p.planeW, p.ldw = wp.data_ptr(), wp.stride(0), K
+    o32, op = _out_args(p, M, Cout, out, out_planes, x.device, (B, Ho, Wo))
+    p.bias = _ptr(_dev32(bias, "bias")) if bias is not None else None
+    if rowvec is not None:
+        _dev32(rowvec, "rowvec")
+        if rowvec.dim() != 2 or rowvec.shape[1] != Cout or rowvec.shape[0] not in (1, B):
+            raise ValueError("planes.conv3x3: rowvec must be [B, Cout] or [1, Cout]")
+        p.rowvec = rowvec.data_ptr()
+        p.rows_per_batch = Ho * Wo if rowvec.shape[0] == B and B > 1 else B * Ho * Wo
+    if residual is not None:
+        if tuple(hip._act32(residual, "residual").shape) != (B, Ho, Wo, Cout) or not residual.is_contiguous():
+            raise ValueError("planes.conv3x3: residual must be contiguous fp32 [B, Ho, Wo, Cout]")
+        p.residual, p.ldr = residual.data_ptr(), Cout
+    p.M, p.N, p.K = M, Cout, K
+    p.conv, p.H, p.Wd, p.C1, p.C2, p.Ho, p.Wo = 1, H, Wd, C1, C2, Ho, Wo
+    p.stride, p.ups, p.batch_images, p.pad_hi_only = stride, 1 if upsample else 0, B, 1 if pad_hi_only else 0
+    p.CE1, p.CE2 = CE1, CE2
+    p.out_scale, p.inv_scale, p.zeros = 1.0, 1.0 / (ACT_SCALE * W_SCALE), _zeros(x.device)
+    if tile:
+        p.tile, p.splits = tile, max(1, splits)
+    else:
+        p.tile, p.splits = pick_plan(M, Cout, K, conv=True, variant="|u" if upsample else "")
+    if p.tile in (11, 12):
+        halo_ok = stride == 1 and not pad_hi_only and extra is None and Hp >= 2 and (C1 + C2) % 32 == 0 and (
+            (not upsample and 2 <= Wd <= 64) or (upsample and Wd <= 128 and (H * Wd) % 256 == 0 and 256 % Wd == 0))
+        if not halo_ok:
+            p.tile, p.splits = heuristic_plan(M, Cout, K, True)
+        else:
+            p.tile = 12 if upsample else 11
+    ws = None
+    if p.splits > 1:
+        ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)     # noqa: F841
+        p.ws = ws.data_ptr()
+    nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * ((1 if o32 is not None else 0) + (1 if op is not None else 0) + (1 if residual is not None else 0)))
+    with _Timed(f"igemm_x3p_kernel<true> t{p.tile}" + (f" {M}x{Cout}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
+        _check(lib.ief_gemm_x3p(byref(p), _stream()), "ief_gemm_x3p (conv)")
+    return _ret(o32, op)
+
+
+# ---- producers: the normalisations and the attention kernels write operand planes for the GEMM that follows them
+ENABLED = os.environ.get("IEF_X3P", "1") == "1"        # 0: the f16x3 model keeps the in-kernel split everywhere (A/B runs)
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out32=False):
+    """GroupNorm (+SiLU) over fp32 NHWC / tokens-major x (+ channel-concat x2) -> Planes [..., C1 + C2] (out32: also fp32)"""
+    lib = hip.load()
+    if not hip._act32(x, "x").is_contiguous() or (x2 is not None and not hip._act32(x2, "x2").is_contiguous()):
+        raise ValueError("planes.groupnorm: inputs must be contiguous")
+    B, C1 = x.shape[0], x.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    HW = x.numel() // (B * C1)
+    out = Planes.empty(*x.shape[:-1], C1 + C2, device=x.device)
+    o32 = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float32, device=x.device) if out32 else None
+    nws = lib.ief_groupnorm_f32_ws_floats(B, HW, C1 + C2)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    with _Timed("gn3_f32 (stats + finalize + apply)", 0.0, 12.0 * (x.numel() + (0 if x2 is None else x2.numel()))):
+        _check(lib.ief_groupnorm_silu_x3p_ws(x.data_ptr(), _ptr(x2), C1, C2, _ptr(o32), out.t.data_ptr(), out.plane,
+                                             _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups, eps,
+                                             1 if silu else 0, ws.data_ptr(), nws, _stream()), "ief_groupnorm_silu_x3p_ws")
+    return (out, o32) if out32 else out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    """LayerNorm over the last dim of contiguous fp32 x -> Planes"""
+    lib = hip.load()
+    if not hip._act32(x, "x").is_contiguous():
+        raise ValueError("planes.layernorm: x must be contiguous")
+    C = x.shape[-1]
+    out = Planes.empty(*x.shape, device=x.device)
+    with _Timed("layernorm_f32_vec_kernel", 0.0, 8.0 * x.numel()):
+        _check(lib.ief_layernorm_x3p(x.data_ptr(), out.t.data_ptr(), out.plane, _dev32(gamma, "gamma").data_ptr(),
+                                     _dev32(beta, "beta").data_ptr(), x.numel() // C, C, eps, _stream()), "ief_layernorm_x3p")
+    return out
+
+
+def attn_out_args(p, B, N, C, device, out32=False):
+    """fill OutP (and Out) of an IefAttnF32Params for an attention launch whose consumer is to_out's planes GEMM"""
+    op = Planes.empty(B, N, C, device=device)
+    p.OutP, p.planeO, p.sOPb, p.ldp = op.t.data_ptr(), op.plane, N * C, C
+    o32 = None
+    if out32:
+        o32 = torch.empty(B, N, C, dtype=torch.float32, device=device)
+        p.Out, p.sOb, p.ldo = o32.data_ptr(), N * C, C
+    return op, o32

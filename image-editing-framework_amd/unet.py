@@ -33,7 +33,7 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
-from . import hip
+from . import hip, planes
 from .config import UNetConfig
 
 
@@ -267,6 +267,33 @@ class Attention(nn.Module):
         return lin(o, residual=residual)
 
 
+    def forward_x3p(self, xp, ctx, residual):
+        """split-operand mode on operand planes (csrc/gemm_x3p.hip): xp = planes of the LayerNorm'ed input (written by the
+        LayerNorm launch), the attention kernel writes the planes to_out's GEMM stages by LDS-DMA; returns fp32 (the residual
+        stream).  Same dataflow as `forward` (`/root/reference/p2p/model/register.py:11-64`)."""
+        B, N, C = xp.shape
+        self.last_tokens = N
+        plan = self._plan
+        if ctx is None:
+            qkv = planes.gemm(xp, self.w_qkv)
+            qs = ks = vs = None
+            if plan is not None:
+                qs, ks, vs = plan.self_sources(B, N, self)
+            o = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads, self.scale, q_src=qs, k_src=ks,
+                               v_src=vs, out_planes=True)
+        else:
+            q = planes.gemm(xp, self.to_q.weight)
+            kv = self.context_kv(ctx)
+            args = plan.cross_edit(B, self) if plan is not None else {}
+            if self.map_out is not None:
+                hip.attn_probs(q, kv[..., :C], self.heads, self.scale, out=self.map_out)
+            o = hip.attn_cross_p2p(q, kv[..., :C], kv[..., C:], self.heads, self.scale, out_planes=True, **args)
+        if plan is not None:
+            plan.layer_done(self)
+        lin = self.to_out[0]
+        return planes.gemm(o, lin.weight, bias=lin.bias, residual=residual)
+
+
 class GEGLU(nn.Module):
     """Linear(C -> 8C) + hidden * gelu(gate) in ONE GEMM: the [hidden | gate] halves of the weight are interleaved
     in groups of 8 rows at pack time so the GEMM epilogue sees a hidden chunk next to its gate chunk and writes
@@ -341,6 +368,24 @@ class BasicTransformerBlock(nn.Module):
         return self.ff(self.norm3(h), residual=h)
 
 
+    def _attend_x3p(self, attn, norm, h, ctx):
+        if attn.is_native():
+            return attn.forward_x3p(planes.layernorm(h, norm.weight, norm.bias, norm.eps), ctx, residual=h)
+        return self._attend(attn, norm(h), h, ctx)          # a hook owns forward: fp32 in, fp32 out (generic path)
+
+    def forward_x3p(self, h, ctx, last):
+        """split-operand mode on operand planes: every LayerNorm writes the planes its GEMM consumes, FeedForward.net[0]
+        writes the GEGLU product as planes; last: the block's output is read by proj_out only -> planes only"""
+        h = self._attend_x3p(self.attn1, self.norm1, h, None)
+        h = self._attend_x3p(self.attn2, self.norm2, h, ctx)
+        n3 = planes.layernorm(h, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        f0, lin = self.ff.net[0].proj, self.ff.net[2]
+        g = planes.gemm(n3, f0.weight, bias=f0.bias, geglu=True, out=False, out_planes=True)
+        if last:
+            return planes.gemm(g, lin.weight, bias=lin.bias, residual=h, out=False, out_planes=True)
+        return planes.gemm(g, lin.weight, bias=lin.bias, residual=h)
+
+
 class Transformer2DModel(nn.Module):
     def __init__(self, sd, prefix, dim, heads, cross_dim, groups, dev, name, depth=1):
         super().__init__()
@@ -370,6 +415,24 @@ class Transformer2DModel(nn.Module):
         for blk in self.transformer_blocks:
             h = blk(h, encoder_hidden_states)
         return self.proj_out(h.reshape(B, H, W, C), residual=x, col_stats=col_stats)
+
+
+    def forward_x3p(self, x, encoder_hidden_states=None, want_planes=False):
+        """x fp32 NHWC -> (out fp32, Planes | None): GroupNorm writes proj_in's operand planes, the last block's FeedForward
+        writes proj_out's; proj_out's epilogue adds the fp32 residual and (want_planes) also emits the planes of the result for
+        a consumer that reads the raw stream (a shortcut source, Downsample2D / Upsample2D, a skip connection)"""
+        B, H, W, C = x.shape
+        n = self.norm
+        hn = planes.groupnorm(x, n.weight, n.bias, n.num_groups, n.eps, silu=False)
+        h = planes.gemm(hn.reshape(B, H * W, C), self.proj_in.weight, bias=self.proj_in.bias)
+        last = len(self.transformer_blocks) - 1
+        for k, blk in enumerate(self.transformer_blocks):
+            h = blk.forward_x3p(h, encoder_hidden_states, last=(k == last))
+        r = planes.gemm(h, self.proj_out.weight, bias=self.proj_out.bias, residual=x.reshape(B, H * W, C), out=True,
+                        out_planes=want_planes)
+        if want_planes:
+            return r[0].reshape(B, H, W, C), r[1].reshape(B, H, W, C)
+        return r.reshape(B, H, W, C), None
 
 
 # ------------------------------------------------------------------------------------- resnet
@@ -424,6 +487,29 @@ class ResnetBlock2D(nn.Module):
         return hip.conv3x3_shortcut(h, self.w2_fused, self.b2_fused, x, skip, col_stats=col_stats)
 
 
+    def forward_x3p(self, x, xp, temb_row, skip=None, skip_p=None, want_planes=False):
+        """split-operand mode on operand planes: x (+ skip) fp32 NHWC; xp / skip_p their planes (needed by the fused 1x1
+        shortcut only; split here when the producer did not emit them).  The two GroupNorms write the planes conv1 / conv2
+        stage by LDS-DMA; returns (out fp32, Planes | None).  Dataflow: `/root/reference/pnp/model/register.py:102-175`."""
+        n1, n2 = self.norm1, self.norm2
+        g1 = planes.groupnorm(x, n1.weight, n1.bias, n1.num_groups, n1.eps, silu=True, x2=skip)
+        h = planes.conv3x3(g1, self.conv1.weight, self.conv1.bias, rowvec=temb_row)
+        if self._inject is not None and self._inject.feature_source(h.shape[0]) is not None:
+            # Plug-and-Play: gather conv2's input rows (see `forward`); the gather runs on fp32, then one split
+            g2 = planes.split(hip.gather_rows(hip.groupnorm(h, n2.weight, n2.bias, n2.num_groups, n2.eps, silu=True),
+                                              self._inject.feature_source(h.shape[0])))
+        else:
+            g2 = planes.groupnorm(h, n2.weight, n2.bias, n2.num_groups, n2.eps, silu=True)
+        if self.conv_shortcut is None:
+            r = planes.conv3x3(g2, self.conv2.weight, self.conv2.bias, residual=x, out=True, out_planes=want_planes)
+        else:
+            xp = planes.split(x) if xp is None else xp
+            if skip is not None and skip_p is None:
+                skip_p = planes.split(skip)
+            r = planes.conv3x3(g2, self.w2_fused, self.b2_fused, extra=(xp, skip_p), out=True, out_planes=want_planes)
+        return r if want_planes else (r, None)
+
+
 class Downsample2D(nn.Module):
     def __init__(self, sd, prefix, dev):
         super().__init__()
@@ -431,6 +517,10 @@ class Downsample2D(nn.Module):
 
     def forward(self, x, col_stats=False):
         return self.conv(x, col_stats=col_stats)
+
+    def forward_x3p(self, xp, want_planes=True):
+        r = planes.conv3x3(xp, self.conv.weight, self.conv.bias, stride=2, out=True, out_planes=want_planes)
+        return r if want_planes else (r, None)
 
 
 class Upsample2D(nn.Module):
@@ -442,6 +532,10 @@ class Upsample2D(nn.Module):
 
     def forward(self, x, col_stats=False):
         return hip.conv3x3(x, self.conv.weight, self.conv.bias, upsample=True, col_stats=col_stats)
+
+    def forward_x3p(self, xp, want_planes=True):
+        r = planes.conv3x3(xp, self.conv.weight, self.conv.bias, upsample=True, out=True, out_planes=want_planes)
+        return r if want_planes else (r, None)
 
 
 # ------------------------------------------------------------------------------------- blocks
@@ -596,6 +690,10 @@ class UNet2DConditionModel(nn.Module):
         order += [m for blk in self.up_blocks for m in blk.modules() if m.__class__.__name__ == "Attention"]
         for i, m in enumerate(order):
             m._exec_index = i
+        # split-operand mode: activations travel as pre-split operand planes between the kernels (planes.py, csrc/gemm_x3p.hip)
+        # when every channel count suits the planes kernels (K tiles of 32 channels, column tiles of 160 / 80 or 64)
+        self.x3p = (self.precision == "f16x3" and planes.ENABLED and dev.type == "cuda"
+                    and all(c % 160 == 0 or c % 64 == 0 for c in ch) and cfg.cross_attention_dim % 32 == 0)
         self._temb_table = None   # per-step rows, see precompute_time_table
         self._temb_static = None  # [1, width] fp32 buffer a captured graph reads
         self._plan = None
@@ -704,6 +802,14 @@ class UNet2DConditionModel(nn.Module):
             if taps is not None:
                 taps[name] = v.float().permute(0, 3, 1, 2).cpu()
 
+        if self.x3p:
+            eps = self._trunk_x3p(x, trow, ctx, tap)
+            if per_step_kv:
+                for m in cross:
+                    m._kv_view = None
+            if self._plan is not None:
+                self._plan.end_forward(B)
+            return (eps,) if not return_dict else UNetOutput(sample=eps)
         # `hs` travels beside `h`: the column statistics its producing launch left for the next GroupNorm (hip.ColStats),
         # or None when that launch does not emit them (small levels, split-K plans, conv_in)
         h, hs = hip.conv_in(x, self.conv_in.weight, self.conv_in.bias), None
@@ -742,6 +848,47 @@ class UNet2DConditionModel(nn.Module):
         if not return_dict:
             return (eps,)
         return UNetOutput(sample=eps)
+
+    def _trunk_x3p(self, x, trow, ctx, tap):
+        """conv_in .. conv_out of the split-operand mode on operand planes.  `hp` travels beside `h`: the planes of h, emitted
+        by the launch that produced h WHERE A CONSUMER READS THE RAW STREAM through a GEMM / convolution — a skip connection or
+        block input feeding a fused 1x1 shortcut, Downsample2D / Upsample2D (no normalisation in front of them) — else None.
+        Everything a normalisation feeds gets its planes from that normalisation's launch."""
+        h = hip.conv_in(x, self.conv_in.weight, self.conv_in.bias)
+        hp = planes.split(h)
+        tap("conv_in", h)
+        skips = [(h, hp)]
+        for bi, blk in enumerate(self.down_blocks):
+            for j, res in enumerate(blk.resnets):
+                attn = blk.has_cross_attention
+                h, hp = res.forward_x3p(h, hp, trow(res), want_planes=not attn)       # every down-path output is a skip connection
+                if attn:
+                    h, hp = blk.attentions[j].forward_x3p(h, ctx, want_planes=True)
+                skips.append((h, hp))
+            if blk.downsamplers is not None:
+                h, hp = blk.downsamplers[0].forward_x3p(hp, want_planes=True)
+                skips.append((h, hp))
+            tap(f"down{bi}", h)
+        mid = self.mid_block
+        h, hp = mid.resnets[0].forward_x3p(h, hp, trow(mid.resnets[0]))
+        h, hp = mid.attentions[0].forward_x3p(h, ctx)
+        h, hp = mid.resnets[1].forward_x3p(h, None, trow(mid.resnets[1]), want_planes=True)     # x of up_blocks[0].resnets[0]'s shortcut
+        tap("mid", h)
+        nb = len(self.up_blocks)
+        for bi, blk in enumerate(self.up_blocks):
+            nr = len(blk.resnets)
+            for j, res in enumerate(blk.resnets):
+                sk, skp = skips.pop()
+                attn = blk.has_cross_attention
+                final = bi == nb - 1 and j == nr - 1            # feeds conv_norm_out only
+                h, hp = res.forward_x3p(h, hp, trow(res), skip=sk, skip_p=skp, want_planes=not attn and not final)
+                if attn:
+                    h, hp = blk.attentions[j].forward_x3p(h, ctx, want_planes=not final)
+            if blk.upsamplers is not None:
+                h, hp = blk.upsamplers[0].forward_x3p(hp, want_planes=True)
+            tap(f"up{bi}", h)
+        h = self.conv_norm_out(h, silu=True)
+        return hip.conv_out(h, self.conv_out.weight, self.conv_out.bias)
 
     def _cross_modules(self):
         c = getattr(self, "_cross_cache", None)

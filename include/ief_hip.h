@@ -28,12 +28,12 @@ typedef uint16_t ief_half;
 extern "C" {
 #endif
 
-#define IEF_ABI_VERSION 3
+#define IEF_ABI_VERSION 4
 int ief_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char* ief_target_arch(void);
 /* sizeof the parameter structs as compiled (0: IefGemmParams, 1: IefAttnParams, 2: IefCrossParams, 3: IefAttnBwdParams,
- * 4: IefMapLossParams) */
+ * 4: IefMapLossParams, 5: IefGemmF32Params, 6: IefAttnF32Params, 7: IefGemmX3pParams) */
 int ief_struct_size(int which);
 
 /* ------------------------------------------------------------------ GEMM / conv3x3
@@ -295,6 +295,15 @@ typedef struct IefAttnF32Params {
     float scale;
     const int* q_src; const int* k_src; const int* v_src;
     int x3;                 /* ABI 3: != 0 -> both products on split fp16 operands (csrc/split_x3.hip), softmax in fp32 */
+    /* ABI 4 (split-operand kernels only): the output ALSO / ONLY as operand planes for the to_out GEMM (csrc/gemm_x3p.hip):
+     * OutP hi plane [B][N][ldp] (batch stride sOPb), lo plane planeO elements further; Out may then be NULL */
+    ief_half* OutP;
+    long long planeO, sOPb;
+    int ldp;
+    /* ief_attn_cross_p2p_f32: power-of-two scale of the EDITED maps' hi / lo split, chosen by the host from the plan's
+     * coefficients so that scale * max |c1| + |c2| stays below the fp16 range (AttentionReweight: c1 = alpha * equalizer);
+     * 0 = 2^14 (maps <= 1) */
+    float p_scale;
 } IefAttnF32Params;
 int ief_attn_flash_f32(const IefAttnF32Params* p, void* stream);
 int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
@@ -322,6 +331,14 @@ int ief_groupnorm_bwd_f32_ws(const float* x, const float* x2, int C1, int C2, co
                              long long ws_floats, void* stream);
 int ief_layernorm_f32(const float* x, float* out, const float* gamma, const float* beta, long long rows, int C, float eps,
                       void* stream);
+/* ABI 4: the two normalisations as PRODUCERS of operand planes (hi = fp16(y), lo = fp16(y - hi), lo `plane` elements after hi;
+ * csrc/gemm_x3p.hip consumes them): GroupNorm (+SiLU) in the three row-streaming launches (out: optional fp32 copy), LayerNorm
+ * over rows of C <= 2560, C % 4 == 0 */
+int ief_groupnorm_silu_x3p_ws(const float* x, const float* x2, int C1, int C2, float* out, ief_half* outp, long long plane,
+                              const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu, float* ws,
+                              long long ws_floats, void* stream);
+int ief_layernorm_x3p(const float* x, ief_half* outp, long long plane, const float* gamma, const float* beta, long long rows, int C,
+                      float eps, void* stream);
 int ief_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
 int ief_silu_f32(const float* x, float* out, long long n, void* stream);
 /* hidden * gelu(gate) on the interleaved FF1 layout ([8 hidden | 8 gate] groups): pre [rows][2 Ch] -> out [rows][Ch] */
@@ -336,6 +353,53 @@ int ief_conv_out_f32act(const float* x, const float* w, const float* bias, float
 /* uint8 image epilogue of latent2image (/root/reference/p2p/model/sd_utils.py:85-88): fp32 NCHW in [-1, 1] -> uint8 NHWC,
  * (x / 2 + 0.5).clamp(0, 1) * 255 truncated */
 int ief_image_u8(const float* x, unsigned char* out, int B, int C, int H, int Wd, void* stream);
+
+/* ------------------------------------------------------------------ ABI 4: split-operand contractions on PRE-SPLIT PLANES
+ * (csrc/gemm_x3p.hip).  An activation tensor x [rows][C] of the f16x3 mode travels between kernels as two fp16 planes
+ *     hi = fp16(x),  lo = fp16(x - hi)            (activation scale 1; weights: scale 2^8, ief_x3_split_weights)
+ * the same 4 bytes per element as fp32: the PRODUCER of an activation (GroupNorm / LayerNorm apply, the GEGLU epilogue, the
+ * attention epilogues, a GEMM epilogue) writes the planes, so the GEMM that consumes it stages BOTH operands by LDS-DMA
+ * (global_load_lds) and its K loop holds no vector work at all: per 32-deep K tile three v_mfma_f32_16x16x32_f16 per fragment
+ * pair (Al Bh + Ah Bl + Ah Bh, fp32 accumulate).  A plane pair is addressed as (hi pointer, element offset of the lo plane).
+ * Same operator set as IefGemmParams (dense; 3x3 implicit GEMM with channel concat, nearest-2x, stride 2, fused 1x1 range),
+ * replaces the same reference call sites: /root/reference/p2p/model/register.py:33-54 (linears),
+ * /root/reference/pnp/model/register.py:139-175 (ResnetBlock2D convolutions + shortcut + temb / skip adds). */
+typedef struct IefGemmX3pParams {
+    const ief_half* A;  long long planeA;     /* dense: [M][lda] hi plane; conv: NHWC source 1 (C1 channels)            */
+    const ief_half* A2; long long planeA2;    /* conv: NHWC source 2 of a channel concat (C2 channels) or NULL            */
+    const ief_half* E1; long long planeE1;    /* conv: fused 1x1 range, sources sampled at the output pixel (CE1, CE2)     */
+    const ief_half* E2; long long planeE2;
+    const ief_half* W;  long long planeW;     /* [N][ldw] hi plane of the weight (scale w_scale)                           */
+    float* Out;                               /* fp32 [M][ldo] or NULL                                                     */
+    ief_half* OutP; long long planeO;         /* planes of the result, [M][ldp] (scale 1) or NULL; at least one of the two */
+    const float* bias;                        /* [N] or NULL */
+    const float* rowvec;                      /* [M / rows_per_batch][N] or NULL */
+    const float* residual;                    /* fp32 [M][ldr] or NULL */
+    int M, N, K;
+    int lda, ldw, ldo, ldp, ldr;
+    int conv, H, Wd, C1, C2, Ho, Wo, stride, ups, batch_images, pad_hi_only, CE1, CE2;
+    int rows_per_batch;
+    float out_scale;                          /* out = (acc * inv_scale + bias + rowvec + residual) * out_scale */
+    float inv_scale;                          /* 1 / (activation scale * weight scale) */
+    int tile;                                 /* 1: 128x160 (8 waves), 2: the same + 4 loader waves, 3: 128x80 (4 waves), 4: 256x160 (8 waves),
+                                                 5: 64x160 (4 waves), 6: 128x64 (4 waves; widths that are multiples of 64 only); 11 / 12: conv3x3_halo_x3p (256x80, 8 waves + 4 loader waves;
+                                                 plain 3x3 stride 1 pad 1, rows of <= 64 pixels; 12: nearest-2x fused) */
+    int splits;                               /* split-K over grid.y: fp32 slabs ws[splits][M][N] summed in slab order by a second launch */
+    float* ws;
+    int geglu;                                /* weight rows interleaved [8 hidden | 8 gate]: out [M][N / 2] = hidden * gelu(gate) */
+    const void* zeros;                        /* >= 16 bytes of device zeros (source of out-of-range rows / padded taps) */
+    /* statistics of the OUTPUT for the consumer's normalisation, in the (count, mean, M2) form merged Chan-style:
+     * rstat_out [M][ceil(N / BN)][2] = (mean, M2) of each row over this launch's N tiles (LayerNorm of the next block);
+     * cstat_out [ceil(M / BM)][N][2] = (mean, M2) of each output channel over the rows of an M tile (GroupNorm) */
+    float* rstat_out;
+    float* cstat_out;
+} IefGemmX3pParams;
+int ief_gemm_x3p(const IefGemmX3pParams* p, void* stream);
+int ief_gemm_x3p_tile_bm(int tile);
+int ief_gemm_x3p_tile_bn(int tile);
+/* fp32 x [rows][ldx] -> planes hi / lo [rows][ldp] (lo plane `plane` elements after hi); C % 4 == 0, 16-byte aligned rows */
+int ief_x3_split_act(const float* x, ief_half* planes, long long plane, long long rows, int C, int ldx, int ldp, float scale,
+                     void* stream);
 
 /* ------------------------------------------------------------------ activation gradients of the fp32-storage modes
  * (csrc/backward_f32.hip): the reverse pass of null-text inversion / Pix2Pix-zero at the reference's precision

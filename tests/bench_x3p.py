@@ -1,0 +1,107 @@
+"""Kernel-level A/B on one MI355X: the planes GEMM / convolution (csrc/gemm_x3p.hip) against the in-kernel split
+(csrc/split_x3.hip) on the SD1.5 batch-4 step's layer shapes.  Each timing = one hipGraph of 20 launches over cache-cold weight
+copies (hip._time_graph), us per launch and algorithmic TFLOP/s (peak of the mode: 2500 / 3 = 833).
+
+    python tests/bench_x3p.py [--tiles 1,2,3,4] [--conv] [--lin]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ief_amd  # noqa: E402,F401
+from ief_amd import hip, planes  # noqa: E402
+
+LIN = [(16384, 320, 320), (16384, 960, 320), (16384, 2560, 320), (16384, 320, 1280), (4096, 640, 640), (4096, 1920, 640),
+       (4096, 5120, 640), (4096, 640, 2560), (1024, 1280, 1280), (1024, 3840, 1280), (1024, 10240, 1280), (1024, 1280, 5120),
+       (256, 1280, 1280), (256, 10240, 1280)]
+# (B, H, W, C1, C2, Cout, stride, upsample, CE1, CE2)
+CONV = [(4, 64, 64, 320, 0, 320, 1, False, 0, 0), (4, 64, 64, 320, 320, 320, 1, False, 0, 0), (4, 64, 64, 640, 320, 320, 1, False, 0, 0),
+        (4, 64, 64, 320, 0, 320, 1, False, 320, 320), (4, 32, 32, 640, 0, 640, 1, False, 0, 0), (4, 32, 32, 320, 0, 640, 1, False, 0, 0),
+        (4, 32, 32, 640, 640, 640, 1, False, 0, 0), (4, 16, 16, 1280, 0, 1280, 1, False, 0, 0), (4, 16, 16, 1280, 1280, 1280, 1, False, 0, 0),
+        (4, 8, 8, 1280, 0, 1280, 1, False, 0, 0), (4, 64, 64, 320, 0, 320, 2, False, 0, 0), (4, 32, 32, 640, 0, 640, 1, True, 0, 0)]
+
+
+def rnd(*shape, scale=1.0):
+    return torch.randn(*shape, device="cuda") * scale
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", default="1,2,3,4")
+    ap.add_argument("--conv", action="store_true")
+    ap.add_argument("--lin", action="store_true")
+    ap.add_argument("--splits", default="1")
+    args = ap.parse_args()
+    tiles = [int(t) for t in args.tiles.split(",")]
+    splits = [int(s) for s in args.splits.split(",")]
+    do_lin, do_conv = args.lin or not args.conv, args.conv or not args.lin
+    with hip.f32_contraction("x3"):
+        if do_lin:
+            for M, N, K in LIN:
+                a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+                wc = hip._cold_copies(w)
+                for x in wc:
+                    planes.weight_planes(x)
+                ap_ = planes.split(a)
+                out = torch.empty(M, N, device="cuda")
+                fl = 2.0 * M * N * K
+                us_old = hip._time_graph(lambda i: hip.gemm(a, wc[i % len(wc)], out=out))
+                line = f"lin {M:6d}x{N:5d}x{K:5d}  old {us_old:7.1f} us {fl / us_old / 1e6:6.1f} TF |"
+                for t in tiles:
+                    bm, bn = planes._TILES[t]
+                    if N % bn:
+                        continue
+                    best = None
+                    for sp in splits:
+                        if sp > 1 and K // 32 // sp < 4:
+                            continue
+                        us = hip._time_graph(lambda i: planes.gemm(ap_, wc[i % len(wc)], out=out, tile=t, splits=sp))
+                        if best is None or us < best[0]:
+                            best = (us, sp)
+                    line += f" t{t}: {best[0]:7.1f} us {fl / best[0] / 1e6:6.1f} TF s{best[1]} |"
+                print(line, flush=True)
+                del wc
+        if do_conv:
+            for B, H, W, C1, C2, Cout, stride, ups, CE1, CE2 in CONV:
+                x, x2 = rnd(B, H, W, C1), (rnd(B, H, W, C2) if C2 else None)
+                K = 9 * (C1 + C2) + CE1 + CE2
+                w = rnd(Cout, K, scale=K ** -0.5) if CE1 else rnd(Cout, 3, 3, C1 + C2, scale=K ** -0.5)
+                Ho, Wo = (H * (2 if ups else 1)) // stride, (W * (2 if ups else 1)) // stride
+                e1 = rnd(B, Ho, Wo, CE1) if CE1 else None
+                e2 = rnd(B, Ho, Wo, CE2) if CE2 else None
+                extra = (e1, e2) if CE1 else None
+                wc = hip._cold_copies(w)
+                for t_ in wc:
+                    planes.weight_planes(t_)
+                xp, x2p = planes.split(x), (planes.split(x2) if C2 else None)
+                extrap = (planes.split(e1), planes.split(e2) if CE2 else None) if CE1 else None
+                M = B * Ho * Wo
+                fl = 2.0 * M * Cout * K
+                us_old = hip._time_graph(lambda i: hip.conv3x3(x, wc[i % len(wc)], x2=x2, stride=stride, upsample=ups, extra=extra))
+                line = f"conv {H:3d}x{W:3d} {C1:4d}+{C2:4d}->{Cout:4d} s{stride} u{int(ups)} e{CE1 + CE2:4d}  old {us_old:7.1f} us {fl / us_old / 1e6:6.1f} TF |"
+                for t in tiles:
+                    bm, bn = planes._TILES[t]
+                    if Cout % bn:
+                        continue
+                    best = None
+                    for sp in splits:
+                        if sp > 1 and K // 32 // sp < 4:
+                            continue
+                        try:
+                            us = hip._time_graph(lambda i: planes.conv3x3(xp, wc[i % len(wc)], x2=x2p, stride=stride, upsample=ups,
+                                                                          extra=extrap, tile=t, splits=sp))
+                        except RuntimeError:
+                            continue
+                        if best is None or us < best[0]:
+                            best = (us, sp)
+                    if best:
+                        line += f" t{t}: {best[0]:7.1f} us {fl / best[0] / 1e6:6.1f} TF s{best[1]} |"
+                print(line, flush=True)
+                del wc
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,28 @@ elif what == "gemmff":
 elif what == "gemmsq":      # the most frequent linear of the step: a square projection with bias + residual (to_out / proj_out)
     a, w, b, r = h(4, 4096, 320), h(320, 320, scale=0.05), torch.randn(320, device=DEV), h(4, 4096, 320)
     fn = lambda: hip.gemm(a, w, bias=b, residual=r)
+elif what.endswith("x3p"):      # the planes kernels (csrc/gemm_x3p.hip); optional tile id after a colon: conv64x3p:2
+    from ief_amd import planes
+    tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    f = lambda *s, scale=1.0: torch.randn(*s, device=DEV) * scale
+    base = what[:-3]
+    with hip.f32_contraction("x3"):
+        if base == "conv64":
+            x, w, b = planes.split(f(4, 64, 64, 320)), f(320, 3, 3, 320, scale=0.02), torch.randn(320, device=DEV)
+            g = lambda: planes.conv3x3(x, w, b, tile=tile)
+        elif base == "conv32":
+            x, w, b = planes.split(f(4, 32, 32, 640)), f(640, 3, 3, 640, scale=0.02), torch.randn(640, device=DEV)
+            g = lambda: planes.conv3x3(x, w, b, tile=tile)
+        elif base == "gemmsq":
+            a, w, b, r = planes.split(f(4, 4096, 320)), f(320, 320, scale=0.05), torch.randn(320, device=DEV), f(4, 4096, 320)
+            g = lambda: planes.gemm(a, w, bias=b, residual=r, tile=tile)
+        elif base == "gemmff":
+            a, w = planes.split(f(4096, 640)), f(5120, 640, scale=0.04)
+            g = lambda: planes.gemm(a, w, tile=tile)
+
+    def fn():
+        with hip.f32_contraction("x3"):
+            g()
 elif what.endswith("x3") or what.endswith("f32"):      # fp32-storage modes: split-operand ("x3") or fp32-MFMA contractions
     mode = "x3" if what.endswith("x3") else "f32"
     base = what[:-2] if mode == "x3" else what[:-3]

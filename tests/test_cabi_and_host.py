@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ief_hip.h but not exported"
     assert sorted(hip.EXPORTS) == names, "binding and header disagree on the entry-point list"
-    assert lib.ief_abi_version() == 3 and lib.ief_target_arch() == b"gfx950"
+    assert lib.ief_abi_version() == 4 and lib.ief_target_arch() == b"gfx950"
 
 
 def test_binding_rejects_host_tensors_no_cpu_fallback():

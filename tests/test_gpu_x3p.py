@@ -1,0 +1,212 @@
+"""Split-operand contractions on PRE-SPLIT PLANES (`csrc/gemm_x3p.hip`, `ief_amd.planes`) on a real MI355X.
+
+The f16x3 mode's activations travel as two fp16 planes (hi = fp16(x), lo = fp16(x - hi)) written by their producers; the GEMM /
+implicit-GEMM convolution stages both operands by LDS-DMA and runs three fp16 MFMAs per fragment pair.  The reference computes
+these layers in fp32 (`/root/reference/p2p/model/register.py:33-54`, `/root/reference/pnp/model/register.py:139-175`).
+
+Stated tolerances (every test prints what it measured):
+    planes written by any producer            == split of the fp32 value, bit for bit
+    single contractions vs fp64 on the host   <= 4e-6 of max |reference|  (the bound of tests/test_gpu_x3.py, unchanged)
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from ief_amd import hip, planes  # noqa: E402
+from ief_amd.planes import Planes  # noqa: E402
+
+XTOL = 4e-6
+
+
+def f32(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max()).item()
+
+
+def ref_split(x):
+    """the definition of the planes: two round-to-nearest conversions"""
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return hi, lo
+
+
+def assert_planes_equal_split(pl, x32):
+    hi, lo = ref_split(x32.float().cpu())
+    assert torch.equal(pl.hi.cpu(), hi), "hi plane differs from fp16(x)"
+    assert torch.equal(pl.lo.cpu(), lo), "lo plane differs from fp16(x - hi)"
+
+
+@pytest.fixture(autouse=True)
+def _x3():
+    with hip.f32_contraction("x3"):
+        yield
+
+
+def test_split_act_is_the_definition():
+    x = torch.cat([f32(64, 320, seed=1), f32(64, 320, seed=2, scale=1e-4), f32(64, 320, seed=3, scale=1e4)])        # max |x| ~ 4.5e4 < 65504
+    pl = planes.split(dev(x))
+    assert_planes_equal_split(pl, x)
+    assert (pl.to_f32().cpu() - x).abs().max() <= 2 ** -21 * x.abs().max()
+    # a strided destination (column slice of a wider planes tensor)
+    wide = Planes.empty(192, 960, device="cuda")
+    wide.t.zero_()
+    planes.split(dev(x), out=wide[:, 320:640])
+    assert_planes_equal_split(wide[:, 320:640], x)
+    assert wide.t[:, :, :320].abs().max() == 0 and wide.t[:, :, 640:].abs().max() == 0
+
+
+def test_gemm_x3p_identity_asymmetric():
+    """A = I with an asymmetric W of fp16-exact values catches a swapped row / column fragment map, a wrong swizzle and a dropped term"""
+    a = torch.eye(160)
+    w = torch.arange(320)[:, None] * 0.25 + torch.arange(160)[None, :] * 1.0 + 1.0 / 1024
+    for tile in (1, 2, 3, 4, 5):
+        out = planes.gemm(planes.split(dev(a)), dev(w), tile=tile)
+        assert out.dtype == torch.float32 and torch.equal(out.cpu(), w.t().contiguous()), f"tile {tile}"
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(128, 160, 32), (300, 320, 96), (16384, 320, 320), (77, 1280, 768), (4, 1280, 320),
+                                   (1000, 480, 96), (4096, 2560, 320), (256, 1280, 5120)])
+def test_gemm_x3p(M, N, K, tile):
+    a, w = f32(M, K, seed=1), f32(N, K, seed=2, scale=K ** -0.5)
+    bias, res = f32(N, seed=3, scale=0.1), f32(M, N, seed=4)
+    ap = planes.split(dev(a))
+    out, op = planes.gemm(ap, dev(w), bias=dev(bias), residual=dev(res), out_scale=0.5, out=True, out_planes=True, tile=tile)
+    ref = (a.double() @ w.double().t() + bias.double() + res.double()) * 0.5
+    e = rel_err(out, ref)
+    old = hip.gemm(dev(a), dev(w), bias=dev(bias), residual=dev(res), out_scale=0.5)       # the in-kernel split (scale 4)
+    print(f"gemm x3p t{tile} {M}x{N}x{K}: {e:.2e} vs fp64 (in-kernel split: {rel_err(old, ref):.2e})")
+    assert e < XTOL
+    assert_planes_equal_split(op, out)                       # the epilogue's planes ARE the split of its fp32 output
+    # split-K: slabs summed in slab order by the reducer launch
+    if K >= 256:
+        o2 = planes.gemm(ap, dev(w), bias=dev(bias), residual=dev(res), out_scale=0.5, tile=tile, splits=4)
+        assert rel_err(o2, ref) < XTOL
+    # planes only; row vector; strided A and output views
+    rv = f32(2, N, seed=5)
+    if M % 2 == 0:
+        o3 = planes.gemm(ap, dev(w), rowvec=dev(rv), rows_per_batch=M // 2, out=False, out_planes=True, tile=tile)
+        ref3 = a.double() @ w.double().t() + rv.double().repeat_interleave(M // 2, 0)
+        assert isinstance(o3, Planes) and rel_err(o3.to_f32(), ref3) < XTOL
+    wide = planes.split(dev(f32(M, K + 64, seed=6)))
+    owide = torch.zeros(M, N + 4, device="cuda")
+    planes.gemm(wide[:, 32:32 + K], dev(w), out=owide[:, :N], tile=tile)
+    assert rel_err(owide[:, :N], wide[:, 32:32 + K].to_f32().double().cpu() @ w.double().t()) < XTOL and owide[:, N:].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,Ch,K", [(4096, 1280, 320), (300, 640, 96), (333, 160, 64)])
+def test_gemm_x3p_fused_geglu(M, Ch, K):
+    a, w, bias = f32(M, K, seed=1), f32(2 * Ch, K, seed=2, scale=K ** -0.5), f32(2 * Ch, seed=3, scale=0.1)
+    out, op = planes.gemm(planes.split(dev(a)), dev(w), bias=dev(bias), geglu=True, out=True, out_planes=True)
+    pre = (a.double() @ w.double().t() + bias.double()).reshape(M, Ch // 8, 2, 8)
+    ref = (pre[:, :, 0] * F.gelu(pre[:, :, 1])).reshape(M, Ch)
+    e = rel_err(out, ref)
+    print(f"x3p fused GEGLU {M}x{2 * Ch}x{K}: {e:.2e}")
+    assert e < XTOL
+    assert_planes_equal_split(op, out)
+
+
+def _conv_ref(x, w, bias, x2=None, stride=1, upsample=False, pad_hi_only=False):
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    xin = xin.permute(0, 3, 1, 2).double()
+    if upsample:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    wt = w.permute(0, 3, 1, 2).double()
+    if pad_hi_only:
+        xin = F.pad(xin, (0, 1, 0, 1))
+        y = F.conv2d(xin, wt, None if bias is None else bias.double(), stride=stride)
+    else:
+        y = F.conv2d(xin, wt, None if bias is None else bias.double(), stride=stride, padding=1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", ["plain", "concat", "stride2", "upsample", "pad_hi", "odd"])
+def test_conv_x3p(case, tile):
+    B, H, W, C1, Cout = 2, 16, 16, 64, 160
+    kw, C2 = {}, 0
+    if case == "concat":
+        C2 = 32
+    elif case == "stride2":
+        kw["stride"] = 2
+    elif case == "upsample":
+        kw["upsample"] = True
+        H = W = 8
+    elif case == "pad_hi":
+        kw.update(stride=2, pad_hi_only=True)
+    elif case == "odd":
+        B, H, W = 3, 9, 7
+    x, w, bias = f32(B, H, W, C1, seed=1), f32(Cout, 3, 3, C1 + C2, seed=2, scale=(9 * (C1 + C2)) ** -0.5), f32(Cout, seed=3, scale=0.1)
+    x2 = f32(B, H, W, C2, seed=4) if C2 else None
+    ref = _conv_ref(x, w, bias, x2, **kw)
+    rv = f32(B, Cout, seed=5)
+    res = f32(*ref.shape, seed=6)
+    out, op = planes.conv3x3(planes.split(dev(x)), dev(w), dev(bias), x2=None if x2 is None else planes.split(dev(x2)),
+                             rowvec=dev(rv), residual=dev(res), out=True, out_planes=True, tile=tile, **kw)
+    full = ref + rv.double()[:, None, None, :] + res.double()
+    e = rel_err(out, full)
+    print(f"conv x3p {case} t{tile}: {e:.2e}")
+    assert e < XTOL
+    assert_planes_equal_split(op, out)
+    if case in ("plain", "concat"):
+        o2 = planes.conv3x3(planes.split(dev(x)), dev(w), dev(bias), x2=None if x2 is None else planes.split(dev(x2)), tile=tile, splits=3)
+        assert rel_err(o2, ref) < XTOL
+
+
+@pytest.mark.parametrize("tile", [1, 3])
+def test_conv_x3p_fused_shortcut(tile):
+    """ResnetBlock2D tail with a channel-changing shortcut in ONE launch: conv3x3(h) + conv1x1([x | skip])"""
+    B, H, W, Cout, Cx, Cs = 2, 16, 16, 160, 64, 96
+    h, x, skip = f32(B, H, W, Cout, seed=1), f32(B, H, W, Cx, seed=2), f32(B, H, W, Cs, seed=3)
+    w2, ws, bias = f32(Cout, 3, 3, Cout, seed=4, scale=0.03), f32(Cout, Cx + Cs, seed=5, scale=0.08), f32(Cout, seed=6, scale=0.1)
+    wf = torch.cat([w2.reshape(Cout, -1), ws], 1).contiguous()
+    out = planes.conv3x3(planes.split(dev(h)), dev(wf), dev(bias), extra=(planes.split(dev(x)), planes.split(dev(skip))), tile=tile)
+    ref = _conv_ref(h, w2, bias) + torch.cat([x, skip], -1).double() @ ws.double().t()
+    e = rel_err(out, ref)
+    print(f"conv x3p + fused 1x1 shortcut t{tile}: {e:.2e}")
+    assert e < XTOL
+    out1 = planes.conv3x3(planes.split(dev(h)), dev(torch.cat([w2.reshape(Cout, -1), ws[:, :Cx]], 1).contiguous()), dev(bias),
+                          extra=(planes.split(dev(x)), None), tile=tile)
+    assert rel_err(out1, _conv_ref(h, w2, bias) + x.double() @ ws[:, :Cx].double().t()) < XTOL
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 64, 64), (1000, 192, 128), (4096, 1024, 128), (77, 256, 64)])
+def test_gemm_x3p_widths_of_64(M, N, K):
+    """tile 6 (128 x 64): the widths of the TINY / SMALLXL test geometries and of the VAE (multiples of 64, not of 80)"""
+    a, w, bias = f32(M, K, seed=1), f32(N, K, seed=2, scale=K ** -0.5), f32(N, seed=3, scale=0.1)
+    out = planes.gemm(planes.split(dev(a)), dev(w), bias=dev(bias))
+    e = rel_err(out, a.double() @ w.double().t() + bias.double())
+    print(f"gemm x3p (auto tile) {M}x{N}x{K}: {e:.2e}")
+    assert e < XTOL
+    x, wc = f32(2, 16, 16, 64, seed=4), f32(128, 3, 3, 64, seed=5, scale=0.04)
+    assert rel_err(planes.conv3x3(planes.split(dev(x)), dev(wc)), _conv_ref(x, wc, None)) < XTOL
+
+
+def test_sd15_shapes_x3p_full_size():
+    """the step's largest layers at their real sizes (batch 4): K = C projection, FeedForward.net[0], the 64x64 convolution"""
+    for (M, N, K) in [(16384, 320, 320), (16384, 2560, 320), (4096, 640, 2560)]:
+        a, w = f32(M, K, seed=1), f32(N, K, seed=2, scale=K ** -0.5)
+        out = planes.gemm(planes.split(dev(a)), dev(w))
+        idx = torch.randint(0, M, (256,), generator=torch.Generator().manual_seed(3))
+        ref = a[idx].double() @ w.double().t()
+        e = ((out[idx.cuda()].double().cpu() - ref).abs().max() / ref.abs().max()).item()
+        print(f"x3p {M}x{N}x{K}: {e:.2e}")
+        assert e < XTOL
+    x, w = f32(4, 64, 64, 320, seed=1), f32(320, 3, 3, 320, seed=2, scale=2880 ** -0.5)
+    out = planes.conv3x3(planes.split(dev(x)), dev(w))
+    ref = _conv_ref(x[:1], w, None)
+    e = rel_err(out[:1], ref)
+    print(f"x3p conv 64x64x320: {e:.2e}")
+    assert e < XTOL
