@@ -608,7 +608,7 @@ extern "C" int ief_p2p_cross_edit_f32(float* P, const int* edit_src, const int* 
 __global__ __launch_bounds__(512) void groupnorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
                                                             float* __restrict__ out, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int HW, int groups, float eps, int silu,
-                                                            int PY, int KS) {
+                                                            int PY, int KS, half_t* __restrict__ outp = nullptr, long long plane = 0) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     __shared__ float red[8];
     __shared__ float bc;
@@ -670,7 +670,14 @@ __global__ __launch_bounds__(512) void groupnorm_f32_kernel(const float* __restr
             if (p < HW) {
                 float y0 = v[u][0] * sc0 + sh0, y1 = v[u][1] * sc1 + sh1;
                 if (silu) { y0 = silu_x(y0); y1 = silu_x(y1); }
-                *(f32x2*)(ob + (long long)p * C) = (f32x2){y0, y1};
+                if (out) *(f32x2*)(ob + (long long)p * C) = (f32x2){y0, y1};
+                if (outp) {          // operand planes (csrc/gemm_x3p.hip): hi = fp16(y), lo = fp16(y - hi)
+                    const half2_t h = __builtin_convertvector((f32x2){y0, y1}, half2_t);
+                    const half2_t l = __builtin_convertvector((f32x2){y0 - (float)h[0], y1 - (float)h[1]}, half2_t);
+                    half_t* o = outp + ((long long)b * HW + p) * C + c;
+                    *(half2_t*)o = h;
+                    *(half2_t*)(o + plane) = l;
+                }
             }
         }
     }
@@ -1123,6 +1130,30 @@ extern "C" int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, i
     while (KS * 2 <= rounds && B * groups * KS < 1024) KS *= 2;
     hipLaunchKernelGGL(groupnorm_f32_kernel, dim3(B * groups * KS), dim3(threads), 0, (hipStream_t)stream, x, x2, C1, C2, out,
                        gamma, beta, HW, groups, eps, silu, PY, KS);
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
+// one launch (KS workgroups per (image, group)) writing operand planes: the small levels, where three row-streaming launches are
+// three dispatch latencies for a few hundred KB
+extern "C" int ief_groupnorm_silu_x3p_small(const float* x, const float* x2, int C1, int C2, ief_half* outp, long long plane,
+                                            const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu,
+                                            void* stream) {
+    if (!x || !outp || !gamma || !beta || (C2 > 0 && !x2)) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups || (plane & 1)) return IEF_ESHAPE;
+    const int cpg = (C1 + C2) / groups;
+    if ((cpg & 1) || (C1 & 1) || (cpg >> 1) > 256) return IEF_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) & 7) || ((uintptr_t)outp & 3)) return IEF_EALIGN;
+    const int cp2 = cpg >> 1;
+    int PY = 512 / cp2;
+    if (PY > HW) PY = HW;
+    int threads = ((cp2 * PY + 63) / 64) * 64;
+    if (threads > 512) { PY -= 1; threads = ((cp2 * PY + 63) / 64) * 64; }
+    const int rounds = (HW + PY * 8 - 1) / (PY * 8);
+    int KS = 1;
+    while (KS * 2 <= rounds && B * groups * KS < 1024) KS *= 2;
+    hipLaunchKernelGGL(groupnorm_f32_kernel, dim3(B * groups * KS), dim3(threads), 0, (hipStream_t)stream, x, x2, C1, C2, (float*)nullptr,
+                       gamma, beta, HW, groups, eps, silu, PY, KS, (half_t*)outp, plane);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

@@ -12,7 +12,7 @@
 //
 //   K tile = 32 halves per plane (64-byte LDS rows: two planes of both operands make a 128 x 160 tile 36 KiB per ring slot);
 //   a ring slot is [A hi | A lo | W hi | W lo] as 16-row PIECES of 1 KiB = one LDS-DMA wave-instruction (lane l -> row l >> 2,
-//   16-byte slot l & 3); the slot of chunk c of row r is c ^ f((r >> 2) & 3), f = {0, 2, 3, 1}: conflict-free ds_read_b128
+//   16-byte slot l & 3); the slot of chunk c of row r is c ^ (2 * bit 2 of r): conflict-free ds_read_b128
 //   fragments of 16 consecutive rows (checked against the instruction's four 16-lane groups), applied to the per-lane SOURCE
 //   address (the LDS image of a piece is lane-linear).  Pieces are dealt round-robin to the staging waves (all waves, or NL
 //   loader waves); a wave whose share is short issues filler pieces from the zero page into a scratch kilobyte so that every
@@ -26,41 +26,7 @@
 #include "ief_params.h"
 #include "x3_common.h"
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-__device__ __forceinline__ void glds16(const char* g, half_t* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
-}
-
-#define XP_BK 32
-#ifndef XP_ABL
-#define XP_ABL 0        // timing-only ablation builds (outputs wrong): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 one MFMA per block, 8 no barrier
-#endif
-#define XP_GROUP_M 8
-#if XP_ABL & 8
-#define XP_BARRIER() do {} while (0)
-#else
-#define XP_BARRIER() asm volatile("s_barrier" ::: "memory")
-#endif
-// slot (16-byte unit inside a 64-byte LDS row) of chunk c of row r is c ^ xp_swz(r)
-__device__ __forceinline__ int xp_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-
-// the epilogue of one 16 x 16 block held as f32x4 per lane (row m, columns n .. n + 3): bias / row vector / residual, fp32
-// and / or plane stores
-__device__ __forceinline__ void xp_store(const IefGemmX3pParams& p, f32x4 v, int m, int n) {
-    if (p.bias) v += *(const f32x4*)(p.bias + n);
-    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n);
-    if (p.residual) v += *(const f32x4*)(p.residual + (long long)m * p.ldr + n);
-    v = v * p.out_scale;
-    if (p.Out) *(f32x4*)(p.Out + (long long)m * p.ldo + n) = v;
-    if (p.OutP) {
-        half4 h, l;
-        split4(v, 1.0f, h, l);
-        half_t* o = p.OutP + (long long)m * p.ldp + n;
-        *(half4*)o = h;
-        *(half4*)(o + p.planeO) = l;
-    }
-}
+#include "x3p_common.h"
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, int NL, bool CONV>
 __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kernel(const IefGemmX3pParams p) {
@@ -106,7 +72,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
     // ---- staging state: one 64-bit source pointer per piece (plane offset included), advanced by one K tile (64 B) per stage.
     // Out-of-range rows (M / N tails, padded taps) and filler pieces point at the zero page and do not advance.
     const int prow = lane >> 2;                                                     // row of this lane inside a piece
-    const unsigned kcb = (unsigned)(((lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3)) * 16);   // chunk FETCHED for LDS slot lane & 3
+    const unsigned kcb = (unsigned)(XP_LANE_CHUNK(lane) * 16);                         // chunk FETCHED for LDS slot lane & 3
     const char* ptr[G];
     unsigned step[G];
     bool exists[G], isA[G];          // wave-uniform

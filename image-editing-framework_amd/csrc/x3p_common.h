@@ -1,0 +1,47 @@
+// Shared pieces of the planes kernels (gemm_x3p.hip, conv_halo_x3p.hip): LDS-DMA piece, LDS swizzle, the epilogue of one block.
+#pragma once
+#include "ief_common.h"
+#include "ief_params.h"
+#include "x3_common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+__device__ __forceinline__ void glds16(const char* g, half_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+#define XP_BK 32
+#ifndef XP_ABL
+#define XP_ABL 0        // timing-only ablation builds (outputs wrong): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 one MFMA per block, 8 no barrier
+#endif
+#define XP_GROUP_M 8
+#if XP_ABL & 8
+#define XP_BARRIER() do {} while (0)
+#else
+#define XP_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
+// LDS rows are 64 B (one 32-deep K tile of one plane); the slot (16-byte unit) of chunk c of row r is c ^ xp_swz(r).  With
+// xp_swz(r) = 2 * bit 2 of r the ds_read_b128 fragments of 16 CONSECUTIVE rows starting at ANY row are free of bank conflicts
+// (brute-forced over the instruction's four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...; the tap shift of the
+// halo convolution moves the start).  An LDS-DMA piece is lane-linear (lane l -> row l >> 2 of 16, slot l & 3), so the swizzle
+// is applied to the SOURCE chunk a lane fetches: XP_LANE_CHUNK(l), the same for every piece (pieces start at multiples of 16 rows)
+__device__ __forceinline__ int xp_swz(int row) { return (row >> 1) & 2; }
+#define XP_LANE_CHUNK(lane) (((lane) & 3) ^ (((lane) >> 3) & 2))
+
+// the epilogue of one 16 x 16 block held as f32x4 per lane (row m, columns n .. n + 3): bias / row vector / residual, fp32
+// and / or plane stores
+__device__ __forceinline__ void xp_store(const IefGemmX3pParams& p, f32x4 v, int m, int n) {
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n);
+    if (p.residual) v += *(const f32x4*)(p.residual + (long long)m * p.ldr + n);
+    v = v * p.out_scale;
+    if (p.Out) *(f32x4*)(p.Out + (long long)m * p.ldo + n) = v;
+    if (p.OutP) {
+        half4 h, l;
+        split4(v, 1.0f, h, l);
+        half_t* o = p.OutP + (long long)m * p.ldp + n;
+        *(half4*)o = h;
+        *(half4*)(o + p.planeO) = l;
+    }
+}
+

@@ -148,7 +148,7 @@ EXPORTS = [
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
     "ief_map_loss_rows_f32", "ief_nti_adam_f32g",
     # ABI 4: split-operand contractions on pre-split planes (csrc/gemm_x3p.hip)
-    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p",
+    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small",
 ]
 
 
@@ -264,6 +264,8 @@ def load():
     lib.ief_x3_split_act.argtypes = [c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_int, c_float, c_void_p]
     lib.ief_groupnorm_silu_x3p_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                               c_int, c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]
+    lib.ief_groupnorm_silu_x3p_small.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,
+                                                 c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.ief_layernorm_x3p.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p]
     if lib.ief_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("libief_hip.so ABI version mismatch; rebuild")

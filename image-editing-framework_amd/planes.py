@@ -157,6 +157,56 @@ def pick_plan(M, N, K, conv=False, variant=""):
     return hit[0], hit[1]
 
 
+AUTOTUNE = os.environ.get("IEF_AUTOTUNE_X3", "0") == "1"      # tune unseen shapes on first (eager) use: tests/tune_plans_x3.py
+
+
+def candidate_plans(M, N, K, conv=False, halo_ok=False, ncb=0, geglu=False):
+    """(tile, splits) worth timing for one shape"""
+    nk = K // 32
+    out = []
+    for t, (bm, bn) in _TILES.items():
+        if t in (11, 12):
+            continue
+        if N % bn or (t == 6 and N % 80 == 0):
+            continue
+        tiles = -(-M // bm) * (N // bn)
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sp > 1 and (geglu or nk // sp < 4 or tiles * sp > 2048 or tiles >= 512):
+                continue
+            if tiles * sp < 40 and sp < 16:
+                continue
+            out.append((t, sp))
+    if conv and halo_ok:
+        tiles = -(-M // 256) * (N // 80)
+        for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
+            if sp > 1 and (sp > ncb // 2 or tiles * sp > 1024 or tiles >= 384):
+                continue
+            if tiles * sp < 40 and sp < 16:
+                continue
+            out.append((11, sp))
+    return out
+
+
+def _autotune(key, cands, run, w):
+    """time run(tile, splits, weight copy) for every candidate (hipGraph of 20 launches over cache-cold weight copies)"""
+    wc = hip._cold_copies(w)
+    for x in wc:
+        weight_planes(x)
+    best = None
+    for t, sp in cands:
+        try:
+            us = hip._time_graph(lambda i: run(t, sp, wc[i % len(wc)]))
+        except (RuntimeError, ValueError):
+            continue
+        if best is None or us < best[0]:
+            best = (us, t, sp)
+    for x in wc[1:]:
+        hip._x3_planes.pop((x.data_ptr(), tuple(x.shape), float(W_SCALE)), None)
+    if best is not None:
+        _plan_table()[key] = (best[1], best[2])
+    return best
+
+
 def supported(N, K):
     """shapes the planes kernels take (everything else stays on the in-kernel split of csrc/split_x3.hip)"""
     return (N % 80 == 0 or N % 64 == 0) and K % 32 == 0
@@ -218,7 +268,12 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     if tile:
         p.tile, p.splits = tile, max(1, splits)
     else:
-        p.tile, p.splits = pick_plan(M, N, K)
+        key = f"gemm|{M}|{N}|{K}" + ("|g" if geglu else "")
+        if AUTOTUNE and key not in _plan_table() and not hip._capturing() and hip._prof is None:
+            _autotune(key, candidate_plans(M, N, K, geglu=geglu),
+                      lambda t, sp, wi: gemm(a, wi, bias=bias, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch, out=out,
+                                             out_planes=out_planes, out_scale=out_scale, geglu=geglu, tile=t, splits=sp), w)
+        p.tile, p.splits = pick_plan(M, N, K, variant="|g" if geglu else "")
     if geglu:
         p.splits = 1
     ws = None
@@ -286,28 +341,51 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
     p.stride, p.ups, p.batch_images, p.pad_hi_only = stride, 1 if upsample else 0, B, 1 if pad_hi_only else 0
     p.CE1, p.CE2 = CE1, CE2
     p.out_scale, p.inv_scale, p.zeros = 1.0, 1.0 / (ACT_SCALE * W_SCALE), _zeros(x.device)
+    # the halo form (input super-tile resident in LDS across the nine taps): plain 3x3 / stride 1 / pad 1 on rows of <= 64
+    # pixels, or the fused nearest-2x on rows of <= 128 pixels with whole output rows per 256-pixel tile
+    halo_ok = HALO and stride == 1 and not pad_hi_only and extra is None and Hp >= 2 and Cout % 80 == 0 and (
+        (not upsample and 2 <= Wd <= 64) or (upsample and Wd <= 128 and (H * Wd) % 256 == 0 and 256 % Wd == 0))
     if tile:
         p.tile, p.splits = tile, max(1, splits)
     else:
-        p.tile, p.splits = pick_plan(M, Cout, K, conv=True, variant="|u" if upsample else "")
-    if p.tile in (11, 12):
-        halo_ok = stride == 1 and not pad_hi_only and extra is None and Hp >= 2 and (C1 + C2) % 32 == 0 and (
-            (not upsample and 2 <= Wd <= 64) or (upsample and Wd <= 128 and (H * Wd) % 256 == 0 and 256 % Wd == 0))
-        if not halo_ok:
-            p.tile, p.splits = heuristic_plan(M, Cout, K, True)
+        variant = ("|u" if upsample else "") + (f"|s{stride}" if stride != 1 else "") + ("|e" if extra is not None else "")
+        key = f"conv|{M}|{Cout}|{K}{variant}"
+        if AUTOTUNE and key not in _plan_table() and not hip._capturing() and hip._prof is None:
+            _autotune(key, candidate_plans(M, Cout, K, conv=True, halo_ok=halo_ok, ncb=(C1 + C2) // 32),
+                      lambda t, sp, wi: conv3x3(x, wi, bias, x2=x2, stride=stride, upsample=upsample, rowvec=rowvec, residual=residual,
+                                                out=out, out_planes=out_planes, extra=extra, pad_hi_only=pad_hi_only, tile=t, splits=sp), w)
+        hit = _plan_table().get(key)
+        if hit is not None and (hit[0] not in (11, 12) or halo_ok):
+            p.tile, p.splits = hit[0], hit[1]
+        elif halo_ok:
+            tiles, ncb = -(-M // 256) * (Cout // 80), (C1 + C2) // 32
+            sp = 1
+            while tiles * sp < 192 and sp * 2 <= ncb // 2 and sp < 16:       # cut K (whole channel blocks) until ~256 workgroups exist
+                sp *= 2
+            p.tile, p.splits = 11, sp
         else:
-            p.tile = 12 if upsample else 11
+            p.tile, p.splits = heuristic_plan(M, Cout, K, conv=True)        # (the table is keyed WITH the variant: no plain-key fallback)
+            if TILE_FORCE and TILE_FORCE < 10:
+                p.tile = TILE_FORCE
+    if p.tile in (11, 12):
+        if not halo_ok:
+            raise ValueError("planes.conv3x3: this geometry has no halo form (tile 11 / 12)")
+        p.tile = 12 if upsample else 11
+        p.splits = min(p.splits, (C1 + C2) // 32)
     ws = None
     if p.splits > 1:
         ws = torch.empty(p.splits * M * Cout, dtype=torch.float32, device=x.device)     # noqa: F841
         p.ws = ws.data_ptr()
     nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * ((1 if o32 is not None else 0) + (1 if op is not None else 0) + (1 if residual is not None else 0)))
-    with _Timed(f"igemm_x3p_kernel<true> t{p.tile}" + (f" {M}x{Cout}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
+    kn = f"conv3x3_halo_x3p_kernel<{'true' if upsample else 'false'}>" if p.tile in (11, 12) else f"igemm_x3p_kernel<true> t{p.tile}"
+    with _Timed(kn + (f" {M}x{Cout}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
         _check(lib.ief_gemm_x3p(byref(p), _stream()), "ief_gemm_x3p (conv)")
     return _ret(o32, op)
 
 
 # ---- producers: the normalisations and the attention kernels write operand planes for the GEMM that follows them
+GN_SMALL_ELEMS = int(os.environ.get("IEF_GN_SMALL_ELEMS", str(3 << 20)))      # GroupNorm inputs up to this many elements take one launch
+HALO = os.environ.get("IEF_X3P_HALO", "1") == "1"      # 0: every convolution on the implicit GEMM (A/B runs)
 ENABLED = os.environ.get("IEF_X3P", "1") == "1"        # 0: the f16x3 model keeps the in-kernel split everywhere (A/B runs)
 
 
@@ -320,6 +398,14 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out32=False):
     C2 = 0 if x2 is None else x2.shape[-1]
     HW = x.numel() // (B * C1)
     out = Planes.empty(*x.shape[:-1], C1 + C2, device=x.device)
+    cpg = (C1 + C2) // groups
+    if not out32 and B * HW * (C1 + C2) <= GN_SMALL_ELEMS and cpg % 2 == 0 and C1 % 2 == 0 and cpg // 2 <= 256:
+        # small tensors (the 16x16 / 8x8 levels): ONE launch instead of three dispatch latencies
+        with _Timed("groupnorm_f32_kernel", 0.0, 12.0 * (x.numel() + (0 if x2 is None else x2.numel()))):
+            _check(lib.ief_groupnorm_silu_x3p_small(x.data_ptr(), _ptr(x2), C1, C2, out.t.data_ptr(), out.plane,
+                                                    _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups,
+                                                    eps, 1 if silu else 0, _stream()), "ief_groupnorm_silu_x3p_small")
+        return out
     o32 = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float32, device=x.device) if out32 else None
     nws = lib.ief_groupnorm_f32_ws_floats(B, HW, C1 + C2)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)

@@ -337,6 +337,9 @@ int ief_layernorm_f32(const float* x, float* out, const float* gamma, const floa
 int ief_groupnorm_silu_x3p_ws(const float* x, const float* x2, int C1, int C2, float* out, ief_half* outp, long long plane,
                               const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu, float* ws,
                               long long ws_floats, void* stream);
+/* one launch (a few workgroups per (image, group), each streaming the group's slab for the statistics): small tensors */
+int ief_groupnorm_silu_x3p_small(const float* x, const float* x2, int C1, int C2, ief_half* outp, long long plane, const float* gamma,
+                                 const float* beta, int B, int HW, int groups, float eps, int silu, void* stream);
 int ief_layernorm_x3p(const float* x, ief_half* outp, long long plane, const float* gamma, const float* beta, long long rows, int C,
                       float eps, void* stream);
 int ief_add_f32(const float* a, const float* b, float* out, long long n, void* stream);

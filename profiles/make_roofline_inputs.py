@@ -35,6 +35,12 @@ def family(name: str) -> str:
             if args[0] == "true":
                 return base + "<.., conv> (3x3 implicit-GEMM convolution)"
             return base + "<.., linear> (linear / 1x1)"
+    if name.startswith("igemm_x3p_kernel"):
+        if name.rstrip(">").endswith("true"):
+            return "conv3x3 on operand planes (conv3x3_halo_x3p_kernel + igemm_x3p_kernel<.., conv>)"
+        return "igemm_x3p_kernel<.., linear> (linear / 1x1 on operand planes, LDS-DMA staged)"
+    if name.startswith("conv3x3_halo_x3p_kernel"):
+        return "conv3x3 on operand planes (conv3x3_halo_x3p_kernel + igemm_x3p_kernel<.., conv>)"
     if name.startswith("attn_flash"):
         return name.split("<")[0] + "<..> (self-attention, all head dims)"
     return name
@@ -66,7 +72,8 @@ def main():
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     entry = {}
     for k, (calls, ns) in fam.items():
-        e = {"launches_in_trace": calls, "avg_launch_us_rocprof": round(ns / calls / 1e3, 3), "source": os.path.basename(path)}
+        e = {"launches_in_trace": calls, "avg_launch_us_rocprof": round(ns / calls / 1e3, 3), "total_us_rocprof": round(ns / 1e3, 1),
+             "source": os.path.basename(path)}
         hit = [v for kk, v in pmc.items() if not kk.startswith("_") and v.get("family") == k]
         if hit:
             e["hbm_bytes_per_launch"] = hit[0]["hbm_bytes"]

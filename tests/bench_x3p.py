@@ -83,6 +83,10 @@ def main():
                 us_old = hip._time_graph(lambda i: hip.conv3x3(x, wc[i % len(wc)], x2=x2, stride=stride, upsample=ups, extra=extra))
                 line = f"conv {H:3d}x{W:3d} {C1:4d}+{C2:4d}->{Cout:4d} s{stride} u{int(ups)} e{CE1 + CE2:4d}  old {us_old:7.1f} us {fl / us_old / 1e6:6.1f} TF |"
                 for t in tiles:
+                    if t in (11, 12):
+                        if stride != 1 or CE1 or (ups and (H * 2) * (W * 2) % 256) or (not ups and W > 64):
+                            continue
+                        t = 12 if ups else 11
                     bm, bn = planes._TILES[t]
                     if Cout % bn:
                         continue

@@ -132,11 +132,16 @@ def _conv_ref(x, w, bias, x2=None, stride=1, upsample=False, pad_hi_only=False):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 11])
 @pytest.mark.parametrize("case", ["plain", "concat", "stride2", "upsample", "pad_hi", "odd"])
 def test_conv_x3p(case, tile):
+    """tile 11 = the halo form (super-tile resident across the nine taps; 12 with the fused nearest-2x): plain / concat / odd sizes"""
+    if tile == 11 and case in ("stride2", "pad_hi"):
+        pytest.skip("the halo form covers stride 1 / pad 1 only")
     B, H, W, C1, Cout = 2, 16, 16, 64, 160
     kw, C2 = {}, 0
+    if tile == 11 and case == "upsample":
+        tile = 12
     if case == "concat":
         C2 = 32
     elif case == "stride2":
@@ -192,6 +197,26 @@ def test_gemm_x3p_widths_of_64(M, N, K):
     assert e < XTOL
     x, wc = f32(2, 16, 16, 64, seed=4), f32(128, 3, 3, 64, seed=5, scale=0.04)
     assert rel_err(planes.conv3x3(planes.split(dev(x)), dev(wc)), _conv_ref(x, wc, None)) < XTOL
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,ups,splits", [(4, 64, 64, 320, 0, 320, False, 1), (2, 32, 32, 640, 320, 640, False, 2),
+                                                          (4, 16, 16, 1280, 0, 1280, False, 4), (3, 8, 8, 1280, 0, 1280, False, 8),
+                                                          (2, 24, 40, 64, 32, 80, False, 1), (2, 32, 32, 640, 0, 640, True, 1),
+                                                          (4, 8, 8, 1280, 0, 1280, True, 4), (1, 64, 64, 320, 0, 320, True, 1)])
+def test_conv_halo_x3p_real_shapes(B, H, W, C1, C2, Cout, ups, splits):
+    """the halo form at the UNet's real geometries (tile edges inside images, rows of 8 .. 128 pixels, split-K over channel blocks)
+    against the implicit GEMM of the same mode (both <= 4e-6 of fp64 on the small cases above) and fp64 on one image"""
+    x, w = f32(B, H, W, C1, seed=1), f32(Cout, 3, 3, C1 + C2, seed=2, scale=(9 * (C1 + C2)) ** -0.5)
+    x2 = f32(B, H, W, C2, seed=3) if C2 else None
+    bias = f32(Cout, seed=4, scale=0.1)
+    xp, x2p = planes.split(dev(x)), (planes.split(dev(x2)) if C2 else None)
+    halo = planes.conv3x3(xp, dev(w), dev(bias), x2=x2p, upsample=ups, tile=12 if ups else 11, splits=splits)
+    ig = planes.conv3x3(xp, dev(w), dev(bias), x2=x2p, upsample=ups, tile=1)
+    e = rel_err(halo, ig)
+    ref = _conv_ref(x[:1], w, bias, None if x2 is None else x2[:1], upsample=ups)
+    e64 = rel_err(halo[:1], ref)
+    print(f"halo x3p {B}x{H}x{W} {C1}+{C2}->{Cout} ups={ups} s{splits}: {e:.2e} vs implicit GEMM, {e64:.2e} vs fp64")
+    assert e < XTOL and e64 < XTOL
 
 
 def test_sd15_shapes_x3p_full_size():
