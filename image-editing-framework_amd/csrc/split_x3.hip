@@ -640,13 +640,18 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     constexpr int DT = (D + 31) / 32;            // 32-row tiles of O^T
     constexpr int KLD = DG * 16 + 8;             // halves per K row (bytes = 16 mod 32: conflict-free b128 fragments)
     constexpr int KT = 32 * KS;                  // keys per iteration
-    constexpr int VLD = KT + 4;                  // halves per V^T row
+    // V stays ROW-major in LDS ([key][VRS] per plane, 8-byte stores of four head-dim values): the V^T fragments of O^T += V^T P^T
+    // come from TRANSPOSING reads (ds_read_b64_tr_b16, as the fp16 kernel csrc/attention.hip) -- the former [d][key] image was
+    // written by 16-bit scatter stores whose bank conflicts were 29 % of the LDS-active cycles (profiles/r03_pmc_sq_x3.txt).
+    // Row stride 64 or 192 (mod 256) bytes: the four rows a 32-lane half touches fall into distinct 64-byte bank slots.
+    constexpr int VRS = D <= 32 ? 32 : (D <= 96 ? 96 : 160);
+    static_assert(VRS >= 32 * DT, "V row covers the padded head dim");
     constexpr float SQ = 1.f, SK = 1.f, SV = 1.f, SP = 16384.f;     // activations: scale 1 (the fp16 range itself); maps <= 1: 2^14
-    __shared__ __attribute__((aligned(16))) half_t smem_f[2 * KT * KLD + 2 * DT * 32 * VLD];
+    __shared__ __attribute__((aligned(16))) half_t smem_f[2 * KT * KLD + 2 * KT * VRS];
     half_t* Kh = smem_f;
     half_t* Kl = Kh + KT * KLD;
-    half_t* Vh = Kl + KT * KLD;                  // [DT*32][VLD]
-    half_t* Vl = Vh + DT * 32 * VLD;
+    half_t* Vh = Kl + KT * KLD;                  // [KT][VRS]
+    half_t* Vl = Vh + KT * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // (head, query block) from the XCD-contiguous logical id: the query blocks of one head run on ONE XCD, whose L2 then
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     half_t* OP = p.OutP ? p.OutP + (long long)b * p.sOPb + (long long)h * D : nullptr;
     const int q0 = qb * 128 + wid * 32;
     const int qi = q0 + li;
-    // zero the LDS once: padding columns of K (d >= D) and padding rows of V^T stay zero (staging never writes them)
+    // zero the LDS once: padding columns of K (d >= D) and of V (d >= D, up to VRS) stay zero (staging never writes them)
     for (int c = tid; c < (int)(sizeof(smem_f) / 16); c += 256) ((f32x4*)smem_f)[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this lane's query, split: for every 16-deep d group the 8 values d = 16 g + 8 lh + j
     half8_t qh[DG], ql[DG];
@@ -712,14 +717,13 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
                 *(half4*)(Kh + row * KLD + ch * 4) = hh;
                 *(half4*)(Kl + row * KLD + ch * 4) = ll;
                 split4(rv[i], SV, hh, ll);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    Vh[(ch * 4 + j) * VLD + row] = hh[j];
-                    Vl[(ch * 4 + j) * VLD + row] = ll[j];
-                }
+                *(half4*)(Vh + row * VRS + ch * 4) = hh;
+                *(half4*)(Vl + row * VRS + ch * 4) = ll;
             }
         }
     };
+    const int L16 = lane & 15;
+    const int v_lane = (4 * lh + (L16 >> 2)) * VRS + 16 * ((lane >> 4) & 1) + 4 * (L16 & 3);      // transposing V reads
     const int nt = (p.L + KT - 1) / KT;
     load_kv(0);
     for (int t = 0; t < nt; ++t) {
@@ -747,21 +751,30 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
         // are masked only in the tile that crosses L, exp2 is the bare v_exp_f32 (arguments <= 0: the library form's
         // denormal-range rescue costs five instructions per call and guards results that round to 0 here anyway), and the
         // accumulators are rescaled only when some lane's running maximum moved (alpha == 1 exactly otherwise)
-        float mx = -INFINITY;
+        // (the scale rides in the exponent's FMA: exp2(s sc2 - m) is one v_fma + one v_exp per score; the maximum is taken on the raw
+        // scores -- sc2 > 0 -- by v_max3 over the two sub-tiles)
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
-            if (t * KT + (u + 1) * 32 > p.L) {    // wave-uniform
+            if (t * KT + (u + 1) * 32 > p.L) {    // wave-uniform: only the tile that crosses L is masked
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * KT + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    sacc[u][r] = key < p.L ? sacc[u][r] * sc2 : -INFINITY;
-                    mx = fmaxf(mx, sacc[u][r]);
+                    if (key >= p.L) sacc[u][r] = -INFINITY;
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[u][r] *= sc2; mx = fmaxf(mx, sacc[u][r]); }
             }
         }
+        float mxa = -INFINITY, mxb = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (KS == 2) {
+                mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, sacc[0][r]), sacc[KS - 1][r]);
+                mxb = __builtin_fmaxf(__builtin_fmaxf(mxb, sacc[0][8 + r]), sacc[KS - 1][8 + r]);
+            } else {
+                mxa = __builtin_fmaxf(mxa, sacc[0][r]);
+                mxb = __builtin_fmaxf(mxb, sacc[0][8 + r]);
+            }
+        }
+        float mx = fmaxf(mxa, mxb) * sc2;
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // exp2(-inf) = 0 on the first tile
@@ -769,7 +782,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
 #pragma unroll
         for (int u = 0; u < KS; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(sacc[u][r] - m_new); ls += sacc[u][r]; }
+            for (int r = 0; r < 16; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][r], sc2, -m_new)); ls += sacc[u][r]; }
         l_run = l_run * alpha + ls;
         if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
 #pragma unroll
@@ -794,11 +807,11 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
                 }
 #pragma unroll
                 for (int tt = 0; tt < DT; ++tt) {
-                    const half_t* vr = Vh + (tt * 32 + li) * VLD + u * 32 + 16 * s + 4 * lh;
-                    const half_t* vq = Vl + (tt * 32 + li) * VLD + u * 32 + 16 * s + 4 * lh;
+                    // fragment = head-dim rows 32 tt .., keys {4 lh .. + 3} and {8 + 4 lh .. + 3} of this 16-key step
+                    const int vo = v_lane + (u * 32 + 16 * s) * VRS + 32 * tt;
+                    const half4 a0 = x3_lds_tr_read(Vh + vo), a1 = x3_lds_tr_read(Vh + vo + 8 * VRS);
+                    const half4 b0 = x3_lds_tr_read(Vl + vo), b1 = x3_lds_tr_read(Vl + vo + 8 * VRS);
                     half8_t vh, vl;
-                    const half4 a0 = *(const half4*)vr, a1 = *(const half4*)(vr + 8);
-                    const half4 b0 = *(const half4*)vq, b1 = *(const half4*)(vq + 8);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
                     o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[tt], 0, 0, 0);

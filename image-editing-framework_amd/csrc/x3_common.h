@@ -38,4 +38,14 @@ __device__ __forceinline__ void split4(const f32x4 v, const float s, half4& hi, 
     lo = half4{l0[0], l0[1], l1[0], l1[1]};
 }
 
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of halves, delivered column-major (lane i of the group gets
+// column i of the 4 rows); every lane passes the address of row (L >> 2), columns 4 (L & 3) .. of ITS group's block (L = lane & 15).
+// EXEC must be all ones.
+typedef __fp16 x3_fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) x3_fp16x4_t x3_lds_fp16x4_t;
+__device__ __forceinline__ half4 x3_lds_tr_read(const half_t* p) {
+    const x3_fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((x3_lds_fp16x4_t*)p);
+    return __builtin_bit_cast(half4, v);
+}
+
 enum { X3_LIN = 0, X3_LIN_SLOW = 1, X3_CONV = 2, X3_CONV_UPS = 3, X3_CONV_SLOW = 4 };

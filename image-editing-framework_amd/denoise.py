@@ -30,6 +30,16 @@ _POOL: Dict[tuple, list] = {}
 _POOL_CAP = 8
 
 
+def _check_finite(lat, unet):
+    """one host sync per finished loop: the fp16-operand modes ("f16", "f16x3") represent operand elements up to 65504; an
+    activation beyond that becomes inf in its hi half and the output NaN -- say so instead of handing NaN images on"""
+    if not bool(torch.isfinite(lat).all()):
+        mode = getattr(unet, "precision", "f16")
+        hint = ("an operand left the fp16 range (|x| > 65504): run this model with precision=\"f32\" (IEF_PRECISION=f32 / --precision f32), "
+                "the fp32-input MFMA has the fp32 range" if mode != "f32" else "check the inputs / weights")
+        raise FloatingPointError(f"non-finite latents after the denoising loop (precision={mode}): {hint}")
+
+
 class FusedDenoiser:
     def __init__(self, model, context: torch.Tensor, num_latents: int, latent_hw, guidance_scale: Optional[float],
                  mode: str = "denoise", uncond_list: Optional[List[torch.Tensor]] = None, use_graph: bool = True,
@@ -235,6 +245,7 @@ class FusedDenoiser:
             if keep_all:
                 traj.append(self.lat.clone())
         out = self.lat.clone()
+        _check_finite(out, self.unet)
         return (out, traj) if keep_all else out
 
     def release(self):

@@ -677,7 +677,11 @@ class f32_contraction:
         return False
 
 
-_x3_planes = {}      # (data_ptr, shape) -> (weight tensor kept alive, its _version, planes fp16 [2, N, K])
+# (data_ptr, shape, scale) -> (weakref to the weight tensor, its _version, planes fp16 [2, N, K]).  The entry dies WITH the weight
+# (weakref.finalize): a model that is dropped frees its planes (they are as large as the weights).  A captured graph bakes the
+# planes' address in: an in-place update of a weight after capture would replace the entry and free planes the graph still
+# reads, so weights are immutable once a graph over them exists (the weight broadcast runs before any forward).
+_x3_planes = {}
 X3_FUSE_GEGLU = os.environ.get("IEF_X3_FUSE_GEGLU", "1") == "1"   # 0: FF1 writes its pre-activation, ief_geglu_il_f32 follows (A/B)
 X3_PRESPLIT = os.environ.get("IEF_X3_PRESPLIT", "1") == "1"       # 0: split the weights in every launch, like the activations
 
@@ -689,7 +693,7 @@ def x3_weight_planes(w, scale=None):
     scale = X3_SCALE_W if scale is None else scale
     key = (w.data_ptr(), tuple(w.shape), float(scale))
     hit = _x3_planes.get(key)
-    if hit is not None and hit[0] is w and hit[1] == w._version:
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
         return hit[2]
     if _capturing() or w.numel() % 4 or not w.is_contiguous():
         return None
@@ -697,7 +701,9 @@ def x3_weight_planes(w, scale=None):
     n = w.shape[0]
     planes = torch.empty(2, n, w.numel() // n, dtype=torch.float16, device=w.device)
     _check(lib.ief_x3_split_weights(w.data_ptr(), planes.data_ptr(), w.numel(), float(scale), _stream()), "ief_x3_split_weights")
-    _x3_planes[key] = (w, w._version, planes)
+    import weakref
+    _x3_planes[key] = (weakref.ref(w), w._version, planes)
+    weakref.finalize(w, _x3_planes.pop, key, None)
     return planes
 
 

@@ -54,8 +54,9 @@ def main(argv=None):
         for category in CATEGORIES:
             items += PIE(args.dataset_path, None, category=category).items
     mine = list(range(rank, len(items), world))
-    writer = PngWriter()          # PNG encoding on host threads: the GPU loop never waits for a file
-    try:                           # the pool is drained (and a failed write reported) even if the GPU loop raises
+    # PNG encoding on host threads: the GPU loop never waits for a file; the context manager drains the pool when the loop
+    # raises too, WITHOUT letting a failed write replace the loop's own exception (PngWriter.__exit__)
+    with PngWriter() as writer:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in mine:
@@ -68,8 +69,6 @@ def main(argv=None):
                 writer.save_pil(original, os.path.join(out_path, "source.png"))
                 writer.save_img(images[0], os.path.join(out_path, "inversion.png"))
                 writer.save_img(images[1], os.path.join(out_path, "edit.png"))
-    finally:
-        writer.close()                # the timing includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

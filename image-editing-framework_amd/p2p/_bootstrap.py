@@ -25,10 +25,13 @@ def seed_everything(seed: int):
 
 def load_pipe(sd_version: str, device: torch.device, dtype=torch.float32, precision=None):
     """the loader switch of `/root/reference/p2p/edit_syn.py:58-86` for the versions this tier supports.
-    precision: "f16" (default; fp16 storage, fp32 accumulation) or "f32" — the reference's own precision (its CLIs load the
-    pipeline with torch_dtype=float32, :38): fp32 weights / activations on the fp32-MFMA kernels.  `--precision` of the
-    CLIs, or the IEF_PRECISION environment variable for the folders whose CLIs do not carry the flag."""
-    precision = precision or os.environ.get("IEF_PRECISION", "f16")
+    precision (`--precision` of the P2P CLIs, the IEF_PRECISION environment variable for the folders whose CLIs do not carry the
+    flag): the reference computes in fp32 in EVERY folder (`/root/reference/p2p/edit_syn.py:38`, `masactrl/edit_syn.py:38`,
+    `pnp/edit_syn.py:39-40`, `pix2pix-zero/model/sd_utils.py:28`), so the default of all four folders is "f16x3" -- fp32
+    storage, every contraction on split fp16 operands: the fastest mode inside north_star's 1e-3 image bound; "f32" = the
+    fp32-input MFMA; "f16" = fp16 storage (3e-3 on a 50-step image: outside the bound, 2x the speed).  Exception: the SDXL
+    family defaults to "f16", the precision BASELINE.json states for its configuration 5 (measured image error: DESIGN.md §4)."""
+    precision = precision or os.environ.get("IEF_PRECISION") or ("f16" if sd_version in ("xl-base", "smallxl") else "f16x3")
     # multi-GPU runs (the PIE drivers under torchrun): rank 0 loads / draws the weights, the others build the same module
     # tree from zeros and receive the packed tensors by ONE bucketed broadcast (RCCL over xGMI) -- `dist.broadcast_pipeline`
     import torch.distributed as tdist

@@ -161,8 +161,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
 
-    writer = PngWriter()          # encodes / writes on host threads: the GPU loop never waits for a file
-    try:                           # the pool is drained (and a failed write reported) even if the GPU loop raises
+    # PNG encoding on host threads: the GPU loop never waits for a file; the context manager drains the pool when the loop
+    # raises too, WITHOUT letting a failed write replace the loop's own exception (PngWriter.__exit__)
+    with PngWriter() as writer:
 
         def save(image_path, original, images):
             if args.no_save:
@@ -175,8 +176,6 @@ def main(argv=None):
 
         run_items(pipe, editor, invertor, [items[i] for i in mine], size, device, args.inversion_type, args.invert_batch,
                   args.in_flight, save)
-    finally:
-        writer.close()                # the timing below includes the last files
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n = torch.tensor([float(len(mine)), dt], device=device)

@@ -414,3 +414,58 @@ def test_cross_attention_p2p_edit_fused_x3(heads, N, L, d, monkeypatch):
     e, em = rel_err(out, ref), rel_err(mat, ref)
     print(f"cross-attention + P2P edit fused N={N} L={L} d={d}: {e:.2e} vs fp64 (materialised form {em:.2e})")
     assert out.dtype == torch.float32 and e < XTOL and em < XTOL
+
+
+@pytest.mark.parametrize("equalizer", [5.0, 10.0, 40.0])
+def test_cross_attention_reweight_large_equalizer_x3(equalizer, monkeypatch):
+    """AttentionReweight lowers to c1 = alpha * equalizer (`/root/reference/p2p/model/attention_control.py:42-46`): the edited map
+    P' = c1 T + c2 P reaches `equalizer` on a peaky source row.  With the fixed map scale 2^14 the hi half of P' overflowed
+    fp16 at P' >= 4 (inf - inf = NaN for the whole image); the scale now comes from the plan's coefficient bound
+    (`hip.map_split_scale`), in the fused kernel and in the materialised form."""
+    heads, N, L, d, B = 2, 256, 77, 40, 4
+    C = heads * d
+    q, k, v = f32(B, N, C, seed=1), f32(B, L, C, seed=2, scale=1.5), f32(B, L, C, seed=3)
+    k[0, 7] = q[0, :, :].mean(0) * 0 + 3.0 * torch.sign(f32(C, seed=9))          # a key that dominates many source rows: maps near 1
+    q[0] = q[0] + 2.0 * torch.sign(f32(C, seed=9))
+    mt, coef = torch.zeros(1, 96, 96), torch.zeros(1, 2, 96)
+    mt[0, :L, :L] = torch.eye(L)
+    coef[0, 0, :L] = 1.0
+    coef[0, 0, 7] = equalizer
+    es, sl = torch.tensor([-1, 0, -1, 0], dtype=torch.int32), torch.zeros(B, dtype=torch.int32)
+    qh = q.double().reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    P = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1)
+    assert P[0, :, :, 7].max() > 0.8, "the source map must be peaky for the test to mean anything"
+    Pe = P.clone()
+    for b in (1, 3):
+        Pe[b] = coef[0, 0, :L].double() * P[0]
+    ref = (Pe @ vh).permute(0, 2, 1, 3).reshape(B, N, C).float()
+    bound = float((coef[:, 0].abs() + coef[:, 1].abs()).max())
+    args = (dev(q), dev(k), dev(v), heads, d ** -0.5, dev(es), dev(sl), dev(mt), dev(coef))
+    out = hip.attn_cross_p2p(*args, coef_bound=bound)
+    monkeypatch.setattr(hip, "X3_FUSE_CROSS", False)
+    mat = hip.attn_cross_p2p(*args, coef_bound=bound)
+    e, em = rel_err(out, ref), rel_err(mat, ref)
+    print(f"reweight equalizer {equalizer}: max P' {Pe.max():.2f}, map split scale {hip.map_split_scale(bound):.0f}: fused {e:.2e}, "
+          f"materialised {em:.2e} vs fp64")
+    assert e < XTOL and em < XTOL
+
+
+def test_x3_activations_of_2e4_stay_finite_and_exact():
+    """the activation scale of the split is 1 (the fp16 range itself, 65504; it was 4: NaN beyond 16376): operands of ~2e4 go
+    through the in-kernel split, the planes GEMM and the fused attention and stay as exact as O(1) operands"""
+    from ief_amd import planes
+    a, w = f32(300, 320, seed=1, scale=6e3), f32(160, 320, seed=2, scale=0.05)
+    assert a.abs().max() > 2e4
+    ref = a.double() @ w.double().t()
+    e_old = rel_err(hip.gemm(dev(a), dev(w)), ref.float())
+    e_new = rel_err(planes.gemm(planes.split(dev(a)), dev(w)), ref.float())
+    print(f"operands up to {a.abs().max():.3g}: in-kernel split {e_old:.2e}, planes {e_new:.2e}")
+    assert e_old < XTOL and e_new < XTOL
+    B, heads, N, d = 1, 2, 256, 40
+    q, k, v = f32(B, N, heads * d, seed=3, scale=0.5), f32(B, N, heads * d, seed=4, scale=0.5), f32(B, N, heads * d, seed=5, scale=6e3)
+    out = hip.attn_flash(dev(q), dev(k), dev(v), heads, d ** -0.5)
+    qh, kh, vh = (t.double().reshape(B, N, heads, d).permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(B, N, heads * d)
+    assert rel_err(out, ref.float()) < XTOL
