@@ -129,6 +129,8 @@ def parse():
                     "GPU, which RCCL refuses: rehearsals of the N > 1 paths on a one-GPU box)")
     ap.add_argument("--pie-images", type=int, default=8, help="synthetic PIE images timed per GPU for images_per_sec (0: skip)")
     ap.add_argument("--steps-1024", type=int, default=10, help="timed edit steps on 128x128 latents (0: skip)")
+    ap.add_argument("--nti-images", type=int, default=1, help="BASELINE.json configs[1]: synthetic images timed through null-text "
+                    "inversion + edit in the headline mode (0: skip)")
     return ap.parse_args()
 
 
@@ -330,6 +332,9 @@ def main():
         # BASELINE.json's second metric: PIE-Bench images/sec (reference per-image order, then the batched schedule)
         if full and args.pie_images > 0 and not cfg.addition_embed:
             res.update(pie_images_per_sec(pipe_m, dev, rank, world, dist, barrier, args.pie_images))
+        # BASELINE.json configs[1] (edit_real.py --inversion_type null-text): the optimisation's inner iteration and a whole image
+        if full and args.nti_images > 0 and not cfg.addition_embed and hw == cfg.sample_size:
+            res["null_text"] = null_text_numbers(pipe_m, cfg, dev, rank, world, dist, barrier, args.nti_images)
         return res, job
 
     # ---- headline mode
@@ -460,6 +465,59 @@ def pie_images_per_sec(pipe, dev, rank, world, dist, barrier, n):
                             "self 0.6, PNGs not written; images_per_sec = reference per-image order, images_per_sec_batched = "
                             "--invert_batch 4 --in_flight 4 (identical pixels)")
     return res
+
+
+def null_text_numbers(pipe, cfg, dev, rank, world, dist, barrier, n):
+    """config 2: (a) one inner iteration of `NTI.null_optimization` (`/root/reference/p2p/inversion/nti.py:15-33`: UNet forward at
+    batch 1 keeping the adjoint's inputs, the objective, the activation-gradient pass, Adam) from its captured graph; (b) images/s of
+    the PIE loop with `--inversion_type null-text` (VAE encode, 50-step DDIM inversion, up to 50 x 10 inner iterations with the
+    reference's early stop, 50-step edit with the per-step embeddings, VAE decode) on n synthetic images per GPU, one at a time"""
+    import importlib.util
+    import tempfile
+    from ief_amd.nti import NullTextOptimizer
+    hw = cfg.sample_size
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.1
+    lats = [torch.randn(1, 4, hw, hw, generator=g) for _ in range(51)]
+    opt = NullTextOptimizer(pipe, ctx[1:], 7.5, (hw, hw), use_graph=True)
+    opt.run(lats, ctx[:1], 1, 0.0, num_outer=1)          # capture + warm-up
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    iters = 20
+    ev[0].record()
+    for _ in range(iters):
+        opt._run(1)
+    ev[1].record()
+    torch.cuda.synchronize()
+    inner_ms = ev[0].elapsed_time(ev[1]) / iters
+    opt.release()
+    pdir = os.path.join(ROOT, "image-editing-framework_amd", "p2p")
+    if pdir not in sys.path:
+        sys.path.insert(0, pdir)
+    spec = importlib.util.spec_from_file_location("ief_p2p_pie_driver_nti", os.path.join(pdir, "test.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    from ief_amd.p2p.dataset.pie import SyntheticPIE
+    from ief_amd.p2p.inversion.nti import NTI
+    from ief_amd.p2p.model.sd_utils import P2P_NTI
+    size = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    root = tempfile.mkdtemp(prefix=f"ief_bench_nti_r{rank}_")
+    items = list(SyntheticPIE(root, n + 1, size=size, seed=100 + rank).items)
+    editor, invertor = P2P_NTI(model=pipe, num_inference_steps=MAX_STEPS), NTI()
+    drv.run_items(pipe, editor, invertor, items[:1], size, dev, "null-text")          # untimed: captures / pools the graphs
+    barrier()
+    t0 = time.perf_counter()
+    drv.run_items(pipe, editor, invertor, items[1:], size, dev, "null-text")
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([dt], device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dt = te.item()
+    return {"nti_inner_ms": round(inner_ms, 3), "inner_iterations_per_s": round(1000.0 / inner_ms, 2),
+            "images_per_sec_null_text": round(world * n / dt, 4), "seconds_per_image": round(dt / n, 2),
+            "config": f"{n} synthetic {size}x{size} image(s) per GPU after one untimed image, edit_real.py --inversion_type null-text: 50 "
+                      "timesteps x up to 10 inner Adam iterations (early stop as `/root/reference/p2p/inversion/nti.py:31-33`), UNet batch 1"}
 
 
 def _family(kernel_name: str) -> str:

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
     if (wave >= NW) {
         // ------------------------------------------------------------------------------------------------ loader waves
         const int l = wave - NW;
+        bool abl_prologue = true;                 // (ablation builds only: XP_ABL & 1 keeps the prologue's LDS-DMA, drops the loop's)
         const unsigned st_chunk = (unsigned)(XP_LANE_CHUNK(lane) * 16);
         const int ms_lane = st_row0 + (lane >> 2);
         const char* an_src = zp; long long an_pl = 0; unsigned an_cs = 0, an_c0 = 0; bool an_on = false;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
             const int ms = ms_lane + 16 * q;
             const bool ok = exists && an_on && (unsigned)ms < (unsigned)src_pixels;
             const char* g = ok ? an_src + ((long long)pl * an_pl + (long long)((unsigned)ms * an_cs + an_c0) * 2 + st_chunk) : zp;
-            glds16(g, (half_t*)(smem + (exists ? pl * AD + buf_off + q * 1024 : DUMP)));
+            if (!(XP_ABL & 1) || abl_prologue) glds16(g, (half_t*)(smem + (exists ? pl * AD + buf_off + q * 1024 : DUMP)));
         };
         const long long w_lane = (long long)(n0 + (lane >> 2)) * p.K * 2 + st_chunk;
         auto issue_b = [&](int cb, int tap, bool on, int slot_off) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
                 const int pl = v >= NPB ? 1 : 0, q = v - pl * NPB;
                 const bool ok = exists && on && n0 + 16 * q + (lane >> 2) < p.N;
                 const char* g = ok ? (const char*)p.W + ((long long)pl * p.planeW * 2 + w_lane + (long long)(16 * q) * p.K * 2 + k0) : zp;
-                glds16(g, (half_t*)(smem + (exists ? BOFF + slot_off + pl * BPL + q * 1024 : DUMP)));
+                if (!(XP_ABL & 1) || abl_prologue) glds16(g, (half_t*)(smem + (exists ? BOFF + slot_off + pl * BPL + q * 1024 : DUMP)));
             }
         };
         auto n_issued = [](int tap) constexpr -> int { return 3 + (tap < ATAPS ? APT : 0); };
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
             asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             XP_BARRIER();
         }
+        abl_prologue = false;
         int bs_prev = 4 * BBUF, bs = 0, bs_next = BBUF;
         for (int cbi = 0; cbi < nblk; ++cbi) {
             const int cb = cb_lo + cbi;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
             const int steps_left = nsteps - cbi * 9;
             auto one_step = [&](auto tap_tag) {
                 constexpr int tap = decltype(tap_tag)::value;
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued((tap + 8) % 9) + n_issued((tap + 7) % 9)) : "memory");
+                if (!(XP_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_issued((tap + 8) % 9) + n_issued((tap + 7) % 9)) : "memory");
                 XP_BARRIER();
                 if constexpr (tap < ATAPS) {
 #pragma unroll
@@ -180,7 +182,9 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
         return (a_edge[i] & tmask) ? ZA : ad;
     };
     half8 ah[2][TM], al[2][TM], bh[TN], bl[TN];
+    bool abl_read_done = false;                   // (ablation builds only: XP_ABL & 2 keeps the first fragment reads, drops the loop's)
     auto read_a = [&](half8 (&h)[TM], half8 (&l)[TM], int abuf, int ky, int kx) {
+        if ((XP_ABL & 2) && abl_read_done) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int ad = a_addr(i, abuf, ky, kx);
@@ -214,9 +218,12 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[PAR][i], acc[j][i], 0, 0, 0);
             }
             // this block's weight fragments of step t + 1 take the registers just consumed
-            bh[j] = *(const half8*)(smem + bs_next + b_off[j]);
-            bl[j] = *(const half8*)(smem + bs_next + b_off[j] + BPL);
+            if (!(XP_ABL & 2)) {
+                bh[j] = *(const half8*)(smem + bs_next + b_off[j]);
+                bl[j] = *(const half8*)(smem + bs_next + b_off[j] + BPL);
+            }
         }
+        abl_read_done = true;
         bs_next = bs_next == (NSB - 1) * BBUF ? 0 : bs_next + BBUF;
     };
     for (int cbi = 0; cbi < nblk; cbi += 2) {

@@ -458,9 +458,9 @@ __global__ __launch_bounds__(256) void attn_flash_f32_kernel(const IefAttnF32Par
 int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st);      // split_x3.hip
 
 extern "C" int ief_attn_flash_f32(const IefAttnF32Params* pp, void* stream) {
-    if (!pp || !pp->Q || !pp->K || !pp->V || (!pp->Out && !pp->OutP)) return IEF_EINVAL;
+    if (!pp || (!pp->Qp && (!pp->Q || !pp->K || !pp->V)) || (!pp->Out && !pp->OutP)) return IEF_EINVAL;
     const IefAttnF32Params p = *pp;
-    if (p.OutP && !p.x3) return IEF_EINVAL;              // operand planes are written by the split-operand kernel only
+    if ((p.OutP || p.Qp) && !p.x3) return IEF_EINVAL;    // operand planes are read / written by the split-operand kernels only
     if (!p.x3 && (!p.Out || (p.ldo & 3) || (p.sOb & 3))) return IEF_EINVAL;
     if (p.B <= 0 || p.heads <= 0 || p.N <= 0 || p.L <= 0) return IEF_ESHAPE;
     if ((p.ldq & 3) || (p.ldk & 3) || (p.ldv & 3) || (p.sQb & 3) || (p.sKb & 3) || (p.sVb & 3)) return IEF_EALIGN;

@@ -311,10 +311,13 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * WM + i * 16 + fr;
+            float mu = 0.f, rs = 1.f;
+            if (p.rstat_in && m < p.M) xp_ln_row(p, m, mu, rs);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nb = n0 + wc * WN + j * 16, n = nb + 4 * fq;
                 f32x4 v = acc[j][i] * inv;
+                if (p.rstat_in && n < p.N) v = (v - *(const f32x4*)(p.colsum + n) * mu) * rs;        // LayerNorm folded (x3p_common.h)
                 if (p.bias && n < p.N) v += *(const f32x4*)(p.bias + n);
                 f32x4 g;
 #pragma unroll
@@ -337,14 +340,31 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
         }
         return;
     }
+    const int slots_out = (p.N + WN - 1) / WN;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wr * WM + i * 16 + fr;
-        if (m >= p.M) continue;
+        const bool mok = m < p.M;
+        float mu = 0.f, rs = 1.f;
+        if (p.rstat_in && mok) xp_ln_row(p, m, mu, rs);
+        f32x4 vv[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wc * WN + j * 16 + 4 * fq;
-            if (n < p.N) xp_store(p, acc[j][i] * inv, m, n);
+            vv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mok && n < p.N) {
+                f32x4 v = acc[j][i] * inv;
+                if (p.rstat_in) v = (v - *(const f32x4*)(p.colsum + n) * mu) * rs;                    // LayerNorm folded
+                vv[j] = xp_store(p, v, m, n);
+            }
+        }
+        if (p.rstat_out) {        // (mean, M2) of this wave's WN-column slice of row m (host-checked: N % WN == 0): every lane shuffles
+            float sm, sq;
+            xp_row_stats<TN>(vv, sm, sq);
+            if (fq == 0 && mok && n0 + wc * WN < p.N) {
+                float* ro = p.rstat_out + ((long long)m * slots_out + (n0 + wc * WN) / WN) * 2;
+                ro[0] = sm; ro[1] = sq;
+            }
         }
     }
 }
@@ -406,6 +426,7 @@ extern "C" int ief_gemm_x3p_tile_bm(int tile) {
         default: return 0;
     }
 }
+extern "C" int ief_gemm_x3p_tile_wn(int tile) { return tile == 6 ? 64 : 80; }
 extern "C" int ief_gemm_x3p_tile_bn(int tile) {
     switch (tile) {
         case 1: case 2: case 4: case 5: return 160;
@@ -441,6 +462,9 @@ extern "C" int ief_gemm_x3p(const IefGemmX3pParams* pp, void* stream) {
     if ((p.bias && ((uintptr_t)p.bias & 15)) || (p.rowvec && ((uintptr_t)p.rowvec & 15)) ||
         (p.residual && (((uintptr_t)p.residual & 15) || (p.ldr & 3)))) return IEF_EALIGN;
     if (p.geglu && ((p.N & 15) || p.residual || p.rowvec)) return IEF_EINVAL;
+    if (p.rstat_out && (p.splits > 1 || p.geglu || p.tile == 11 || p.tile == 12 || (p.N % ief_gemm_x3p_tile_wn(p.tile)))) return IEF_EINVAL;
+    if (p.rstat_in && (!p.colsum || p.rstat_slots <= 0 || p.rstat_cnt <= 0 || p.rstat_slots * p.rstat_cnt != p.K || p.splits > 1 ||
+                       p.conv || !(p.ln_eps > 0.f) || ((uintptr_t)p.colsum & 15))) return IEF_EINVAL;
     if (p.conv) {
         if (p.C1 <= 0 || p.C2 < 0 || (p.C1 % XP_BK) || (p.C2 % XP_BK) || (p.CE1 % XP_BK) || (p.CE2 % XP_BK)) return IEF_ESHAPE;
         if ((p.C2 > 0 && !p.A2) || (p.CE1 > 0 && !p.E1) || (p.CE2 > 0 && !p.E2) || (p.CE2 > 0 && p.CE1 == 0)) return IEF_EINVAL;

@@ -844,6 +844,233 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     }
 }
 
+
+// --------------------------------------------------------------------------------------------- fused attention on OPERAND PLANES
+// The same product as attn_flash_x3_kernel with Q / K / V arriving as pre-split hi / lo fp16 planes (written by the q|k|v GEMM's
+// epilogue, csrc/gemm_x3p.hip).  What that buys, measured on the fp32-input kernel at N = 4096, d = 40 (profiles/r04_pmc_attn40x3.txt):
+// every workgroup re-split the whole K / V of its head (20 % of the vector instructions) and kept the prefetched tiles in 24
+// registers, which held the kernel at 162 VGPRs = 3 workgroups per CU = 768 slots for 1024 workgroups: a second round one third
+// full.  Here K / V tiles are staged by LDS-DMA (global_load_lds, wave w stages plane w of {K hi, K lo, V hi, V lo}: no staging
+// registers, no split, no LDS stores), the kernel fits 128 VGPRs and 40 KiB of LDS: four workgroups per CU, one round.
+//   LDS: two buffers of [K hi | K lo | V hi | V lo], each KT rows of D halves, UNPADDED (an LDS-DMA piece is lane-linear); D = 64:
+//   16-byte chunk c of row r lives in slot c ^ (r & 7) (128-byte rows would otherwise put every row on the same banks); D = 40
+//   (80-byte rows) and D = 80 need none.  Nothing is read past a row: the score product's padding lanes (d >= D) and the
+//   transposing V reads of head-dim columns >= D take their address from column 0 -- their operand is multiplied by the zero
+//   padding of Q, respectively lands in output rows >= D that are never stored.
+//   One barrier per tile: [own DMA of tile t landed] barrier [issue tile t + 1 into the other buffer] scores, softmax, P V.
+//   NWV waves per workgroup (32 queries each).  d = 40: 8 waves / 256 queries: two workgroups (80 KiB of LDS, 16 waves) per CU --
+//   four 40-KiB workgroups of 4 waves are exactly the CU's 160 KiB and were NOT co-resident (measured: still a second round);
+//   a tile is then also staged once for 256 queries instead of 128.
+template <int D, int KS, int NWV>
+__global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kernel(const IefAttnF32Params p) {
+    constexpr int DG = (D + 15) / 16, DT = (D + 31) / 32;
+    constexpr int KT = 32 * KS;
+    constexpr int CPR = D / 8;                   // 16-byte chunks per row
+    constexpr int PL = KT * D;                   // halves per plane of a tile
+    constexpr int NP = PL * 2 / 1024;            // LDS-DMA pieces per plane
+    static_assert((PL * 2) % 1024 == 0, "a plane of a tile is a whole number of LDS-DMA pieces");
+    constexpr bool SWZ = D == 64;
+    constexpr float SP = 16384.f;
+    __shared__ __attribute__((aligned(1024))) half_t smem_p[2 * 4 * PL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int nqb = gridDim.x;
+    const int lid = xcd_remap(blockIdx.x + nqb * blockIdx.y, nqb * gridDim.y);
+    const int bh = lid / nqb, qb = lid - bh * nqb, b = bh / p.heads, h = bh - b * p.heads;
+    const int bq = p.q_src ? p.q_src[b] : b, bk = p.k_src ? p.k_src[b] : b, bv = p.v_src ? p.v_src[b] : b;
+    const half_t* Qh = p.Qp + (long long)bq * p.sQb + (long long)h * D;
+    // the four planes of a tile: 0 K hi, 1 K lo, 2 V hi, 3 V lo
+    const char* srcs[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+        srcs[pl] = (const char*)(pl < 2 ? p.Kp + (long long)bk * p.sKb + (pl & 1) * p.planeK
+                                        : p.Vp + (long long)bv * p.sVb + (pl & 1) * p.planeV) + (long long)h * D * 2;
+    const char* zp = (const char*)p.zeros;
+    float* O = p.Out ? p.Out + (long long)b * p.sOb + (long long)h * D : nullptr;
+    half_t* OP = p.OutP ? p.OutP + (long long)b * p.sOPb + (long long)h * D : nullptr;
+    const int q0 = qb * (32 * NWV) + wid * 32;
+    const int qi = q0 + li;
+    // the lane's query: for every 16-deep d group the 8 values d = 16 g + 8 lh + j, hi and lo straight from the planes
+    half8_t qh[DG], ql[DG];
+#pragma unroll
+    for (int g = 0; g < DG; ++g) {
+        const int d0 = g * 16 + 8 * lh;
+        if (qi < p.N && d0 < D) {
+            qh[g] = *(const half8_t*)(Qh + (long long)qi * p.ldq + d0);
+            ql[g] = *(const half8_t*)(Qh + p.planeQ + (long long)qi * p.ldq + d0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qh[g][j] = 0; ql[g][j] = 0; }
+        }
+    }
+    // staging: the 4 NP pieces of a tile are dealt round-robin to the waves; piece q = plane q / NP, chunks 64 (q % NP) + lane of it,
+    // chunk c -> (row c / CPR, 16-byte chunk c % CPR)
+    constexpr int NPW = (4 * NP + NWV - 1) / NWV;
+    int s_row[NPW];
+    unsigned s_off[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int q = wid + NWV * i, j = q % NP;
+        const int c = 64 * j + lane;
+        s_row[i] = c / CPR;
+        const int ch = c - s_row[i] * CPR;
+        s_off[i] = (unsigned)((SWZ ? (ch ^ (s_row[i] & 7)) : ch) * 16);     // the swizzle is applied to the chunk FETCHED for this LDS slot
+    }
+    auto issue = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int q = wid + NWV * i;                     // wave-uniform
+            if (q < 4 * NP) {
+                const int pl = q / NP, j = q - pl * NP;
+                const int row = t * KT + s_row[i];
+                const int ldr = pl < 2 ? p.ldk : p.ldv;
+                const char* g = row < p.L ? srcs[pl] + (long long)row * ldr * 2 + s_off[i] : zp;
+                x3_glds16(g, smem_p + buf * (4 * PL) + pl * PL + j * 512);
+            }
+        }
+    };
+    // fragment offsets (halves inside a plane of the tile)
+    int koff[DG];                                // K row li of a 32-key sub-tile, chunk 2 g + lh (clamped to chunk 0 in the d padding)
+#pragma unroll
+    for (int g = 0; g < DG; ++g) {
+        const int chunk = (g * 16 + 8 * lh < D) ? 2 * g + lh : 0;
+        koff[g] = li * D + (SWZ ? ((chunk ^ (li & 7)) << 3) : (chunk << 3));
+    }
+    const int L16 = lane & 15;
+    const int vrow = 4 * lh + (L16 >> 2);        // row of this lane's 8-byte granule inside a 16-key step
+    int voff[DT];
+#pragma unroll
+    for (int tt = 0; tt < DT; ++tt) {
+        int col = 32 * tt + 16 * ((lane >> 4) & 1) + 4 * (L16 & 3);
+        if (col >= D) col = 0;                   // feeds output rows >= D only (never stored)
+        voff[tt] = col;
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = p.scale * 1.44269504088896341f;      // scores in log2 units (operand scale 1)
+    const int nt = (p.L + KT - 1) / KT;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's plane of tile t has landed
+        __syncthreads();                                    // everybody's has; everybody is done with the other buffer
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const half_t* Kh = smem_p + (t & 1) * (4 * PL);
+        const half_t* Kl = Kh + PL;
+        const half_t* Vh = Kl + PL;
+        const half_t* Vl = Vh + PL;
+        f32x16 sacc[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < DG; ++g) {
+                const half8_t kh = *(const half8_t*)(Kh + u * 32 * D + koff[g]);
+                const half8_t kl = *(const half8_t*)(Kl + u * 32 * D + koff[g]);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g], sacc[u], 0, 0, 0);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc[u], 0, 0, 0);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc[u], 0, 0, 0);
+            }
+        }
+        // online softmax (register r <-> key (r & 3) + 8 (r >> 2) + 4 lh of its sub-tile), as attn_flash_x3_kernel
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            if (t * KT + (u + 1) * 32 > p.L) {    // wave-uniform: only the tile that crosses L is masked
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KT + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= p.L) sacc[u][r] = -INFINITY;
+                }
+            }
+        }
+        float mxa = -INFINITY, mxb = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (KS == 2) {
+                mxa = __builtin_fmaxf(__builtin_fmaxf(mxa, sacc[0][r]), sacc[KS - 1][r]);
+                mxb = __builtin_fmaxf(__builtin_fmaxf(mxb, sacc[0][8 + r]), sacc[KS - 1][8 + r]);
+            } else {
+                mxa = __builtin_fmaxf(mxa, sacc[0][r]);
+                mxb = __builtin_fmaxf(mxb, sacc[0][8 + r]);
+            }
+        }
+        float mx = fmaxf(mxa, mxb) * sc2;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][r], sc2, -m_new)); ls += sacc[u][r]; }
+        l_run = l_run * alpha + ls;
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+        }
+        m_run = m_new;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8_t ph, pl;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const f32x4 v = {sacc[u][8 * s2 + 4 * c2], sacc[u][8 * s2 + 4 * c2 + 1], sacc[u][8 * s2 + 4 * c2 + 2], sacc[u][8 * s2 + 4 * c2 + 3]};
+                    half4 hh, ll;
+                    split4(v, SP, hh, ll);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
+                }
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) {
+                    // keys {4 lh .. + 3} and {8 + 4 lh .. + 3} of this 16-key step: rows r0, r0 + 8 of the tile
+                    const int r0 = u * 32 + 16 * s2 + vrow;
+                    const int c = voff[tt];
+                    const int o0 = r0 * D + (SWZ ? ((((c >> 3) ^ (r0 & 7)) << 3) | (c & 7)) : c);
+                    const int o1 = (r0 + 8) * D + (SWZ ? ((((c >> 3) ^ ((r0 + 8) & 7)) << 3) | (c & 7)) : c);
+                    const half4 a0 = x3_lds_tr_read(Vh + o0), a1 = x3_lds_tr_read(Vh + o1);
+                    const half4 b0 = x3_lds_tr_read(Vl + o0), b1 = x3_lds_tr_read(Vl + o1);
+                    half8_t vh, vl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[tt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / (l_tot * SP);
+    if (qi < p.N) {
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = tt * 32 + 8 * g + 4 * lh;
+                if (d < D) {
+                    const f32x4 v = {o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv};
+                    if (O) *(f32x4*)(O + (long long)qi * p.ldo + d) = v;
+                    if (OP) {
+                        half4 hh, ll;
+                        split4(v, 1.0f, hh, ll);
+                        half_t* op = OP + (long long)qi * p.ldp + d;
+                        *(half4*)op = hh;
+                        *(half4*)(op + p.planeO) = ll;
+                    }
+                }
+            }
+    }
+}
+
 // called by ief_attn_flash_f32 (exact_f32.hip) after its argument checks when p.x3 != 0
 int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st) {
     if (p.Out && ((p.ldo & 3) || (p.sOb & 3) || ((uintptr_t)p.Out & 15))) return IEF_EALIGN;
@@ -851,6 +1078,20 @@ int ief_attn_flash_x3_dispatch(const IefAttnF32Params& p, hipStream_t st) {
     const unsigned long long lim = 0xFFFFFFF0ull;
     if (((unsigned long long)(p.L - 1) * p.ldk + p.d) * 4 >= lim || ((unsigned long long)(p.L - 1) * p.ldv + p.d) * 4 >= lim) return IEF_ESHAPE;
     dim3 grid((p.N + 127) / 128, p.B * p.heads);
+    if (p.Qp) {         // operand planes in: K / V tiles by LDS-DMA (attn_flash_x3p_kernel)
+        const dim3 grid8((p.N + 255) / 256, p.B * p.heads);
+        if (!p.Kp || !p.Vp || !p.zeros) return IEF_EINVAL;
+        if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.sQb & 7) || (p.sKb & 7) || (p.sVb & 7) || (p.planeQ & 7) || (p.planeK & 7) ||
+            (p.planeV & 7) || (((uintptr_t)p.Qp | (uintptr_t)p.Kp | (uintptr_t)p.Vp) & 15)) return IEF_EALIGN;
+        switch (p.d) {
+            case 40: hipLaunchKernelGGL((attn_flash_x3p_kernel<40, 2, 8>), grid8, dim3(512), 0, st, p); break;
+            case 64: hipLaunchKernelGGL((attn_flash_x3p_kernel<64, 1, 4>), grid, dim3(256), 0, st, p); break;
+            case 80: hipLaunchKernelGGL((attn_flash_x3p_kernel<80, 1, 4>), grid, dim3(256), 0, st, p); break;
+            default: return IEF_ESHAPE;
+        }
+        IEF_LAUNCH_CHECK();
+        return IEF_OK;
+    }
     // 64 keys per barrier pair where there are that many (self-attention); the 77-key cross maps keep 32 (3 tiles, not 2 x 64)
     const bool ks2 = g_flash_ks2 && p.L >= 128;
 #define FLASH_GO(D_) do { if (ks2) hipLaunchKernelGGL((attn_flash_x3_kernel<D_, 2>), grid, dim3(256), 0, st, p); \

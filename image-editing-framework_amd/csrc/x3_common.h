@@ -48,4 +48,9 @@ __device__ __forceinline__ half4 x3_lds_tr_read(const half_t* p) {
     return __builtin_bit_cast(half4, v);
 }
 
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses -> 1 KiB of LDS at a wave-uniform base
+__device__ __forceinline__ void x3_glds16(const char* g, half_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 enum { X3_LIN = 0, X3_LIN_SLOW = 1, X3_CONV = 2, X3_CONV_UPS = 3, X3_CONV_SLOW = 4 };

@@ -108,6 +108,8 @@ class IefAttnF32Params(Structure):
         ("q_src", c_void_p), ("k_src", c_void_p), ("v_src", c_void_p),
         ("x3", c_int),
         ("OutP", c_void_p), ("planeO", c_longlong), ("sOPb", c_longlong), ("ldp", c_int), ("p_scale", c_float),
+        ("Qp", c_void_p), ("Kp", c_void_p), ("Vp", c_void_p), ("planeQ", c_longlong), ("planeK", c_longlong), ("planeV", c_longlong),
+        ("zeros", c_void_p),
     ]
 
 
@@ -124,7 +126,8 @@ class IefGemmX3pParams(Structure):
         ("stride", c_int), ("ups", c_int), ("batch_images", c_int), ("pad_hi_only", c_int), ("CE1", c_int), ("CE2", c_int),
         ("rows_per_batch", c_int), ("out_scale", c_float), ("inv_scale", c_float),
         ("tile", c_int), ("splits", c_int), ("ws", c_void_p), ("geglu", c_int), ("zeros", c_void_p),
-        ("rstat_out", c_void_p), ("cstat_out", c_void_p),
+        ("rstat_out", c_void_p), ("cstat_out", c_void_p), ("rstat_in", c_void_p), ("colsum", c_void_p),
+        ("rstat_slots", c_int), ("rstat_cnt", c_int), ("ln_eps", c_float),
     ]
 
 
@@ -148,7 +151,7 @@ EXPORTS = [
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
     "ief_map_loss_rows_f32", "ief_nti_adam_f32g",
     # ABI 4: split-operand contractions on pre-split planes (csrc/gemm_x3p.hip)
-    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small",
+    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_gemm_x3p_tile_wn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small",
 ]
 
 
@@ -261,6 +264,7 @@ def load():
     lib.ief_gemm_x3p.argtypes = [POINTER(IefGemmX3pParams), c_void_p]
     lib.ief_gemm_x3p_tile_bm.argtypes = [c_int]
     lib.ief_gemm_x3p_tile_bn.argtypes = [c_int]
+    lib.ief_gemm_x3p_tile_wn.argtypes = [c_int]
     lib.ief_x3_split_act.argtypes = [c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_int, c_float, c_void_p]
     lib.ief_groupnorm_silu_x3p_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                               c_int, c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]

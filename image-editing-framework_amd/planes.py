@@ -236,11 +236,43 @@ def _ret(o32, op):
     return o32 if op is None else op
 
 
+class RowStats:
+    """(mean, M2) of every output row over each column slice of ONE launch (IefGemmX3pParams.rstat_out): what the next GEMM
+    needs to fold the LayerNorm between them into its epilogue"""
+    __slots__ = ("buf", "slots", "cnt")
+
+    def __init__(self, buf, slots, cnt):
+        self.buf, self.slots, self.cnt = buf, slots, cnt
+
+
+class FoldedLN:
+    """a linear with the LayerNorm that feeds it folded in (`/root/reference` computes norm(x) W^T + b with diffusers'
+    BasicTransformerBlock): weight W gamma, bias b + W beta, and colsum[n] = sum_k (W gamma)[n][k] AS THE OPERAND PLANES HOLD IT, so
+    that  LN(x) W^T + b = rstd (x (W gamma)^T - mean colsum) + (b + W beta)  is exact up to the products' own rounding"""
+    __slots__ = ("w", "bias", "colsum", "eps")
+
+    def __init__(self, w, bias, gamma, beta, eps):
+        wf = (w * gamma[None, :]).contiguous()
+        self.w = wf
+        b = w @ beta
+        self.bias = (b if bias is None else b + bias).contiguous()
+        pl = weight_planes(wf)
+        self.colsum = ((pl[0].float().sum(1) + pl[1].float().sum(1)) / W_SCALE).contiguous()
+        self.eps = eps
+
+
+LN_FOLD = os.environ.get("IEF_X3P_FOLD_LN", "0") == "1"      # 1: fold the transformer LayerNorms into their consumer GEMMs.  Measured
+# on the SD1.5 batch-4 step (same box): 14.86 ms folded vs 14.16 ms with the 48 LayerNorm launches -- every producer of the residual
+# stream then writes fp32 AND planes AND row statistics, its consumers lose their split-K plans: the launches saved cost less
+
+
 def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None, out_planes=None, out_scale=1.0,
-         geglu=False, tile=0, splits=0):
+         geglu=False, tile=0, splits=0, row_stats=False, ln=None):
     """(a . w^T + bias + rowvec + residual) * out_scale with a: Planes [..., K], w: fp32 weight [N, K] (its planes are cached).
     out: an fp32 tensor to write / True (allocate one) / None (allocate one unless planes are asked for) / False (none);
-    out_planes: True / a Planes to receive the result's planes.  Returns the fp32 tensor, the Planes, or (fp32, Planes)."""
+    out_planes: True / a Planes to receive the result's planes.  Returns the fp32 tensor, the Planes, or (fp32, Planes).
+    row_stats=True: a RowStats of the output rows is appended to the result; ln=(RowStats of a's rows, colsum, eps): the launch
+    folds the LayerNorm of its input (w / bias are then the folded ones, `FoldedLN`)."""
     lib = hip.load()
     if not isinstance(a, Planes):
         raise TypeError("planes.gemm: a must be Planes")
@@ -274,8 +306,20 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
                       lambda t, sp, wi: gemm(a, wi, bias=bias, residual=residual, rowvec=rowvec, rows_per_batch=rows_per_batch, out=out,
                                              out_planes=out_planes, out_scale=out_scale, geglu=geglu, tile=t, splits=sp), w)
         p.tile, p.splits = pick_plan(M, N, K, variant="|g" if geglu else "")
-    if geglu:
+    if geglu or row_stats or ln is not None:
         p.splits = 1
+    rs = None
+    if row_stats:
+        wn = lib.ief_gemm_x3p_tile_wn(p.tile)
+        if N % wn:
+            raise ValueError("planes.gemm: row statistics need N to be a multiple of the tile's wave width")
+        rs = RowStats(torch.empty(M, N // wn, 2, dtype=torch.float32, device=a.device), N // wn, wn)
+        p.rstat_out = rs.buf.data_ptr()
+    if ln is not None:
+        st, colsum, eps = ln
+        if st.buf.shape[0] != M or st.slots * st.cnt != K or _dev32(colsum, "colsum").numel() != N:
+            raise ValueError("planes.gemm: ln statistics / colsum do not match this launch")
+        p.rstat_in, p.rstat_slots, p.rstat_cnt, p.colsum, p.ln_eps = st.buf.data_ptr(), st.slots, st.cnt, colsum.data_ptr(), eps
     ws = None
     if p.splits > 1:
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)       # noqa: F841 (alive until queued)
@@ -283,7 +327,10 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
     nbytes = 4.0 * (M * K + N * K + M * No * ((1 if o32 is not None else 0) + (1 if op is not None else 0)) + (M * N if residual is not None else 0))
     with _Timed(f"igemm_x3p_kernel<false> t{p.tile}" + (f" {M}x{N}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * N * K, nbytes):
         _check(lib.ief_gemm_x3p(byref(p), _stream()), "ief_gemm_x3p")
-    return _ret(o32, op)
+    r = _ret(o32, op)
+    if row_stats:
+        return (r + (rs,)) if isinstance(r, tuple) else (r, rs)
+    return r
 
 
 def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, residual=None, out=None, out_planes=None,
@@ -438,3 +485,43 @@ def attn_out_args(p, B, N, C, device, out32=False):
         o32 = torch.empty(B, N, C, dtype=torch.float32, device=device)
         p.Out, p.sOb, p.ldo = o32.data_ptr(), N * C, C
     return op, o32
+
+
+FLASH_PLANES = os.environ.get("IEF_X3P_FLASH", "1") == "1"       # 0: the fused attention always takes fp32 q / k / v (A/B runs)
+FLASH_PLANES_DIMS = (40, 64, 80)
+
+
+def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, out_planes=True):
+    """fused attention on operand planes: q [B,N,h*d], k / v [B,L,h*d] as Planes (column slices of the q|k|v GEMM's output are
+    fine); K / V tiles are staged by LDS-DMA, nothing is split in the kernel (`attn_flash_x3p_kernel`).  Returns Planes (for
+    to_out's GEMM) or, with out_planes=False, fp32."""
+    lib = hip.load()
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        if not isinstance(t, Planes) or t.dim() != 3:
+            raise TypeError(f"planes.attn_flash: {nm} must be Planes [B, rows, heads*d]")
+    B, N, C = q.shape
+    L, d = k.shape[1], C // heads
+    if d not in FLASH_PLANES_DIMS:
+        raise ValueError(f"planes.attn_flash: head dim {d} has no planes instantiation")
+    p = hip.IefAttnF32Params()
+    for t, nm in ((q, "Q"), (k, "K"), (v, "V")):
+        h_ = t.hi
+        if h_.stride(2) != 1 or (h_.shape[0] > 1 and h_.stride(0) != h_.shape[1] * h_.stride(1)):
+            raise ValueError("planes.attn_flash: operands must be [B, rows, heads*d] with batch stride rows * ld")
+        setattr(p, nm + "p", h_.data_ptr())
+        setattr(p, "plane" + nm, t.plane)
+    p.ldq, p.ldk, p.ldv = q.hi.stride(1), k.hi.stride(1), v.hi.stride(1)
+    p.sQb, p.sKb, p.sVb = q.hi.stride(0), k.hi.stride(0), v.hi.stride(0)
+    p.B, p.heads, p.N, p.L, p.d, p.scale = B, heads, N, L, d, scale
+    p.q_src, p.k_src, p.v_src = _ptr(hip._devi32(q_src, "q_src")), _ptr(hip._devi32(k_src, "k_src")), _ptr(hip._devi32(v_src, "v_src"))
+    p.x3, p.zeros = 1, _zeros(q.device)
+    op = None
+    if out_planes:
+        op, _ = attn_out_args(p, B, N, C, q.device)
+    else:
+        if out is None:
+            out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+        p.Out, p.sOb, p.ldo = hip._act32(out, "out").data_ptr(), out.stride(0), out.stride(1)
+    with _Timed(f"attn_flash_x3p_kernel<{d}>", 4.0 * B * heads * N * L * d, 4.0 * B * heads * d * (2 * N + 2 * L)):
+        _check(lib.ief_attn_flash_f32(byref(p), _stream()), "ief_attn_flash_f32 (planes)")
+    return op if out_planes else out

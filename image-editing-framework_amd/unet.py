@@ -267,22 +267,38 @@ class Attention(nn.Module):
         return lin(o, residual=residual)
 
 
-    def forward_x3p(self, xp, ctx, residual):
+    def fold_layernorm_x3p(self, norm):
+        """split-operand mode: W gamma / b + W beta / colsum of the q (cross) or q|k|v (self) projection (planes.FoldedLN)"""
+        w = self.w_qkv if self.w_qkv is not None else self.to_q.weight
+        self.ln3 = planes.FoldedLN(w, None, norm.weight, norm.bias, norm.eps)
+
+    def forward_x3p(self, xp, ctx, residual, ln_stats=None, want_stats=False):
         """split-operand mode on operand planes (csrc/gemm_x3p.hip): xp = planes of the LayerNorm'ed input (written by the
-        LayerNorm launch), the attention kernel writes the planes to_out's GEMM stages by LDS-DMA; returns fp32 (the residual
-        stream).  Same dataflow as `forward` (`/root/reference/p2p/model/register.py:11-64`)."""
+        LayerNorm launch) -- or, with ln_stats (planes.RowStats of its rows), planes of the RAW residual stream: the LayerNorm is
+        then folded into the input projection.  The attention kernel writes the planes to_out's GEMM stages by LDS-DMA; returns
+        fp32 (the residual stream); want_stats: (fp32, Planes, RowStats) of the output for the next folded LayerNorm.  Same
+        dataflow as `forward` (`/root/reference/p2p/model/register.py:11-64`)."""
         B, N, C = xp.shape
         self.last_tokens = N
         plan = self._plan
+        w_in, b_in, ln = (self.w_qkv if ctx is None else self.to_q.weight), None, None
+        if ln_stats is not None:
+            w_in, b_in, ln = self.ln3.w, self.ln3.bias, (ln_stats, self.ln3.colsum, self.ln3.eps)
         if ctx is None:
-            qkv = planes.gemm(xp, self.w_qkv)
             qs = ks = vs = None
             if plan is not None:
                 qs, ks, vs = plan.self_sources(B, N, self)
-            o = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads, self.scale, q_src=qs, k_src=ks,
-                               v_src=vs, out_planes=True)
+            if planes.FLASH_PLANES and self.dim_head in planes.FLASH_PLANES_DIMS:
+                # the q|k|v GEMM writes planes only; the attention kernel stages K / V tiles by LDS-DMA and splits nothing
+                qkv = planes.gemm(xp, w_in, bias=b_in, ln=ln, out=False, out_planes=True)
+                o = planes.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads, self.scale, q_src=qs,
+                                      k_src=ks, v_src=vs)
+            else:
+                qkv = planes.gemm(xp, w_in, bias=b_in, ln=ln)
+                o = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.heads, self.scale, q_src=qs, k_src=ks,
+                                   v_src=vs, out_planes=True)
         else:
-            q = planes.gemm(xp, self.to_q.weight)
+            q = planes.gemm(xp, w_in, bias=b_in, ln=ln)
             kv = self.context_kv(ctx)
             args = plan.cross_edit(B, self) if plan is not None else {}
             if self.map_out is not None:
@@ -291,6 +307,8 @@ class Attention(nn.Module):
         if plan is not None:
             plan.layer_done(self)
         lin = self.to_out[0]
+        if want_stats:
+            return planes.gemm(o, lin.weight, bias=lin.bias, residual=residual, out=True, out_planes=True, row_stats=True)
         return planes.gemm(o, lin.weight, bias=lin.bias, residual=residual)
 
 
@@ -373,6 +391,36 @@ class BasicTransformerBlock(nn.Module):
             return attn.forward_x3p(planes.layernorm(h, norm.weight, norm.bias, norm.eps), ctx, residual=h)
         return self._attend(attn, norm(h), h, ctx)          # a hook owns forward: fp32 in, fp32 out (generic path)
 
+    def fold_layernorm_x3p(self):
+        self.attn1.fold_layernorm_x3p(self.norm1)
+        self.attn2.fold_layernorm_x3p(self.norm2)
+        f0 = self.ff.net[0].proj
+        self.ff.net[0].ln3 = planes.FoldedLN(f0.weight, f0.bias, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+
+    def foldable_x3p(self):
+        """folded weights are DERIVED tensors: made at the first eager forward (after a multi-GPU weight broadcast, like the weight
+        planes), never while a graph is being captured"""
+        if not (planes.LN_FOLD and self.attn1.is_native() and self.attn2.is_native()):
+            return False
+        if getattr(self.attn1, "ln3", None) is None:
+            if hip._capturing():
+                return False
+            self.fold_layernorm_x3p()
+        return True
+
+    def forward_x3p_folded(self, h, hp, st, ctx, last, want_stats):
+        """the three LayerNorms folded into the GEMMs they feed (no LayerNorm launch): h fp32 + hp its planes + st the row
+        statistics its producer left; every producer of the residual stream writes fp32, planes and statistics"""
+        h, hp, st = self.attn1.forward_x3p(hp, None, residual=h, ln_stats=st, want_stats=True)
+        h, hp, st = self.attn2.forward_x3p(hp, ctx, residual=h, ln_stats=st, want_stats=True)
+        f0, lin = self.ff.net[0], self.ff.net[2]
+        g = planes.gemm(hp, f0.ln3.w, bias=f0.ln3.bias, geglu=True, out=False, out_planes=True, ln=(st, f0.ln3.colsum, f0.ln3.eps))
+        if last:
+            return planes.gemm(g, lin.weight, bias=lin.bias, residual=h, out=False, out_planes=True)
+        if want_stats:
+            return planes.gemm(g, lin.weight, bias=lin.bias, residual=h, out=True, out_planes=True, row_stats=True)
+        return planes.gemm(g, lin.weight, bias=lin.bias, residual=h)
+
     def forward_x3p(self, h, ctx, last):
         """split-operand mode on operand planes: every LayerNorm writes the planes its GEMM consumes, FeedForward.net[0]
         writes the GEGLU product as planes; last: the block's output is read by proj_out only -> planes only"""
@@ -424,10 +472,20 @@ class Transformer2DModel(nn.Module):
         B, H, W, C = x.shape
         n = self.norm
         hn = planes.groupnorm(x, n.weight, n.bias, n.num_groups, n.eps, silu=False)
-        h = planes.gemm(hn.reshape(B, H * W, C), self.proj_in.weight, bias=self.proj_in.bias)
         last = len(self.transformer_blocks) - 1
-        for k, blk in enumerate(self.transformer_blocks):
-            h = blk.forward_x3p(h, encoder_hidden_states, last=(k == last))
+        if all(blk.foldable_x3p() for blk in self.transformer_blocks):
+            h, hp, st = planes.gemm(hn.reshape(B, H * W, C), self.proj_in.weight, bias=self.proj_in.bias, out=True, out_planes=True,
+                                    row_stats=True)
+            for k, blk in enumerate(self.transformer_blocks):
+                r = blk.forward_x3p_folded(h, hp, st, encoder_hidden_states, last=(k == last), want_stats=(k < last))
+                if k < last:
+                    h, hp, st = r
+                else:
+                    h = r
+        else:
+            h = planes.gemm(hn.reshape(B, H * W, C), self.proj_in.weight, bias=self.proj_in.bias)
+            for k, blk in enumerate(self.transformer_blocks):
+                h = blk.forward_x3p(h, encoder_hidden_states, last=(k == last))
         r = planes.gemm(h, self.proj_out.weight, bias=self.proj_out.bias, residual=x.reshape(B, H * W, C), out=True,
                         out_planes=want_planes)
         if want_planes:

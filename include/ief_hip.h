@@ -304,6 +304,13 @@ typedef struct IefAttnF32Params {
      * coefficients so that scale * max |c1| + |c2| stays below the fp16 range (AttentionReweight: c1 = alpha * equalizer);
      * 0 = 2^14 (maps <= 1) */
     float p_scale;
+    /* ABI 4, ief_attn_flash_f32 with x3 != 0 only: Q / K / V given as OPERAND PLANES (the q|k|v GEMM's epilogue writes them) --
+     * Qp / Kp / Vp hi planes with the layout of Q / K / V (same ld* and batch strides, in elements), lo planes planeQ / planeK /
+     * planeV elements further; Q / K / V are then ignored.  The kernel stages K / V tiles by LDS-DMA and splits nothing
+     * (attn_flash_x3p_kernel, csrc/split_x3.hip); d in {40, 64, 80}. */
+    const ief_half* Qp; const ief_half* Kp; const ief_half* Vp;
+    long long planeQ, planeK, planeV;
+    const void* zeros;      /* >= 16 bytes of device zeros (source of key rows past L) when Qp is set */
 } IefAttnF32Params;
 int ief_attn_flash_f32(const IefAttnF32Params* p, void* stream);
 int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
@@ -391,15 +398,27 @@ typedef struct IefGemmX3pParams {
     float* ws;
     int geglu;                                /* weight rows interleaved [8 hidden | 8 gate]: out [M][N / 2] = hidden * gelu(gate) */
     const void* zeros;                        /* >= 16 bytes of device zeros (source of out-of-range rows / padded taps) */
-    /* statistics of the OUTPUT for the consumer's normalisation, in the (count, mean, M2) form merged Chan-style:
-     * rstat_out [M][ceil(N / BN)][2] = (mean, M2) of each row over this launch's N tiles (LayerNorm of the next block);
-     * cstat_out [ceil(M / BM)][N][2] = (mean, M2) of each output channel over the rows of an M tile (GroupNorm) */
+    /* LayerNorm folded into the NEXT linear (BasicTransformerBlock.norm1/2/3 -> to_q|k|v / to_q / ff.net[0]), in the (count, mean,
+     * M2) form merged Chan-style (no E[x^2] - mean^2 cancellation):
+     *   producer: rstat_out [M][slots][2] = (mean, M2) of each output row over every 80- (tile 6: 64-) column slice one wave owns;
+     *             slots = N / slice width (ief_gemm_x3p_rstat_slots); needs an output (fp32 or planes) and no split-K / GEGLU;
+     *   consumer: rstat_in = the producer's rstat_out over THIS launch's K (rstat_slots slices of rstat_cnt columns each); the
+     *             launch runs on the planes of the RAW residual stream with W gamma as weight and computes
+     *             rstd (acc - mean colsum[n]) + bias[n], colsum[n] = sum_k (W gamma)[n][k] as the planes hold it, bias = b + W beta.
+     * cstat_out [ceil(M / BM)][N][2] = (mean, M2) of each output channel over the rows of an M tile (GroupNorm statistics from
+     * the producer; M % BM == 0, no split-K). */
     float* rstat_out;
     float* cstat_out;
+    const float* rstat_in;
+    const float* colsum;
+    int rstat_slots, rstat_cnt;
+    float ln_eps;
 } IefGemmX3pParams;
 int ief_gemm_x3p(const IefGemmX3pParams* p, void* stream);
 int ief_gemm_x3p_tile_bm(int tile);
 int ief_gemm_x3p_tile_bn(int tile);
+/* columns one wave owns in a tile (the width of a row-statistics slice): 80, tile 6: 64 */
+int ief_gemm_x3p_tile_wn(int tile);
 /* fp32 x [rows][ldx] -> planes hi / lo [rows][ldp] (lo plane `plane` elements after hi); C % 4 == 0, 16-byte aligned rows */
 int ief_x3_split_act(const float* x, ief_half* planes, long long plane, long long rows, int C, int ldx, int ldp, float scale,
                      void* stream);

@@ -34,11 +34,23 @@ def main():
     ap.add_argument("--conv", action="store_true")
     ap.add_argument("--lin", action="store_true")
     ap.add_argument("--splits", default="1")
+    ap.add_argument("--attn", action="store_true", help="the fused split-operand attention at the step's sequence lengths")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     splits = [int(s) for s in args.splits.split(",")]
-    do_lin, do_conv = args.lin or not args.conv, args.conv or not args.lin
+    do_lin, do_conv = args.lin or not (args.conv or args.attn), args.conv or not (args.lin or args.attn)
     with hip.f32_contraction("x3"):
+        if args.attn:
+            for B, heads, N, d in [(4, 8, 4096, 40), (4, 8, 1024, 80), (4, 8, 256, 160), (4, 8, 16384, 40), (4, 5, 9216, 64), (1, 10, 4096, 64)]:
+                qkv = rnd(B, N, 3 * heads * d)
+                C = heads * d
+                fl = 4.0 * B * heads * N * N * d
+                us = hip._time_graph(lambda i: hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, d ** -0.5), iters=5)
+                usp = hip._time_graph(lambda i: hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, d ** -0.5, out_planes=True), iters=5)
+                qp = planes.split(qkv)
+                uspp = hip._time_graph(lambda i: planes.attn_flash(qp[..., :C], qp[..., C:2 * C], qp[..., 2 * C:], heads, d ** -0.5), iters=5) if d in planes.FLASH_PLANES_DIMS else float("nan")
+                print(f"attn_flash_x3 B={B} h={heads} N={N:6d} d={d:3d}: {us:9.1f} us {fl / us / 1e6:6.1f} TF  (planes out: {usp:9.1f} us; planes in + out: "
+                      f"{uspp:9.1f} us {fl / uspp / 1e6:6.1f} TF)", flush=True)
         if do_lin:
             for M, N, K in LIN:
                 a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)

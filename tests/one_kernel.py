@@ -45,6 +45,10 @@ elif what.endswith("x3p"):      # the planes kernels (csrc/gemm_x3p.hip); option
         elif base == "gemmff":
             a, w = planes.split(f(4096, 640)), f(5120, 640, scale=0.04)
             g = lambda: planes.gemm(a, w, tile=tile)
+        elif base in ("attn40", "attn40long"):
+            B, heads, N, d = 4, 8, (16384 if base == "attn40long" else 4096), 40
+            qkv = planes.split(f(B, N, 3 * heads * d)); C = heads * d
+            g = lambda: planes.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, d ** -0.5)
 
     def fn():
         with hip.f32_contraction("x3"):

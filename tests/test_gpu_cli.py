@@ -171,3 +171,18 @@ def test_pie_driver_two_ranks_weight_broadcast_and_shards(tmp_path):
         for name in ("inversion.png", "edit.png"):
             pa, pb = np.array(Image.open(a / d / name)).astype(int), np.array(Image.open(b / d / name)).astype(int)
             assert pa.shape == pb.shape and np.abs(pa - pb).max() == 0, (d, name)
+
+
+def test_cfg_split_two_ranks_one_edit_rccl(tmp_path):
+    """the same split with each rank on its OWN GPU and the per-step eps all-gather over RCCL (`--backend nccl`): the leg the
+    one-GPU box cannot run.  Skipped unless two GPUs are visible (the round-end 8-GPU node; never on the builder's box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: the RCCL leg of the CFG split (its gloo twin above runs on one)")
+    out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29641", os.path.join(ROOT, "tests", "workers", "cfg_split_worker.py"), "--backend", "nccl"],
+              cwd=ROOT, timeout=600)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    print(rec)
+    assert rec["finite"] and rec["ranks_identical"] and rec["cur_step"] == 6
+    assert rec["rel_split_vs_full"] < 5e-3

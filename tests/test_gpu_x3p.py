@@ -219,6 +219,35 @@ def test_conv_halo_x3p_real_shapes(B, H, W, C1, C2, Cout, ups, splits):
     assert e < XTOL and e64 < XTOL
 
 
+@pytest.mark.parametrize("B,heads,N,L,d", [(2, 8, 1024, 1024, 40), (4, 8, 256, 256, 80), (2, 2, 200, 144, 64), (1, 3, 77, 333, 40),
+                                            (1, 5, 4096, 4096, 64), (2, 8, 4096, 4096, 40), (1, 1, 130, 64, 80)])
+def test_attention_planes_in(B, heads, N, L, d):
+    """`attn_flash_x3p_kernel`: q / k / v as operand planes (column slices of one q|k|v planes tensor), K / V tiles by LDS-DMA,
+    unpadded 80 / 128 / 160-byte LDS rows (swizzled for d = 64), key counts that are not multiples of the tile, batch-row
+    indirection (P2P self-replace / MasaCtrl / PnP sources) -- against fp64; the planes it writes == split of its fp32 output"""
+    C = heads * d
+    q, k, v = f32(B, N, C, seed=1), f32(B, L, C, seed=2, scale=1.5), f32(B, L, C, seed=3)
+    if N == L:
+        qkv = planes.split(dev(torch.cat([q, k, v], -1)))
+        qp, kp, vp = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    else:
+        qp, kp, vp = planes.split(dev(q)), planes.split(dev(k)), planes.split(dev(v))
+    src = torch.arange(B, dtype=torch.int32)
+    ks = src.clone()
+    ks[-1] = 0
+    out = planes.attn_flash(qp, kp, vp, heads, d ** -0.5, k_src=dev(ks), v_src=dev(ks), out_planes=False)
+    op = planes.attn_flash(qp, kp, vp, heads, d ** -0.5, k_src=dev(ks), v_src=dev(ks))
+    sub = slice(0, min(N, 512))
+    qh = q.double()[:, sub].reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    kh = k.double()[ks.long()].reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    vh = v.double()[ks.long()].reshape(B, L, heads, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(B, -1, C)
+    e = rel_err(out[:, sub], ref)
+    print(f"attention planes-in B={B} h={heads} N={N} L={L} d={d}: {e:.2e}")
+    assert e < XTOL
+    assert_planes_equal_split(op, out)
+
+
 def test_sd15_shapes_x3p_full_size():
     """the step's largest layers at their real sizes (batch 4): K = C projection, FeedForward.net[0], the 64x64 convolution"""
     for (M, N, K) in [(16384, 320, 320), (16384, 2560, 320), (4096, 640, 2560)]:
@@ -235,3 +264,34 @@ def test_sd15_shapes_x3p_full_size():
     e = rel_err(out[:1], ref)
     print(f"x3p conv 64x64x320: {e:.2e}")
     assert e < XTOL
+
+
+@pytest.mark.parametrize("M,C,N", [(4096, 320, 960), (1000, 640, 640), (300, 1280, 2560)])
+def test_layernorm_folded_into_the_consumer_gemm(M, C, N):
+    """BasicTransformerBlock's norm -> linear pair without the LayerNorm launch: the PRODUCER of the residual stream leaves (mean,
+    M2) of every row per 80-column slice (Chan-mergeable: no E[x^2] - mean^2), the consumer runs on the planes of the RAW stream
+    with W gamma and computes rstd (acc - mean colsum) + (b + W beta).  Against fp64 LayerNorm + linear, with a row offset 20x the
+    row's spread (the cancellation case), and against the unfolded pair of launches; GEGLU epilogue included"""
+    x, res = f32(M, C, seed=1) + 20.0 * f32(M, 1, seed=7), f32(M, C, seed=2)
+    w0, b0 = f32(C, C, seed=3, scale=C ** -0.5), f32(C, seed=4, scale=0.1)
+    gamma, beta = 1.0 + 0.3 * f32(C, seed=5), 0.2 * f32(C, seed=6)
+    w1, b1 = f32(N, C, seed=8, scale=C ** -0.5), f32(N, seed=9, scale=0.1)
+    h, hp, st = planes.gemm(planes.split(dev(x)), dev(w0), bias=dev(b0), residual=dev(res), out=True, out_planes=True, row_stats=True)
+    assert_planes_equal_split(hp, h)
+    hd = h.double().cpu()
+    mean, var = hd.mean(1), hd.var(1, unbiased=False)
+    got_mean = (st.buf[:, :, 0].double().cpu()).mean(1)
+    assert (got_mean - mean).abs().max() < 1e-5 * hd.abs().max()
+    ln = ((hd - mean[:, None]) / torch.sqrt(var[:, None] + 1e-5)) * gamma.double() + beta.double()
+    ref = ln @ w1.double().t() + b1.double()
+    f = planes.FoldedLN(dev(w1), dev(b1), dev(gamma), dev(beta), 1e-5)
+    out = planes.gemm(hp, f.w, bias=f.bias, ln=(st, f.colsum, f.eps))
+    two = planes.gemm(planes.layernorm(h, dev(gamma), dev(beta), 1e-5), dev(w1), bias=dev(b1))
+    e, e2 = rel_err(out, ref), rel_err(two, ref)
+    print(f"LayerNorm folded {M}x{C}->{N}: {e:.2e} vs fp64 (LayerNorm launch + GEMM: {e2:.2e})")
+    assert e < 2e-5 and e2 < 2e-5
+    if N % 16 == 0:
+        pre = ref.reshape(M, N // 16, 2, 8)
+        gref = (pre[:, :, 0] * F.gelu(pre[:, :, 1])).reshape(M, N // 2)
+        g = planes.gemm(hp, f.w, bias=f.bias, geglu=True, ln=(st, f.colsum, f.eps))
+        assert rel_err(g, gref) < 2e-5
