@@ -538,6 +538,8 @@ def _family(kernel_name: str) -> str:
         return "igemm_x3p_kernel<.., linear> (linear / 1x1 on operand planes, LDS-DMA staged)"
     if kernel_name.startswith("igemm_x3p_kernel<true>") or kernel_name.startswith("conv3x3_halo_x3p_kernel"):
         return "conv3x3 on operand planes (conv3x3_halo_x3p_kernel + igemm_x3p_kernel<.., conv>)"
+    if kernel_name.startswith("attn_flash_x3p"):
+        return "attn_flash_x3p_kernel<..> (self-attention on operand planes)"
     if kernel_name.startswith("attn_flash"):
         return kernel_name.split("<")[0] + "<..> (self-attention, all head dims)"
     return kernel_name

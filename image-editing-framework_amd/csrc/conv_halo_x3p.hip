@@ -53,9 +53,15 @@ __global__ __launch_bounds__(768) void conv3x3_halo_x3p_kernel(const IefGemmX3pP
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    // tile order as igemm_x3p_kernel: each XCD (its own L2) takes a contiguous run of logical ids; inside it, groups of XP_GROUP_M
+    // row blocks are walked column by column -- the workgroups resident on an XCD cover a patch of the output, so an input
+    // super-tile and a weight tile are fetched into that L2 once per patch (PMC, 32x32x640 convolution: N-first order made every
+    // XCD fetch all 14.7 MB of weights: 4.5x the algorithmic bytes)
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const bool m_first = p.N > p.M;           // consecutive logical tiles share an XCD's L2: walk N first where the activations are larger
-    const int m0 = (m_first ? lid % tiles_m : lid / tiles_n) * BM, n0 = (m_first ? lid / tiles_m : lid % tiles_n) * BN;
+    const int grp = lid / (XP_GROUP_M * tiles_n), within = lid - grp * (XP_GROUP_M * tiles_n);
+    const int gsz = min(XP_GROUP_M, tiles_m - grp * XP_GROUP_M);
+    const int tn = within / gsz, tm = grp * XP_GROUP_M + (within - tn * gsz);
+    const int m0 = tm * BM, n0 = tn * BN;
     const int W = p.Wd, H = p.H;
     const int Ctot = p.C1 + p.C2;
     const char* __restrict__ zp = (const char*)p.zeros;

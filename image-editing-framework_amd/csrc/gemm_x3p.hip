@@ -419,7 +419,7 @@ extern "C" int ief_x3_split_act(const float* x, ief_half* planes, long long plan
 
 extern "C" int ief_gemm_x3p_tile_bm(int tile) {
     switch (tile) {
-        case 1: case 2: case 3: return 128;
+        case 1: case 2: case 3: case 7: return 128;
         case 4: case 11: case 12: return 256;
         case 5: return 64;
         case 6: return 128;
@@ -429,7 +429,7 @@ extern "C" int ief_gemm_x3p_tile_bm(int tile) {
 extern "C" int ief_gemm_x3p_tile_wn(int tile) { return tile == 6 ? 64 : 80; }
 extern "C" int ief_gemm_x3p_tile_bn(int tile) {
     switch (tile) {
-        case 1: case 2: case 4: case 5: return 160;
+        case 1: case 2: case 4: case 5: case 7: return 160;
         case 3: case 11: case 12: return 80;
         case 6: return 64;
         default: return 0;
@@ -489,6 +489,7 @@ extern "C" int ief_gemm_x3p(const IefGemmX3pParams* pp, void* stream) {
         case 4: rc = launch_x3p<256, 160, 4, 2, 3, 0>(p, st); break;
         case 5: rc = launch_x3p<64, 160, 2, 2, 4, 0>(p, st); break;
         case 6: rc = launch_x3p<128, 64, 4, 1, 3, 0>(p, st); break;
+        case 7: rc = launch_x3p<128, 160, 2, 2, 2, 0>(p, st); break;       // 4 waves (64 x 80 each), 72 KiB of LDS: two workgroups per CU
         case 11: case 12: rc = ief_conv_halo_x3p_dispatch(p, st); break;
         case 1: default: rc = launch_x3p<128, 160, 4, 2, 4, 0>(p, st); break;
     }

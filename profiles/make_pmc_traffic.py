@@ -38,6 +38,19 @@ CASES = {
                  4 * (4096 * 640 + 5120 * 640 + 4096 * 5120)),
     "attn40x3": ("attn_flash_x3", "attn_flash_x3_kernel<..> (self-attention, all head dims)",
                  "f16x3: B=4 heads=8 N=L=4096 d=40, fp32 q / k / v / out", 4 * 4 * 8 * 4096 * 40 * 4),
+    # round 4: operand planes (4 bytes per element: hi + lo fp16 planes), both operands staged by LDS-DMA
+    "conv64x3p": ("conv3x3_halo_x3p", "conv3x3 on operand planes (conv3x3_halo_x3p_kernel + igemm_x3p_kernel<.., conv>)",
+                  "f16x3 planes: conv3x3 B=4 64x64 320->320 (M=16384 N=320 K=2880) on the halo kernel, planes in, fp32 out",
+                  4 * (16384 * 320 * 2 + 320 * 2880)),
+    "conv32x3p": ("conv3x3_halo_x3p", "-", "f16x3 planes: conv3x3 B=4 32x32 640->640 (M=4096 N=640 K=5760) as the plan table runs it "
+                  "(halo kernel, split-K over channel blocks); the reducer launch is listed beside it", 4 * (4096 * 640 * 2 + 640 * 5760)),
+    "gemmsqx3p": ("igemm_x3p_kernel", "igemm_x3p_kernel<.., linear> (linear / 1x1 on operand planes, LDS-DMA staged)",
+                  "f16x3 planes: square projection with bias + residual (M=16384 N=320 K=320), planes in, fp32 residual and out",
+                  4 * (16384 * 320 * 3 + 320 * 320)),
+    "gemmffx3p": ("igemm_x3p_kernel", "-", "f16x3 planes: FeedForward.net[0] shape without the fused GEGLU (M=4096 N=5120 K=640)",
+                  4 * (4096 * 640 + 5120 * 640 + 4096 * 5120)),
+    "attn40x3p": ("attn_flash_x3p", "attn_flash_x3p_kernel<..> (self-attention on operand planes)",
+                  "f16x3 planes: B=4 heads=8 N=L=4096 d=40, planes q / k / v in, planes out", 4 * 4 * 8 * 4096 * 40 * 4),
 }
 
 
@@ -47,7 +60,7 @@ def mean_counter(d, needle):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                if needle in name or "splitk_epilogue" in name or "splitk_reduce" in name:
+                if needle in name or "splitk_epilogue" in name or "splitk_reduce" in name or "x3p_reduce" in name:
                     key = name.replace("void ", "").split("(")[0]
                     out.setdefault(key, []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in out.items()}
@@ -63,10 +76,11 @@ def main():
         fetch = mean_counter(os.path.join(root, f"pmc_{case}_fetch"), needle)
         write = mean_counter(os.path.join(root, f"pmc_{case}_write"), needle)
         for k in fetch:
-            e = {"family": family if "splitk" not in k else "-", "shape": shape if "splitk" not in k else shape + " — its slab reducer",
+            red = "splitk" in k or "x3p_reduce" in k
+            e = {"family": family if not red else "-", "shape": shape if not red else shape + " — its slab reducer",
                  "fetch_size_kb": round(fetch[k], 1), "write_size_kb": round(write.get(k, 0.0), 1),
                  "hbm_bytes": int((2 * fetch[k] + write.get(k, 0.0)) * 1024)}
-            if "splitk" not in k:
+            if not red:
                 e["algorithmic_bytes"] = alg
                 e["hbm_over_algorithmic"] = round(e["hbm_bytes"] / alg, 2)
             res[f"{k} [{case}]"] = e

@@ -41,6 +41,8 @@ def family(name: str) -> str:
         return "igemm_x3p_kernel<.., linear> (linear / 1x1 on operand planes, LDS-DMA staged)"
     if name.startswith("conv3x3_halo_x3p_kernel"):
         return "conv3x3 on operand planes (conv3x3_halo_x3p_kernel + igemm_x3p_kernel<.., conv>)"
+    if name.startswith("attn_flash_x3p"):
+        return "attn_flash_x3p_kernel<..> (self-attention on operand planes)"
     if name.startswith("attn_flash"):
         return name.split("<")[0] + "<..> (self-attention, all head dims)"
     return name
