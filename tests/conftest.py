@@ -53,3 +53,101 @@ def pytest_runtest_setup(item):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- memo of the CPU oracle's UNet forward ---------------------------------------------------------------------------------------
+# The three precision modes' test files compare the HIP path with the oracle on the SAME seeded inputs (and every controlled
+# forward also computes the uncontrolled one): the oracle's eager fp32 forward is the suite's largest single cost on the GPU
+# box.  `oracle.unet_ref.unet_forward` is wrapped for the session: a call whose arguments (weights fingerprint, configuration,
+# sample, timestep, context, added conditioning, and the state of a plain `P2PControlRef` hook) hash to a key seen before
+# returns a clone of the stored output and replays the hook's counter update.  Calls with grad-tracking inputs, taps, q/k/v
+# hooks, injections, storing hooks or any other hook object are never memoised.  Test infrastructure only.
+import hashlib as _hashlib  # noqa: E402
+
+
+def _h_tensor(h, t):
+    import torch
+    if t is None:
+        h.update(b"none")
+        return
+    t = torch.as_tensor(t).detach().cpu().contiguous()
+    h.update(str((t.dtype, tuple(t.shape))).encode())
+    h.update(t.numpy().tobytes() if t.dtype != torch.bfloat16 else t.float().numpy().tobytes())
+
+
+_SD_PRINTS = {}
+
+
+def _sd_fingerprint(sd):
+    """every tensor of the state dict enters (name, shape, sum, sum of |.|, a strided sample); dicts above 64 M elements (the
+    full-size families) are not fingerprinted: their forwards are not memoised"""
+    key = id(sd)
+    if key not in _SD_PRINTS:
+        if sum(v.numel() for v in sd.values()) > (64 << 20):
+            _SD_PRINTS[key] = (sd, None)
+        else:
+            h = _hashlib.sha1()
+            for n in sorted(sd.keys()):
+                v = sd[n].detach().reshape(-1)
+                h.update(n.encode())
+                h.update(str((tuple(sd[n].shape), float(v.double().sum()), float(v.double().abs().sum()))).encode())
+                _h_tensor(h, v[:: max(1, v.numel() // 256)])
+            _SD_PRINTS[key] = (sd, h.hexdigest())                   # holds `sd` so the id cannot be recycled
+    return _SD_PRINTS[key][1]
+
+
+def _hook_key(h, hook):
+    from oracle.p2p_ref import P2PControlRef
+    if hook is None:
+        h.update(b"nohook")
+        return True
+    if type(hook) is not P2PControlRef or hook.store is not None or hook.cur_att_layer != 0:
+        return False
+    h.update(str((hook.mode, hook.num_prompts, tuple(hook.num_self_replace), hook.num_att_layers, hook.cur_step)).encode())
+    for t in (hook.cross_alpha, hook.mapper, hook.alphas, hook.equalizer):
+        _h_tensor(h, t)
+    if hook.prev is not None:
+        return _hook_key(h, hook.prev)
+    h.update(b"noprev")
+    return True
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_forward_memo():
+    import torch
+    from oracle import unet_ref
+    real = unet_ref.unet_forward
+    memo = {}
+
+    def unet_forward(sd, cfg, sample, timestep, ctx, hook=None, qkv_hook=None, taps=None, qkv_path_hook=None, res_inject=None,
+                     added_cond_kwargs=None):
+        plain = qkv_hook is None and taps is None and qkv_path_hook is None and not res_inject
+        tracked = torch.is_grad_enabled() and any(isinstance(v, torch.Tensor) and v.requires_grad for v in (sample, ctx))
+        if not plain or tracked:
+            return real(sd, cfg, sample, timestep, ctx, hook, qkv_hook, taps, qkv_path_hook, res_inject, added_cond_kwargs)
+        fp = _sd_fingerprint(sd)
+        if fp is None:
+            return real(sd, cfg, sample, timestep, ctx, hook, qkv_hook, taps, qkv_path_hook, res_inject, added_cond_kwargs)
+        h = _hashlib.sha1()
+        h.update(fp.encode())
+        h.update(repr(cfg).encode())
+        for t in (sample, timestep, ctx):
+            _h_tensor(h, t)
+        for k in sorted(added_cond_kwargs or {}):
+            h.update(k.encode())
+            _h_tensor(h, added_cond_kwargs[k])
+        if not _hook_key(h, hook):
+            return real(sd, cfg, sample, timestep, ctx, hook, qkv_hook, taps, qkv_path_hook, res_inject, added_cond_kwargs)
+        key = h.hexdigest()
+        if key in memo:
+            if hook is not None:                                   # what `P2PControlRef.__call__` does over one forward
+                hook.cur_step += 1
+            return memo[key].clone()
+        out = real(sd, cfg, sample, timestep, ctx, hook, qkv_hook, taps, qkv_path_hook, res_inject, added_cond_kwargs)
+        if isinstance(out, torch.Tensor) and not out.requires_grad:
+            memo[key] = out.detach().clone()
+        return out
+
+    unet_ref.unet_forward = unet_forward
+    yield memo
+    unet_ref.unet_forward = real

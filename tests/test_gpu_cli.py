@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 from PIL import Image
 
+from _procs import run_parallel
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -118,15 +120,13 @@ def test_bench_two_ranks_weak_and_cfg_split(tmp_path):
 def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
     """--invert_batch K inverts K images in one batched DDIM loop and --in_flight E steps E edits concurrently; images
     are independent, so the PNGs must match the per-image run."""
-    a, b = tmp_path / "a", tmp_path / "b"
-    run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--exp_path", str(a)], cwd=str(tmp_path))
-    out = run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--invert_batch", "2",
-               "--exp_path", str(b)], cwd=str(tmp_path))
-    assert json.loads(out.strip().splitlines()[-1])["images"] == 3
-    c = tmp_path / "c"
-    out = run([os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3", "--invert_batch", "3",
-               "--in_flight", "2", "--exp_path", str(c)], cwd=str(tmp_path))
-    assert json.loads(out.strip().splitlines()[-1])["images"] == 3
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    base = [os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3"]
+    done = run_parallel([(base + ["--exp_path", str(a)], tmp_path / "cwd_a"),
+                         (base + ["--invert_batch", "2", "--exp_path", str(b)], tmp_path / "cwd_b"),
+                         (base + ["--invert_batch", "3", "--in_flight", "2", "--exp_path", str(c)], tmp_path / "cwd_c")])
+    for d in done:
+        assert d.last_json()["images"] == 3
     for other in (b, c):
         for d in sorted(x for x in os.listdir(a) if x.startswith("syn_")):
             for name in ("inversion.png", "edit.png"):
@@ -142,14 +142,15 @@ def test_masactrl_edit_real_and_pie_driver(tmp_path):
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
+    jobs = [([os.path.join(masa, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
+              str(tmp_path / "test.jpg")], tmp_path / inv) for inv in ("ddim", "null-text")]
+    jobs.append(([os.path.join(masa, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--exp_path", str(tmp_path / "t")],
+                 tmp_path / "cwd_t"))
+    done = run_parallel(jobs)
     for inv in ("ddim", "null-text"):
-        run([os.path.join(masa, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
-             str(tmp_path / "test.jpg")], cwd=str(tmp_path))
         for name in ("source.png", "inversion.png", "edit.png"):
-            assert (tmp_path / "exp" / name).exists()
-    out = run([os.path.join(masa, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--exp_path", str(tmp_path / "t")],
-              cwd=str(tmp_path))
-    rec = json.loads(out.strip().splitlines()[-1])
+            assert (tmp_path / inv / "exp" / name).exists()
+    rec = done[2].last_json()
     assert rec["images"] == 2 and rec["images_per_sec"] > 0
 
 

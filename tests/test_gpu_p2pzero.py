@@ -16,6 +16,8 @@ import pytest
 import torch
 from PIL import Image
 
+from _procs import run_parallel
+
 pytestmark = pytest.mark.gpu
 
 from ief_amd import hip  # noqa: E402
@@ -195,33 +197,29 @@ def test_nti_variant_uses_the_per_step_rows(tiny):
 
 def test_p2pzero_clis(tmp_path):
     folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
-    r = subprocess.run([sys.executable, os.path.join(folder, "edit_syn.py"), "--sd_version", "tiny"], cwd=str(tmp_path),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    src = np.array(Image.open(tmp_path / "exp" / "source.png")).astype(int)
-    edit = np.array(Image.open(tmp_path / "exp" / "edit.png")).astype(int)
-    assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
+    jobs = [([os.path.join(folder, "edit_syn.py"), "--sd_version", "tiny"], tmp_path / "syn")]
     for inv in ("ddim", "null-text"):
-        r = subprocess.run([sys.executable, os.path.join(folder, "edit_real.py"), "--sd_version", "tiny", "--inversion_type",
-                            inv, "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True,
-                           text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
+        jobs.append(([os.path.join(folder, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
+                      str(tmp_path / "test.jpg")], tmp_path / inv))
+    run_parallel(jobs)
+    src = np.array(Image.open(tmp_path / "syn" / "exp" / "source.png")).astype(int)
+    edit = np.array(Image.open(tmp_path / "syn" / "exp" / "edit.png")).astype(int)
+    assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
+    for inv in ("ddim", "null-text"):
         for name in ("source.png", "inversion.png", "edit.png"):
-            assert (tmp_path / "exp" / name).exists()
+            assert (tmp_path / inv / "exp" / name).exists()
 
 
 def test_p2pzero_pie_driver(tmp_path):
-    import json
     folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
-    for inv in ("ddim", "null-text"):
-        r = subprocess.run([sys.executable, os.path.join(folder, "test.py"), "--sd_version", "tiny", "--synthetic", "2",
-                            "--invert_batch", "2", "--inversion_type", inv, "--exp_path", str(tmp_path / inv)],
-                           cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
-        rec = json.loads(r.stdout.strip().splitlines()[-1])
+    invs = ("ddim", "null-text")
+    done = run_parallel([([os.path.join(folder, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--invert_batch", "2",
+                           "--inversion_type", inv, "--exp_path", str(tmp_path / inv)], tmp_path / ("cwd_" + inv)) for inv in invs])
+    for inv, d in zip(invs, done):
+        rec = d.last_json()
         assert rec["images"] == 2 and rec["images_per_sec"] > 0
         pngs = [f for _, _, fs in os.walk(tmp_path / inv) for f in fs if f == "edit.png"]
         assert len(pngs) == 2

@@ -12,6 +12,8 @@ import pytest
 import torch
 from PIL import Image
 
+from _procs import run_parallel
+
 pytestmark = pytest.mark.gpu
 
 from ief_amd import hip  # noqa: E402
@@ -133,23 +135,20 @@ def test_pnp_rejects_non_prefix_schedule(tiny):
 
 def test_pnp_clis(tmp_path):
     pnp = os.path.join(ROOT, "image-editing-framework_amd", "pnp")
-    r = subprocess.run([sys.executable, os.path.join(pnp, "edit_syn.py"), "--sd_version", "tiny"], cwd=str(tmp_path),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    src = np.array(Image.open(tmp_path / "exp" / "source.png")).astype(int)
-    edit = np.array(Image.open(tmp_path / "exp" / "edit.png")).astype(int)
-    assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
+    jobs = [([os.path.join(pnp, "edit_syn.py"), "--sd_version", "tiny"], tmp_path / "syn")]
     for inv in ("ddim", "null-text"):
-        r = subprocess.run([sys.executable, os.path.join(pnp, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv,
-                            "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
+        jobs.append(([os.path.join(pnp, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
+                      str(tmp_path / "test.jpg")], tmp_path / inv))
+    run_parallel(jobs)
+    src = np.array(Image.open(tmp_path / "syn" / "exp" / "source.png")).astype(int)
+    edit = np.array(Image.open(tmp_path / "syn" / "exp" / "edit.png")).astype(int)
+    assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
+    for inv in ("ddim", "null-text"):
         for name in ("source.png", "inversion.png", "edit.png"):
-            assert (tmp_path / "exp" / name).exists()
-            os.remove(tmp_path / "exp" / name)
+            assert (tmp_path / inv / "exp" / name).exists()
 
 
 def test_sd21_shape_family_forward_and_pnp():

@@ -81,6 +81,8 @@ import sys  # noqa: E402
 import numpy as np  # noqa: E402
 from PIL import Image  # noqa: E402
 
+from _procs import run_parallel  # noqa: E402
+
 from ief_amd.pipeline import StableDiffusionXLPipeline  # noqa: E402
 from ief_amd.p2p.model.sd_utils import P2P_XL  # noqa: E402
 from ief_amd.p2p.model.attention_base import EmptyControl  # noqa: E402
@@ -239,18 +241,16 @@ def test_p2pzero_xl_two_pass_vs_oracle(xlpipe):
 
 def test_p2pzero_xl_clis(tmp_path):
     folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
-    r = subprocess.run([sys.executable, os.path.join(folder, "edit_syn.py"), "--sd_version", "smallxl"], cwd=str(tmp_path),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
-    r = subprocess.run([sys.executable, os.path.join(folder, "edit_real.py"), "--sd_version", "smallxl", "--inversion_type",
-                        "ddim", "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    run_parallel([([os.path.join(folder, "edit_syn.py"), "--sd_version", "smallxl"], tmp_path / "syn"),
+                  ([os.path.join(folder, "edit_real.py"), "--sd_version", "smallxl", "--inversion_type", "ddim", "--source_image",
+                    str(tmp_path / "test.jpg")], tmp_path / "real")])
+    for name in ("source.png", "edit.png"):
+        assert (tmp_path / "syn" / "exp" / name).exists()
     for name in ("source.png", "inversion.png", "edit.png"):
-        assert (tmp_path / "exp" / name).exists()
+        assert (tmp_path / "real" / "exp" / name).exists()
 
 
 # ------------------------------------------------------------------------------------------------ MasaCtrl on the XL family
@@ -380,14 +380,13 @@ def test_xl_null_text_clis(tmp_path):
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
-    for folder in ("p2p", "pix2pix_zero"):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "image-editing-framework_amd", folder, "edit_real.py"),
-                            "--sd_version", "smallxl", "--inversion_type", "null-text", "--source_image",
-                            str(tmp_path / "test.jpg")], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (folder, r.stderr[-3000:])
+    folders = ("p2p", "pix2pix_zero")
+    run_parallel([([os.path.join(ROOT, "image-editing-framework_amd", folder, "edit_real.py"), "--sd_version", "smallxl",
+                    "--inversion_type", "null-text", "--source_image", str(tmp_path / "test.jpg")], tmp_path / folder)
+                  for folder in folders])
+    for folder in folders:
         for name in ("source.png", "inversion.png", "edit.png"):
-            assert (tmp_path / "exp" / name).exists()
-            os.remove(tmp_path / "exp" / name)
+            assert (tmp_path / folder / "exp" / name).exists()
 
 
 # ------------------------------------------------------------------------------------------------ local SDXL-layout directory
@@ -434,17 +433,15 @@ def test_xl_drivers_and_masactrl_clis(tmp_path):
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
     pkg = os.path.join(ROOT, "image-editing-framework_amd")
-    r = subprocess.run([sys.executable, os.path.join(pkg, "masactrl", "edit_real.py"), "--sd_version", "smallxl",
-                        "--inversion_type", "ddim", "--source_image", str(tmp_path / "test.jpg")], cwd=str(tmp_path),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert (tmp_path / "exp" / "edit.png").exists()
+    jobs = [([os.path.join(pkg, "masactrl", "edit_real.py"), "--sd_version", "smallxl", "--inversion_type", "ddim", "--source_image",
+              str(tmp_path / "test.jpg")], tmp_path)]
     for folder, inv in (("p2p", "null-text"), ("masactrl", "ddim")):
-        r = subprocess.run([sys.executable, os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "1",
-                            "--inversion_type", inv, "--exp_path", str(tmp_path / folder)], cwd=str(tmp_path),
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (folder, r.stderr[-3000:])
-        assert json.loads(r.stdout.strip().splitlines()[-1])["images"] == 1
+        jobs.append(([os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "1", "--inversion_type", inv,
+                      "--exp_path", str(tmp_path / folder)], tmp_path / ("cwd_" + folder)))
+    done = run_parallel(jobs)
+    assert (tmp_path / "exp" / "edit.png").exists()
+    for d in done[1:]:
+        assert d.last_json()["images"] == 1, d.args
 
 
 def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
@@ -455,11 +452,9 @@ def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
     import json
     pkg = os.path.join(ROOT, "image-editing-framework_amd")
 
-    def drive(folder, out, *flags):
-        r = subprocess.run([sys.executable, os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "2",
-                            "--exp_path", str(out)] + list(flags), cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (folder, flags, r.stderr[-3000:])
-        assert json.loads(r.stdout.strip().splitlines()[-1])["images"] == 2
+    def job(folder, out, *flags):
+        return ([os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "2", "--exp_path", str(out)]
+                + list(flags), tmp_path / ("cwd_" + out.name))
 
     def same(a, b):
         dirs = sorted(x for x in os.listdir(a) if x.startswith("syn_"))
@@ -469,24 +464,25 @@ def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
                 pa, pb = np.array(Image.open(a / d / name)).astype(int), np.array(Image.open(b / d / name)).astype(int)
                 assert pa.shape == pb.shape and np.abs(pa - pb).max() <= 1, (d, name, np.abs(pa - pb).max())
 
-    for folder in ("p2p", "pnp"):
-        one, many = tmp_path / (folder + "_one"), tmp_path / (folder + "_many")
-        drive(folder, one)
-        drive(folder, many, "--invert_batch", "2", "--in_flight", "2")
-        same(one, many)
     # null-text: in flight (every mode) the values are the per-image run's bit for bit.  A BATCHED inversion is bit-identical
     # per row only on the fp16-storage path (its kernels' tiles and split-K do not depend on the batch); in the fp32-storage
     # modes a row of a batch-2 launch differs from the batch-1 launch in the last bits (3e-6 on the latents: split-K follows
     # the row count), which the null-text optimisation of a RANDOM-weight net amplifies without bound -- so the batched
     # schedule is pinned where it is exact
-    one, many = tmp_path / "nti_one", tmp_path / "nti_many"
-    drive("p2p", one, "--inversion_type", "null-text")
-    drive("p2p", many, "--inversion_type", "null-text", "--in_flight", "2")
-    same(one, many)
-    one, many = tmp_path / "nti16_one", tmp_path / "nti16_many"
-    drive("p2p", one, "--inversion_type", "null-text", "--precision", "f16")
-    drive("p2p", many, "--inversion_type", "null-text", "--precision", "f16", "--invert_batch", "2", "--in_flight", "2")
-    same(one, many)
+    pairs = []
+    for folder in ("p2p", "pnp"):
+        pairs.append((folder, tmp_path / (folder + "_one"), (), tmp_path / (folder + "_many"), ("--invert_batch", "2", "--in_flight", "2")))
+    pairs.append(("p2p", tmp_path / "nti_one", ("--inversion_type", "null-text"),
+                  tmp_path / "nti_many", ("--inversion_type", "null-text", "--in_flight", "2")))
+    pairs.append(("p2p", tmp_path / "nti16_one", ("--inversion_type", "null-text", "--precision", "f16"),
+                  tmp_path / "nti16_many", ("--inversion_type", "null-text", "--precision", "f16", "--invert_batch", "2", "--in_flight", "2")))
+    jobs = []
+    for folder, one, f1, many, f2 in pairs:
+        jobs += [job(folder, one, *f1), job(folder, many, *f2)]
+    for d in run_parallel(jobs):                     # eight independent driver processes, four at a time
+        assert d.last_json()["images"] == 2, d.args
+    for folder, one, f1, many, f2 in pairs:
+        same(one, many)
 
 
 # ------------------------------------------------------------------------------------------------ Plug-and-Play on the XL family
