@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
                 step[j] = BK * 2;
             }
         } else {
-            const int n = n0 + 16 * blk + prow;
+            const int n = n0 + xp_perm_col<WN>(16 * blk + prow, p.geglu != 0);     // column order: x3p_common.h
             if (n < p.N) {
                 ptr[j] = (const char*)p.W + ((long long)plane[j] * p.planeW + (long long)n * p.ldw) * 2 + kcb + (long long)kt_lo * (BK * 2);
                 step[j] = BK * 2;
@@ -289,7 +289,10 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
     }
     if (!computes) return;
 
-    // ---------------- epilogue: a lane holds row m, columns n .. n + 3 of each 16 x 16 block
+    // ---------------- epilogue: blocks are paired (xp_perm_col): a lane holds row m and, of pair P, the EIGHT columns
+    // cb + 32 P + 8 fq .. + 7 (accumulator 2 P: the first four, 2 P + 1: the last four); of an odd last block columns 16 j + 4 fq .. + 3
+    constexpr int NP2 = TN / 2;
+    const int cb = n0 + wc * WN;
     const float inv = p.inv_scale;
     if (p.splits > 1) {
         float* slab = p.ws + (long long)blockIdx.y * p.M * p.N;
@@ -299,41 +302,68 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wc * WN + j * 16 + 4 * fq;
+                const int n = j < 2 * NP2 ? cb + 32 * (j >> 1) + 8 * fq + 4 * (j & 1) : cb + j * 16 + 4 * fq;
                 if (n < p.N) *(f32x4*)(slab + (long long)m * p.N + n) = acc[j][i] * inv;
             }
         }
         return;
     }
     if (p.geglu) {
-        // weight rows interleaved [8 hidden | 8 gate] per 16-column block: lanes 0-31 of a block hold hidden columns 0-7 (4 per
-        // lane), lanes 32-63 the matching gate columns: one exchange with lane + 32, out[m][8 block + 4 fq .. + 3] = h * gelu(g)
+        // host layout of the weight rows: [8 hidden | 8 gate] per 16.  Pairs (xp_perm_col): accumulator 2 P = hidden pre-activations of
+        // output columns cb / 2 + 16 P + 4 fq .. + 3, accumulator 2 P + 1 = their gates, in the same lane: out = h * gelu(g), no exchange.
+        // Odd last block: lanes 0-31 hold its 8 hidden columns (4 per lane), lanes 32-63 the gates; each half finishes two of the
+        // partner pair's four outputs (one exchange of two values with lane ^ 32)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * WM + i * 16 + fr;
             float mu = 0.f, rs = 1.f;
             if (p.rstat_in && m < p.M) xp_ln_row(p, m, mu, rs);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nb = n0 + wc * WN + j * 16, n = nb + 4 * fq;
+            for (int P = 0; P < NP2; ++P) {
+                const int nh = cb + 32 * P + 16 * (fq >> 1) + 4 * (fq & 1), ng = nh + 8;       // weight rows of this lane's hidden / gate columns
+                if (m >= p.M || nh >= p.N) continue;
+                f32x4 hv = acc[2 * P][i] * inv, gv = acc[2 * P + 1][i] * inv;
+                if (p.rstat_in) {
+                    hv = (hv - *(const f32x4*)(p.colsum + nh) * mu) * rs;
+                    gv = (gv - *(const f32x4*)(p.colsum + ng) * mu) * rs;
+                }
+                if (p.bias) { hv += *(const f32x4*)(p.bias + nh); gv += *(const f32x4*)(p.bias + ng); }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_nb(gv[e]) * p.out_scale;
+                const int no = cb / 2 + 16 * P + 4 * fq;
+                if (p.Out) *(f32x4*)(p.Out + (long long)m * p.ldo + no) = o;
+                if (p.OutP) {
+                    half4 h, l;
+                    split4(o, 1.0f, h, l);
+                    half_t* op = p.OutP + (long long)m * p.ldp + no;
+                    *(half4*)op = h;
+                    *(half4*)(op + p.planeO) = l;
+                }
+            }
+            if constexpr (TN & 1) {
+                constexpr int j = TN - 1;
+                const int nb = cb + j * 16, n = nb + 4 * fq;
+                const bool lo_half = fq < 2;
                 f32x4 v = acc[j][i] * inv;
-                if (p.rstat_in && n < p.N) v = (v - *(const f32x4*)(p.colsum + n) * mu) * rs;        // LayerNorm folded (x3p_common.h)
+                if (p.rstat_in && n < p.N) v = (v - *(const f32x4*)(p.colsum + n) * mu) * rs;
                 if (p.bias && n < p.N) v += *(const f32x4*)(p.bias + n);
-                f32x4 g;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = __shfl_xor(v[e], 32);
-                if (fq < 2 && m < p.M && n < p.N) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
-                    const int no = nb / 2 + 4 * fq;
-                    if (p.Out) *(f32x4*)(p.Out + (long long)m * p.ldo + no) = o;
+                // low lane: hidden 4 fq .. + 3, finishes columns + 0, + 1 (needs gates 0, 1 of lane + 32); high lane: gates, finishes
+                // columns + 2, + 3 of its partner (needs the partner's hidden 2, 3)
+                const float x0 = __shfl_xor(lo_half ? v[2] : v[0], 32), x1 = __shfl_xor(lo_half ? v[3] : v[1], 32);
+                const float o0 = (lo_half ? v[0] * gelu_nb(x0) : x0 * gelu_nb(v[2])) * p.out_scale;
+                const float o1 = (lo_half ? v[1] * gelu_nb(x1) : x1 * gelu_nb(v[3])) * p.out_scale;
+                const int no = nb / 2 + (lo_half ? 4 * fq : 4 * (fq - 2) + 2);
+                if (m < p.M && nb < p.N) {
+                    if (p.Out) *(f32x2*)(p.Out + (long long)m * p.ldo + no) = f32x2{o0, o1};
                     if (p.OutP) {
-                        half4 h, l;
-                        split4(o, 1.0f, h, l);
+                        const half2_t h = __builtin_convertvector(f32x2{o0, o1}, half2_t);
+                        float r0, r1;
+                        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(o0), "v"(h));
+                        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(o1), "v"(h));
                         half_t* op = p.OutP + (long long)m * p.ldp + no;
-                        *(half4*)op = h;
-                        *(half4*)(op + p.planeO) = l;
+                        *(half2_t*)op = h;
+                        *(half2_t*)(op + p.planeO) = __builtin_convertvector(f32x2{r0, r1}, half2_t);
                     }
                 }
             }
@@ -349,20 +379,38 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
         if (p.rstat_in && mok) xp_ln_row(p, m, mu, rs);
         f32x4 vv[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * WN + j * 16 + 4 * fq;
-            vv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) vv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int P = 0; P < NP2; ++P) {
+            const int n = cb + 32 * P + 8 * fq;
+            if (!mok || n >= p.N) continue;
+            f32x4 v0 = acc[2 * P][i] * inv, v1 = acc[2 * P + 1][i] * inv;
+            if (n + 4 < p.N) {
+                if (p.rstat_in) {                                                          // LayerNorm folded
+                    v0 = (v0 - *(const f32x4*)(p.colsum + n) * mu) * rs;
+                    v1 = (v1 - *(const f32x4*)(p.colsum + n + 4) * mu) * rs;
+                }
+                xp_store8(p, v0, v1, m, n);
+                vv[2 * P] = v0; vv[2 * P + 1] = v1;
+            } else {
+                if (p.rstat_in) v0 = (v0 - *(const f32x4*)(p.colsum + n) * mu) * rs;
+                vv[2 * P] = xp_store(p, v0, m, n);
+            }
+        }
+        if constexpr (TN & 1) {
+            constexpr int j = TN - 1;
+            const int n = cb + j * 16 + 4 * fq;
             if (mok && n < p.N) {
                 f32x4 v = acc[j][i] * inv;
-                if (p.rstat_in) v = (v - *(const f32x4*)(p.colsum + n) * mu) * rs;                    // LayerNorm folded
+                if (p.rstat_in) v = (v - *(const f32x4*)(p.colsum + n) * mu) * rs;
                 vv[j] = xp_store(p, v, m, n);
             }
         }
         if (p.rstat_out) {        // (mean, M2) of this wave's WN-column slice of row m (host-checked: N % WN == 0): every lane shuffles
             float sm, sq;
             xp_row_stats<TN>(vv, sm, sq);
-            if (fq == 0 && mok && n0 + wc * WN < p.N) {
-                float* ro = p.rstat_out + ((long long)m * slots_out + (n0 + wc * WN) / WN) * 2;
+            if (fq == 0 && mok && cb < p.N) {
+                float* ro = p.rstat_out + ((long long)m * slots_out + cb / WN) * 2;
                 ro[0] = sm; ro[1] = sq;
             }
         }

@@ -861,6 +861,13 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
 //   NWV waves per workgroup (32 queries each).  d = 40: 8 waves / 256 queries: two workgroups (80 KiB of LDS, 16 waves) per CU --
 //   four 40-KiB workgroups of 4 waves are exactly the CU's 160 KiB and were NOT co-resident (measured: still a second round);
 //   a tile is then also staged once for 256 queries instead of 128.
+//   Tried and dropped (round 4): an in-wave software pipeline -- 32-key sub-steps, O^T += V^T(s-1) P^T(s-1) chunk by chunk beside
+//   the exp / split of sub-step s, transposing reads by inline asm with counted lgkmcnt, two P sets swapping roles.  Inside the 128
+//   registers of four waves per SIMD it spills (O^T 32 + Q 24 + S 16 + two P sets 32 + fragments 16); at two waves per SIMD
+//   (177 registers, one 8-wave workgroup per CU) it was parity-green and SLOWER: N = 4096 425 us vs 360, N = 16384 5.72 ms vs 5.11
+//   (SQ counters: 30 % more vector instructions per key from the operand-tuple moves the register allocator inserts, and half
+//   the waves to hide the rest behind).  What did pay on this loop: the lazy maximum, the split scale in the exponent and raised
+//   priority in the matrix phases (360 -> 347 us, 5.11 -> 5.01 ms).
 template <int D, int KS, int NWV>
 __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kernel(const IefAttnF32Params p) {
     constexpr int DG = (D + 15) / 16, DT = (D + 31) / 32;
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
     constexpr int NP = PL * 2 / 1024;            // LDS-DMA pieces per plane
     static_assert((PL * 2) % 1024 == 0, "a plane of a tile is a whole number of LDS-DMA pieces");
     constexpr bool SWZ = D == 64;
-    constexpr float SP = 16384.f;
+    constexpr float LOGSP = 10.f, THR = 5.f;
     __shared__ __attribute__((aligned(1024))) half_t smem_p[2 * 4 * PL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -963,7 +970,8 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
         const half_t* Kl = Kh + PL;
         const half_t* Vh = Kl + PL;
         const half_t* Vl = Vh + PL;
-        f32x16 sacc[KS];
+        __builtin_amdgcn_s_setprio(1);                      // matrix phases run at raised priority: at equal priority the vector streams of
+        f32x16 sacc[KS];                                    // the SIMD's other waves take the issue port and the MFMAs of this one starve
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
 #pragma unroll
@@ -977,7 +985,8 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
                 sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc[u], 0, 0, 0);
             }
         }
-        // online softmax (register r <-> key (r & 3) + 8 (r >> 2) + 4 lh of its sub-tile), as attn_flash_x3_kernel
+        __builtin_amdgcn_s_setprio(0);
+        // online softmax (register r <-> key (r & 3) + 8 (r >> 2) + 4 lh of its sub-tile)
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
             if (t * KT + (u + 1) * 32 > p.L) {    // wave-uniform: only the tile that crosses L is masked
@@ -988,6 +997,9 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
                 }
             }
         }
+        // LAZY running maximum (as the fp16 kernel, csrc/attention.hip): it moves only when some score of the tile exceeds it by more
+        // than 2^THR in the exponent -- a wave-uniform test, no cross-lane exchange and no rescale on the common path; P <= 2^THR then,
+        // and the hi / lo split scale 2^LOGSP rides in the exponent (P' = 2^10 P <= 2^15: inside fp16; O and l carry it alike)
         float mxa = -INFINITY, mxb = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -1000,22 +1012,25 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
             }
         }
         float mx = fmaxf(mxa, mxb) * sc2;
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float ls = 0.f;
-#pragma unroll
-        for (int u = 0; u < KS; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][r], sc2, -m_new)); ls += sacc[u][r]; }
-        l_run = l_run * alpha + ls;
-        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + THR) != 0) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0, O and l are 0
 #pragma unroll
             for (int tt = 0; tt < DT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
         }
-        m_run = m_new;
+        const float mb = LOGSP - m_run;
+        float ls = 0.f;
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[u][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][r], sc2, mb)); ls += sacc[u][r]; }
+        l_run += ls;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
 #pragma unroll
@@ -1025,7 +1040,7 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
                 for (int c2 = 0; c2 < 2; ++c2) {
                     const f32x4 v = {sacc[u][8 * s2 + 4 * c2], sacc[u][8 * s2 + 4 * c2 + 1], sacc[u][8 * s2 + 4 * c2 + 2], sacc[u][8 * s2 + 4 * c2 + 3]};
                     half4 hh, ll;
-                    split4(v, SP, hh, ll);
+                    split4(v, 1.0f, hh, ll);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
                 }
@@ -1047,9 +1062,10 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / (l_tot * SP);
+    const float inv = 1.0f / l_tot;                          // O and l carry the same 2^10
     if (qi < p.N) {
 #pragma unroll
         for (int tt = 0; tt < DT; ++tt)

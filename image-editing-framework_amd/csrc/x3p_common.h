@@ -47,6 +47,57 @@ __device__ __forceinline__ f32x4 xp_store(const IefGemmX3pParams& p, f32x4 v, in
     return v;
 }
 
+// ---- column order of the implicit GEMM's weight block (igemm_x3p_kernel).  The MFMA hands a lane FOUR consecutive output columns
+// of a 16-column block (rows 4 fq .. 4 fq + 3 of its A operand = the weight block).  Which weight row feeds which MFMA row is the
+// staging's choice, so blocks are PAIRED: LDS row rho of block b (0 / 1) of pair P of a wave's WN-column slice holds
+//   plain:  slice column 32 P + 8 (rho >> 2) + 4 b + (rho & 3)   -> a lane's two accumulators are EIGHT consecutive columns: fp32
+//           results leave as 32 contiguous bytes per lane (a row's 128 bytes from four lanes), planes as 16-byte stores -- measured
+//           with 4-column lanes: FeedForward.net[0] with planes out 123 us vs 99 us with fp32 out of twice the bytes
+//   GEGLU:  weight rows come interleaved [8 hidden | 8 gate] per 16 (host layout); slice row 32 P + 16 (rho >> 3) + 8 b + (rho & 7):
+//           block 0 = the pair's 16 hidden columns, block 1 = their 16 gates -- hidden and gate of a column meet in ONE lane (no
+//           cross-lane exchange, every lane evaluates gelu, a lane stores four consecutive outputs)
+// An odd last block of the slice (WN = 80: the fifth) keeps the identity order.
+template <int WN>
+__device__ __forceinline__ int xp_perm_col(int q, bool geglu) {
+    constexpr int TN = WN / 16, NP2 = TN / 2;
+    const int w = q / WN, lq = q - w * WN, jb = lq >> 4, rho = lq & 15;
+    if (jb >= 2 * NP2) return q;
+    const int P = jb >> 1, b = jb & 1;
+    const int off = geglu ? 32 * P + 16 * (rho >> 3) + 8 * b + (rho & 7) : 32 * P + 8 * (rho >> 2) + 4 * b + (rho & 3);
+    return w * WN + off;
+}
+
+// eight consecutive columns n .. n + 7 of row m (both halves inside N): the pair form of xp_store
+__device__ __forceinline__ void xp_store8(const IefGemmX3pParams& p, f32x4& v0, f32x4& v1, int m, int n) {
+    if (p.bias) { v0 += *(const f32x4*)(p.bias + n); v1 += *(const f32x4*)(p.bias + n + 4); }
+    if (p.rowvec) {
+        const float* rv = p.rowvec + (long long)(m / p.rows_per_batch) * p.N + n;
+        v0 += *(const f32x4*)rv; v1 += *(const f32x4*)(rv + 4);
+    }
+    if (p.residual) {
+        const float* rr = p.residual + (long long)m * p.ldr + n;
+        v0 += *(const f32x4*)rr; v1 += *(const f32x4*)(rr + 4);
+    }
+    v0 = v0 * p.out_scale; v1 = v1 * p.out_scale;
+    if (p.Out) {
+        float* o = p.Out + (long long)m * p.ldo + n;
+        *(f32x4*)o = v0; *(f32x4*)(o + 4) = v1;
+    }
+    if (p.OutP) {
+        half4 h0, l0, h1, l1;
+        split4(v0, 1.0f, h0, l0);
+        split4(v1, 1.0f, h1, l1);
+        half_t* o = p.OutP + (long long)m * p.ldp + n;
+        if ((((uintptr_t)o | (uintptr_t)(p.planeO * 2)) & 15) == 0) {
+            *(half8*)o = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            *(half8*)(o + p.planeO) = half8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        } else {
+            *(half4*)o = h0; *(half4*)(o + 4) = h1;
+            *(half4*)(o + p.planeO) = l0; *(half4*)(o + p.planeO + 4) = l1;
+        }
+    }
+}
+
 // ---- LayerNorm folded into the consumer GEMM (IefGemmX3pParams.rstat_*): (mean, rstd) of row m of the launch's A operand from
 // the producer's per-slice (mean, M2) partials, merged Chan-style in slice order (deterministic)
 __device__ __forceinline__ void xp_ln_row(const IefGemmX3pParams& p, int m, float& mean, float& rstd) {

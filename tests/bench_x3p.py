@@ -35,10 +35,12 @@ def main():
     ap.add_argument("--lin", action="store_true")
     ap.add_argument("--splits", default="1")
     ap.add_argument("--attn", action="store_true", help="the fused split-operand attention at the step's sequence lengths")
+    ap.add_argument("--geglu", action="store_true", help="FeedForward.net[0] as the step runs it: bias + GEGLU epilogue, planes out only")
     args = ap.parse_args()
     tiles = [int(t) for t in args.tiles.split(",")]
     splits = [int(s) for s in args.splits.split(",")]
-    do_lin, do_conv = args.lin or not (args.conv or args.attn), args.conv or not (args.lin or args.attn)
+    only = args.conv or args.attn or args.lin or args.geglu
+    do_lin, do_conv = args.lin or not only, args.conv or not only
     with hip.f32_contraction("x3"):
         if args.attn:
             for B, heads, N, d in [(4, 8, 4096, 40), (4, 8, 1024, 80), (4, 8, 256, 160), (4, 8, 16384, 40), (4, 5, 9216, 64), (1, 10, 4096, 64)]:
@@ -51,6 +53,25 @@ def main():
                 uspp = hip._time_graph(lambda i: planes.attn_flash(qp[..., :C], qp[..., C:2 * C], qp[..., 2 * C:], heads, d ** -0.5), iters=5) if d in planes.FLASH_PLANES_DIMS else float("nan")
                 print(f"attn_flash_x3 B={B} h={heads} N={N:6d} d={d:3d}: {us:9.1f} us {fl / us / 1e6:6.1f} TF  (planes out: {usp:9.1f} us; planes in + out: "
                       f"{uspp:9.1f} us {fl / uspp / 1e6:6.1f} TF)", flush=True)
+        if args.geglu:
+            for M, N, K in [(16384, 2560, 320), (4096, 5120, 640), (1024, 10240, 1280), (256, 10240, 1280)]:
+                a, w, bias = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+                wc = hip._cold_copies(w)
+                for x in wc:
+                    planes.weight_planes(x)
+                ap_ = planes.split(a)
+                outp = planes.Planes.empty(M, N // 2, device="cuda")
+                fl = 2.0 * M * N * K
+                line = f"ff1+geglu {M:6d}x{N:5d}x{K:5d} |"
+                for t in tiles:
+                    bm, bn = planes._TILES[t]
+                    if N % bn:
+                        continue
+                    us = hip._time_graph(lambda i: planes.gemm(ap_, wc[i % len(wc)], bias=bias, geglu=True, out=False, out_planes=outp, tile=t, splits=1))
+                    us0 = hip._time_graph(lambda i: planes.gemm(ap_, wc[i % len(wc)], bias=bias, out=False, out_planes=True, tile=t, splits=1))
+                    line += f" t{t}: {us:7.1f} us {fl / us / 1e6:6.1f} TF (no geglu, planes out: {us0:7.1f}) |"
+                print(line, flush=True)
+                del wc
         if do_lin:
             for M, N, K in LIN:
                 a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 from PIL import Image
 
-from _procs import run_parallel
+from _procs import call_main, run_mixed
 
 pytestmark = pytest.mark.gpu
 
@@ -122,9 +122,10 @@ def test_pie_driver_batched_inversion_matches_per_image(tmp_path):
     are independent, so the PNGs must match the per-image run."""
     a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
     base = [os.path.join(P2P, "test.py"), "--sd_version", "tiny", "--synthetic", "3"]
-    done = run_parallel([(base + ["--exp_path", str(a)], tmp_path / "cwd_a"),
-                         (base + ["--invert_batch", "2", "--exp_path", str(b)], tmp_path / "cwd_b"),
-                         (base + ["--invert_batch", "3", "--in_flight", "2", "--exp_path", str(c)], tmp_path / "cwd_c")])
+    script, base = base[0], base[1:]
+    done = [call_main(script, base + ["--exp_path", str(a)], tmp_path / "cwd_a"),
+            call_main(script, base + ["--invert_batch", "2", "--exp_path", str(b)], tmp_path / "cwd_b"),
+            call_main(script, base + ["--invert_batch", "3", "--in_flight", "2", "--exp_path", str(c)], tmp_path / "cwd_c")]
     for d in done:
         assert d.last_json()["images"] == 3
     for other in (b, c):
@@ -146,7 +147,7 @@ def test_masactrl_edit_real_and_pie_driver(tmp_path):
               str(tmp_path / "test.jpg")], tmp_path / inv) for inv in ("ddim", "null-text")]
     jobs.append(([os.path.join(masa, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--exp_path", str(tmp_path / "t")],
                  tmp_path / "cwd_t"))
-    done = run_parallel(jobs)
+    done = run_mixed(jobs, in_process=(1,))
     for inv in ("ddim", "null-text"):
         for name in ("source.png", "inversion.png", "edit.png"):
             assert (tmp_path / inv / "exp" / name).exists()

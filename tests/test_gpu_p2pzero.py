@@ -16,7 +16,7 @@ import pytest
 import torch
 from PIL import Image
 
-from _procs import run_parallel
+from _procs import run_mixed
 
 pytestmark = pytest.mark.gpu
 
@@ -204,7 +204,7 @@ def test_p2pzero_clis(tmp_path):
     for inv in ("ddim", "null-text"):
         jobs.append(([os.path.join(folder, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
                       str(tmp_path / "test.jpg")], tmp_path / inv))
-    run_parallel(jobs)
+    run_mixed(jobs, in_process=(2,))
     src = np.array(Image.open(tmp_path / "syn" / "exp" / "source.png")).astype(int)
     edit = np.array(Image.open(tmp_path / "syn" / "exp" / "edit.png")).astype(int)
     assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0
@@ -216,8 +216,8 @@ def test_p2pzero_clis(tmp_path):
 def test_p2pzero_pie_driver(tmp_path):
     folder = os.path.join(ROOT, "image-editing-framework_amd", "pix2pix_zero")
     invs = ("ddim", "null-text")
-    done = run_parallel([([os.path.join(folder, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--invert_batch", "2",
-                           "--inversion_type", inv, "--exp_path", str(tmp_path / inv)], tmp_path / ("cwd_" + inv)) for inv in invs])
+    done = run_mixed([([os.path.join(folder, "test.py"), "--sd_version", "tiny", "--synthetic", "2", "--invert_batch", "2",
+                           "--inversion_type", inv, "--exp_path", str(tmp_path / inv)], tmp_path / ("cwd_" + inv)) for inv in invs], in_process=(1,))
     for inv, d in zip(invs, done):
         rec = d.last_json()
         assert rec["images"] == 2 and rec["images_per_sec"] > 0

@@ -12,7 +12,7 @@ import pytest
 import torch
 from PIL import Image
 
-from _procs import run_parallel
+from _procs import run_mixed
 
 pytestmark = pytest.mark.gpu
 
@@ -142,7 +142,7 @@ def test_pnp_clis(tmp_path):
     for inv in ("ddim", "null-text"):
         jobs.append(([os.path.join(pnp, "edit_real.py"), "--sd_version", "tiny", "--inversion_type", inv, "--source_image",
                       str(tmp_path / "test.jpg")], tmp_path / inv))
-    run_parallel(jobs)
+    run_mixed(jobs, in_process=(2,))
     src = np.array(Image.open(tmp_path / "syn" / "exp" / "source.png")).astype(int)
     edit = np.array(Image.open(tmp_path / "syn" / "exp" / "edit.png")).astype(int)
     assert src.shape == edit.shape == (128, 128, 3) and np.abs(src - edit).max() > 0

@@ -81,7 +81,7 @@ import sys  # noqa: E402
 import numpy as np  # noqa: E402
 from PIL import Image  # noqa: E402
 
-from _procs import run_parallel  # noqa: E402
+from _procs import call_main, run_mixed  # noqa: E402
 
 from ief_amd.pipeline import StableDiffusionXLPipeline  # noqa: E402
 from ief_amd.p2p.model.sd_utils import P2P_XL  # noqa: E402
@@ -244,9 +244,9 @@ def test_p2pzero_xl_clis(tmp_path):
     rng = np.random.RandomState(0)
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
-    run_parallel([([os.path.join(folder, "edit_syn.py"), "--sd_version", "smallxl"], tmp_path / "syn"),
+    run_mixed([([os.path.join(folder, "edit_syn.py"), "--sd_version", "smallxl"], tmp_path / "syn"),
                   ([os.path.join(folder, "edit_real.py"), "--sd_version", "smallxl", "--inversion_type", "ddim", "--source_image",
-                    str(tmp_path / "test.jpg")], tmp_path / "real")])
+                    str(tmp_path / "test.jpg")], tmp_path / "real")], in_process=(0,))
     for name in ("source.png", "edit.png"):
         assert (tmp_path / "syn" / "exp" / name).exists()
     for name in ("source.png", "inversion.png", "edit.png"):
@@ -381,9 +381,9 @@ def test_xl_null_text_clis(tmp_path):
     img = np.kron(rng.randint(0, 255, (8, 8, 3)), np.ones((16, 16, 1))).astype(np.uint8)
     Image.fromarray(img).save(tmp_path / "test.jpg")
     folders = ("p2p", "pix2pix_zero")
-    run_parallel([([os.path.join(ROOT, "image-editing-framework_amd", folder, "edit_real.py"), "--sd_version", "smallxl",
+    run_mixed([([os.path.join(ROOT, "image-editing-framework_amd", folder, "edit_real.py"), "--sd_version", "smallxl",
                     "--inversion_type", "null-text", "--source_image", str(tmp_path / "test.jpg")], tmp_path / folder)
-                  for folder in folders])
+                  for folder in folders], in_process=(0,))
     for folder in folders:
         for name in ("source.png", "inversion.png", "edit.png"):
             assert (tmp_path / folder / "exp" / name).exists()
@@ -438,7 +438,7 @@ def test_xl_drivers_and_masactrl_clis(tmp_path):
     for folder, inv in (("p2p", "null-text"), ("masactrl", "ddim")):
         jobs.append(([os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "1", "--inversion_type", inv,
                       "--exp_path", str(tmp_path / folder)], tmp_path / ("cwd_" + folder)))
-    done = run_parallel(jobs)
+    done = run_mixed(jobs, in_process=(1,))
     assert (tmp_path / "exp" / "edit.png").exists()
     for d in done[1:]:
         assert d.last_json()["images"] == 1, d.args
@@ -452,9 +452,10 @@ def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
     import json
     pkg = os.path.join(ROOT, "image-editing-framework_amd")
 
-    def job(folder, out, *flags):
-        return ([os.path.join(pkg, folder, "test.py"), "--sd_version", "smallxl", "--synthetic", "2", "--exp_path", str(out)]
-                + list(flags), tmp_path / ("cwd_" + out.name))
+    def drive(folder, out, *flags):
+        d = call_main(os.path.join(pkg, folder, "test.py"), ["--sd_version", "smallxl", "--synthetic", "2", "--exp_path", str(out)]
+                      + list(flags), tmp_path / ("cwd_" + out.name))
+        assert d.last_json()["images"] == 2, d.args
 
     def same(a, b):
         dirs = sorted(x for x in os.listdir(a) if x.startswith("syn_"))
@@ -476,11 +477,9 @@ def test_xl_pie_drivers_batched_and_in_flight_match_per_image(tmp_path):
                   tmp_path / "nti_many", ("--inversion_type", "null-text", "--in_flight", "2")))
     pairs.append(("p2p", tmp_path / "nti16_one", ("--inversion_type", "null-text", "--precision", "f16"),
                   tmp_path / "nti16_many", ("--inversion_type", "null-text", "--precision", "f16", "--invert_batch", "2", "--in_flight", "2")))
-    jobs = []
-    for folder, one, f1, many, f2 in pairs:
-        jobs += [job(folder, one, *f1), job(folder, many, *f2)]
-    for d in run_parallel(jobs):                     # eight independent driver processes, four at a time
-        assert d.last_json()["images"] == 2, d.args
+    for folder, one, f1, many, f2 in pairs:            # eight driver runs, in this process (tests/_procs.py)
+        drive(folder, one, *f1)
+        drive(folder, many, *f2)
     for folder, one, f1, many, f2 in pairs:
         same(one, many)
 
