@@ -1345,6 +1345,10 @@ extern "C" int ief_gather_rows_f32(const float* in, float* out, const int* src, 
 
 // --------------------------------------------------------------------------------------------- boundary convolutions
 // conv_in:  fp32 NCHW [B,Cin<=8,H,W] -> fp32 NHWC [B,H,W,Cout]; w fp32 [3][3][Cin][Cout].  One thread per (pixel, 4 channels).
+// CIN > 0: the channel count is a compile-time constant and every load of a tap ROW (3 taps x CIN activations, 3 x CIN weight
+// vectors) is requested before the first is used -- the plain loop below issued 9 x Cin dependent load pairs per thread (40 us for
+// the 0.38 GFLOP of SD's 4 -> 320 at 64 x 64, batch 4).  The accumulation order (tap, channel) is the loop's: same bits.
+template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int B, int Cin,
                                                           int H, int Wd, int Cout) {
@@ -1357,14 +1361,43 @@ __global__ __launch_bounds__(256) void conv_in_f32_kernel(const float* __restric
         const int rem = (int)(pix - (long long)b * H * Wd);
         const int oy = rem / Wd, ox = rem - oy * Wd;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int tap = 0; tap < 9; ++tap) {
-            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-            if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float v = x[(((long long)b * Cin + ci) * H + iy) * Wd + ix];
-                const f32x4 wv = *(const f32x4*)(w + ((long long)(tap * Cin + ci)) * Cout + c4 * 4);
+        if constexpr (CIN > 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += v * wv[e];
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy + ky - 1;
+                const bool yok = (unsigned)iy < (unsigned)H;
+                float v[3][CIN];
+                f32x4 wv[3][CIN];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox + kx - 1;
+                    const bool ok = yok && (unsigned)ix < (unsigned)Wd;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        v[kx][ci] = ok ? x[(((long long)b * CIN + ci) * H + iy) * Wd + ix] : 0.f;
+                        wv[kx][ci] = *(const f32x4*)(w + ((long long)((ky * 3 + kx) * CIN + ci)) * Cout + c4 * 4);
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox + kx - 1;
+                    if (!(yok && (unsigned)ix < (unsigned)Wd)) continue;       // a padded tap adds nothing (as the plain loop: skipped, not + 0)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] += v[kx][ci] * wv[kx][ci][e];
+                }
+            }
+        } else {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+                if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float v = x[(((long long)b * Cin + ci) * H + iy) * Wd + ix];
+                    const f32x4 wv = *(const f32x4*)(w + ((long long)(tap * Cin + ci)) * Cout + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v * wv[e];
+                }
             }
         }
         if (bias) {
@@ -1381,7 +1414,8 @@ extern "C" int ief_conv_in_f32act(const float* x, const float* w, const float* b
     const long long total = (long long)B * H * Wd * (Cout / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(conv_in_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, Cin, H, Wd, Cout);
+    if (Cin == 4) hipLaunchKernelGGL(conv_in_f32_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, Cin, H, Wd, Cout);
+    else hipLaunchKernelGGL(conv_in_f32_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, Cin, H, Wd, Cout);
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }
@@ -1430,13 +1464,89 @@ __global__ __launch_bounds__(256) void conv_out_f32_kernel(const float* __restri
         for (int o = 0; o < Cout; ++o) out[(((long long)b * Cout + o) * H + oy) * Wd + ox] = acc[o] + (bias ? bias[o] : 0.f);
     }
 }
+// The same with the weights ([Cout][9][C] fp32: 46 KB for SD's 320 -> 4) staged in LDS once per workgroup and, per pixel, the
+// activation chunks of a whole tap ROW (3 taps x CH chunks of 4 channels per lane) requested before the first is used: the loop
+// above issues one dependent activation + Cout weight loads per chunk (45 round trips per pixel: 65 us for 0.38 GFLOP).  Per lane
+// and output channel the products are added in the loop's order (tap, chunk, element): same bits.
+template <int CH>            // chunks of 4 channels per lane and tap: C <= 64 CH
+__global__ __launch_bounds__(256) void conv_out_f32_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out, int B, int C,
+                                                               int H, int Wd, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float wl_f32[];          // [Cout][9][C]
+    const int sub = threadIdx.x & 15;
+    const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long total = (long long)B * H * Wd;
+    const bool live = pix < total;
+    const long long pc = live ? pix : 0;
+    const int b = (int)(pc / (H * Wd));
+    const int rem = (int)(pc - (long long)b * H * Wd);
+    const int oy = rem / Wd, ox = rem - oy * Wd;
+    const int C4 = C >> 2;
+    const int nw4 = (Cout * 9 * C) >> 2;
+    for (int i = threadIdx.x; i < nw4; i += 256) ((f32x4*)wl_f32)[i] = ((const f32x4*)w)[i];
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        const bool yok = live && (unsigned)iy < (unsigned)H;
+        f32x4 v[3][CH];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            const bool ok = yok && (unsigned)ix < (unsigned)Wd;
+            const float* xp = x + (((long long)b * H + (ok ? iy : 0)) * Wd + (ok ? ix : 0)) * C;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int c4 = sub + 16 * j;
+                v[kx][j] = (ok && c4 < C4) ? *(const f32x4*)(xp + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            if (!(yok && (unsigned)ix < (unsigned)Wd)) continue;               // a padded tap adds nothing (skipped, as in the loop above)
+            const int tap = ky * 3 + kx;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int c4 = sub + 16 * j;
+                if (c4 < C4) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        if (o < Cout) {
+                            const f32x4 wv = *(const f32x4*)(wl_f32 + (o * 9 + tap) * C + c4 * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[o] += v[kx][j][e] * wv[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+    }
+    if (live && sub == 0) {
+        for (int o = 0; o < Cout; ++o) out[(((long long)b * Cout + o) * H + oy) * Wd + ox] = acc[o] + (bias ? bias[o] : 0.f);
+    }
+}
 extern "C" int ief_conv_out_f32act(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int Wd,
                                    int Cout, void* stream) {
     if (!x || !w || !out) return IEF_EINVAL;
     if (B <= 0 || H <= 0 || Wd <= 0 || C <= 0 || (C & 3) || Cout <= 0 || Cout > 8) return IEF_ESHAPE;
     const long long total = (long long)B * H * Wd;
-    hipLaunchKernelGGL(conv_out_f32_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out,
-                       B, C, H, Wd, Cout);
+    const size_t lds = (size_t)Cout * 9 * C * sizeof(float);
+    const dim3 grid((unsigned)((total + 15) / 16));
+    if (lds <= 48 * 1024 && C <= 320 && Cout <= 4) {
+        if (C <= 128) hipLaunchKernelGGL(conv_out_f32_lds_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, out, B, C, H, Wd, Cout);
+        else hipLaunchKernelGGL(conv_out_f32_lds_kernel<5>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, out, B, C, H, Wd, Cout);
+    } else {
+        hipLaunchKernelGGL(conv_out_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, C, H, Wd, Cout);
+    }
     IEF_LAUNCH_CHECK();
     return IEF_OK;
 }

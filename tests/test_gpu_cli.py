@@ -80,7 +80,8 @@ def test_bench_under_torchrun_one_rank(tmp_path):
     """the exact launch line the driver uses for N > 1, with N = 1 (one GPU on this box)"""
     out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-               "--config", "small", "--no-cpu-baseline", "--pie-images", "2", "--steps-1024", "2"], cwd=ROOT, timeout=900)
+               "--config", "small", "--no-cpu-baseline", "--pie-images", "2", "--steps-1024", "2", "--other-modes", "f16", "--in-flight", "2",
+               "--nti-images", "0"], cwd=ROOT, timeout=900)
     rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 6 and rec["value"] > 0 and "roofline" in rec
     # BASELINE.json's second metric and north_star's second latent size ride on the same line

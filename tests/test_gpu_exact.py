@@ -239,6 +239,16 @@ def test_boundary_convs_and_image_epilogue_f32():
     y = hip.conv_out(h, dev(w_out.permute(0, 2, 3, 1).contiguous()), dev(b_out))
     ref2 = F.conv2d(ref.permute(0, 3, 1, 2), w_out.double(), b_out.double(), padding=1)
     assert y.shape == (2, 4, 16, 16) and rel_err(y, ref2.float()) < KTOL
+    # SD's own widths (4 -> 320 -> 4: the LDS-resident weight set of conv_out takes its widest form), ragged image size
+    x = f32(1, 4, 9, 7, seed=11)
+    w_in, b_in = f32(320, 4, 3, 3, seed=12, scale=1 / 6.0), f32(320, seed=13, scale=0.1)
+    h = hip.conv_in(dev(x), dev(w_in.permute(2, 3, 1, 0).contiguous()), dev(b_in))
+    ref = F.conv2d(x.double(), w_in.double(), b_in.double(), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(h, ref.float()) < KTOL
+    w_out, b_out = f32(4, 320, 3, 3, seed=14, scale=1 / 54.0), f32(4, seed=15, scale=0.1)
+    y = hip.conv_out(h, dev(w_out.permute(0, 2, 3, 1).contiguous()), dev(b_out))
+    ref2 = F.conv2d(ref.permute(0, 3, 1, 2), w_out.double(), b_out.double(), padding=1)
+    assert y.shape == (1, 4, 9, 7) and rel_err(y, ref2.float()) < KTOL
     img = f32(2, 3, 32, 40, seed=6) * 0.8
     got = hip.image_u8(dev(img)).cpu().numpy()
     want = ((img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).astype("uint8")     # sd_utils.py:85-88
