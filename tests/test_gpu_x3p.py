@@ -295,3 +295,32 @@ def test_layernorm_folded_into_the_consumer_gemm(M, C, N):
         gref = (pre[:, :, 0] * F.gelu(pre[:, :, 1])).reshape(M, N // 2)
         g = planes.gemm(hp, f.w, bias=f.bias, geglu=True, ln=(st, f.colsum, f.eps))
         assert rel_err(g, gref) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------- GroupNorm as a producer of planes
+@pytest.mark.parametrize("B,H,W,C1,C2,groups,silu", [
+    (4, 64, 64, 320, 0, 32, True),          # three row-streaming launches (the 64 x 64 level of the SD1.5 step)
+    (2, 32, 32, 640, 640, 32, True),        # channel concat
+    (2, 16, 16, 1280, 640, 32, True),       # one launch (small levels); 60 channels per group: group 21 straddles the two sources
+    (1, 8, 8, 1280, 1280, 32, False),
+    (3, 5, 7, 64, 0, 32, True),             # 2 channels per group, ragged image
+])
+def test_groupnorm_writes_planes(B, H, W, C1, C2, groups, silu):
+    """`planes.groupnorm` (three row-streaming launches / the one-launch form of the small levels) against fp64 on activations
+    with a 20-sigma offset (the centred second moment must not cancel); the planes are the split of the fp32 output bit for bit.
+    (Round 4 also built two other one-launch forms -- the (image, group) slab in the registers of one workgroup, and a
+    cooperative launch whose workgroups meet through arrival counters -- both parity-green and NOT faster: DESIGN.md section 3e.)"""
+    x = f32(B, H, W, C1, seed=1) + 20.0
+    x2 = f32(B, H, W, C2, seed=2) * 3.0 - 20.0 if C2 else None
+    gamma, beta = f32(C1 + C2, seed=3) * 0.5 + 1.0, f32(C1 + C2, seed=4) * 0.3
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    ref = F.group_norm(xin.permute(0, 3, 1, 2).double(), groups, gamma.double(), beta.double(), 1e-5).permute(0, 2, 3, 1)
+    if silu:
+        ref = F.silu(ref)
+    pl, o32 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2), out32=True)
+    e = rel_err(o32, ref)
+    assert_planes_equal_split(pl, o32)
+    pl2 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
+    e2 = rel_err(pl2.hi.float() + pl2.lo.float(), ref)
+    print(f"GroupNorm -> planes B={B} {H}x{W} C={C1}+{C2}: {e:.2e} (fp32 + planes), {e2:.2e} (planes only) vs fp64")
+    assert e < 2e-6 and e2 < 2e-6
