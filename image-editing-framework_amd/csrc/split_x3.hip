@@ -823,6 +823,7 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / (l_tot * SV * SP);
+    if (p.lse && qi < p.N && lh == 0) p.lse[((long long)b * p.heads + h) * p.N + qi] = m_run + __log2f(l_tot);     // for ief_attn_bwd_x3
     if (qi < p.N) {
 #pragma unroll
         for (int tt = 0; tt < DT; ++tt)

@@ -143,8 +143,10 @@ class UNetAdjoint:
             a1, a2, ff = blk.attn1, blk.attn2, blk.ff
             h0 = h
             qkv = hip.gemm(blk.norm1(h0), a1.w_qkv)
-            # fp16: the row log-sum-exp feeds the fused backward kernels; fp32: the backward re-materialises the maps
-            lse1 = None if self.f32 else torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device)
+            # fp16: the row log-sum-exp feeds the fused backward kernels; fp32 storage: the backward re-materialises the maps, except
+            # where the split-operand mode has its own fused recomputing kernel (hip.x3_fused_bwd_ok: the large self-attention levels)
+            want_lse = not self.f32 or hip.x3_fused_bwd_ok(C // a1.heads, N)
+            lse1 = torch.empty(B, a1.heads, N, dtype=torch.float32, device=x.device) if want_lse else None
             o1 = hip.attn_flash(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], a1.heads, a1.scale, lse=lse1)
             h1 = a1.to_out[0](o1, residual=h0)
             q2 = hip.gemm(blk.norm2(h1), a2.to_q.weight)

@@ -109,7 +109,17 @@ class IefAttnF32Params(Structure):
         ("x3", c_int),
         ("OutP", c_void_p), ("planeO", c_longlong), ("sOPb", c_longlong), ("ldp", c_int), ("p_scale", c_float),
         ("Qp", c_void_p), ("Kp", c_void_p), ("Vp", c_void_p), ("planeQ", c_longlong), ("planeK", c_longlong), ("planeV", c_longlong),
-        ("zeros", c_void_p),
+        ("zeros", c_void_p), ("lse", c_void_p),
+    ]
+
+
+class IefAttnBwdF32Params(Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("dO", c_void_p), ("lse", c_void_p), ("delta", c_void_p),
+        ("dQ", c_void_p), ("dK", c_void_p), ("dV", c_void_p),
+        ("B", c_int), ("heads", c_int), ("N", c_int), ("L", c_int), ("d", c_int),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int), ("lddq", c_int), ("lddk", c_int), ("lddv", c_int),
+        ("scale", c_float), ("ds_mul", c_float),
     ]
 
 
@@ -151,7 +161,7 @@ EXPORTS = [
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
     "ief_map_loss_rows_f32", "ief_nti_adam_f32g",
     # ABI 4: split-operand contractions on pre-split planes (csrc/gemm_x3p.hip)
-    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_gemm_x3p_tile_wn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small",
+    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_gemm_x3p_tile_wn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small", "ief_attn_bwd_x3", "ief_attn_bwd_delta_f32in",
 ]
 
 
@@ -268,6 +278,8 @@ def load():
     lib.ief_x3_split_act.argtypes = [c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_int, c_float, c_void_p]
     lib.ief_groupnorm_silu_x3p_ws.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                               c_int, c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]
+    lib.ief_attn_bwd_x3.argtypes = [POINTER(IefAttnBwdF32Params), c_int, c_void_p]
+    lib.ief_attn_bwd_delta_f32in.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.ief_groupnorm_silu_x3p_small.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,
                                                  c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.ief_layernorm_x3p.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p]
@@ -1360,9 +1372,10 @@ GN3_F32 = os.environ.get("IEF_GN3_F32", "1") == "1"          # 0: the one-launch
 FLASH_F32 = os.environ.get("IEF_FLASH_F32", "1") == "1"      # 0: always materialise the fp32 maps (A/B runs)
 
 
-def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, out_planes=False):
+def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=None, out_planes=False, lse=None):
     """fused fp32 attention (`ief_attn_flash_f32`): no map is written; None when the head dim has no instantiation.
-    out_planes (split-operand mode only): the result leaves as operand planes for to_out's GEMM (`planes.Planes`)"""
+    out_planes (split-operand mode only): the result leaves as operand planes for to_out's GEMM (`planes.Planes`);
+    lse (split-operand mode only): fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) for `ief_attn_bwd_x3`"""
     lib = load()
     B, N, C = q.shape
     L, d = k.shape[1], C // heads
@@ -1387,6 +1400,10 @@ def _attn_flash_f32(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, o
     p.sVb, _, p.ldv = _batched32(p, v, heads, d, "v")
     p.q_src, p.k_src, p.v_src = _ptr(_devi32(q_src, "q_src")), _ptr(_devi32(k_src, "k_src")), _ptr(_devi32(v_src, "v_src"))
     p.x3 = 1 if _F32_CONTRACT == "x3" else 0
+    if lse is not None:
+        if not p.x3 or tuple(_dev32(lse, "lse").shape) != (B, heads, N) or not lse.is_contiguous():
+            raise ValueError("attn_flash: lse (contiguous fp32 [B, heads, N]) is written by the split-operand kernel only")
+        p.lse = lse.data_ptr()
     with _Timed(f"attn_flash_{'x3' if p.x3 else 'f32'}_kernel<{d}>", 4.0 * B * heads * N * L * d, 4.0 * B * heads * d * (2 * N + 2 * L)):
         _check(lib.ief_attn_flash_f32(byref(p), _stream()), "ief_attn_flash_f32")
     return op if out_planes else out
@@ -1479,11 +1496,14 @@ def attn_flash(q, k, v, heads, scale, q_src=None, k_src=None, v_src=None, out=No
     lse: optional fp32 [B, heads, N] receiving the row log-sum-exp (log2 units) that `attn_bwd` consumes.
     fp32 operands (reference-precision mode): the maps are materialised in HBM, as the reference does."""
     if _is32(q):
-        if lse is not None:
-            raise ValueError("attn_flash: lse output exists only on the fp16 path (the fp32 backward recomputes the maps)")
-        o = _attn_flash_f32(q, k, v, heads, scale, q_src, k_src, v_src, out, out_planes=out_planes)
+        if lse is not None and not x3_fused_bwd_ok(q.shape[2] // heads, k.shape[1]):
+            raise ValueError("attn_flash: on fp32 operands lse exists only where ief_attn_bwd_x3 consumes it (x3_fused_bwd_ok); "
+                             "elsewhere the fp32 backward recomputes the maps")
+        o = _attn_flash_f32(q, k, v, heads, scale, q_src, k_src, v_src, out, out_planes=out_planes, lse=lse)
         if o is not None:
             return o
+        if lse is not None:
+            raise ValueError("attn_flash: the fused fp32 kernel is switched off (IEF_FLASH_F32=0): no lse")
         o = _attn_apply_f32(_attn_scores_f32(q, k, heads, scale, q_src, k_src), v, heads, v_src, out)
         if out_planes:
             from . import planes as _pl
@@ -1818,10 +1838,62 @@ def _softmax_bwd_f32_(probs, dprobs, scale):
     return dprobs
 
 
-def _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv):
+X3_FUSED_BWD = os.environ.get("IEF_X3_FUSED_BWD", "1") == "1"      # 0: the reverse pass keeps the materialised maps everywhere (A/B runs)
+
+
+def x3_fused_bwd_ok(d: int, L: int) -> bool:
+    """the fp32-storage reverse pass differentiates this attention layer with `ief_attn_bwd_x3` (P and dS recomputed per tile from
+    the forward's lse, no map in HBM): split-operand mode, head dims 40 / 64 (the levels whose maps are hundreds of MB), at
+    least 128 keys (self-attention; the 77-key cross maps are small and keep the materialised path)"""
+    return X3_FUSED_BWD and _F32_CONTRACT == "x3" and FLASH_F32 and d in (40, 64) and L >= 128
+
+
+def _attn_bwd_x3(q, k, v, o, do, lse, heads, scale, dq, dk, dv, want_dq, want_dkv):
+    lib = load()
+    B, N, C = q.shape
+    L, d = k.shape[1], C // heads
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (do, "do")):
+        _act32(t, nm)
+        if t.dim() != 3 or t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
+            raise ValueError(f"{nm}: expected [B, rows, heads*d] with unit channel stride and batch stride rows * ld")
+    delta = torch.empty(B, heads, N, dtype=torch.float32, device=q.device)
+    _check(lib.ief_attn_bwd_delta_f32in(o.data_ptr(), do.data_ptr(), delta.data_ptr(), B, heads, N, d, o.stride(1), do.stride(1),
+                                        _stream()), "ief_attn_bwd_delta_f32in")
+    p = IefAttnBwdF32Params()
+    p.Q, p.K, p.V, p.dO, p.lse, p.delta = q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(), _dev32(lse, "lse").data_ptr(), delta.data_ptr()
+    p.B, p.heads, p.N, p.L, p.d = B, heads, N, L, d
+    p.ldq, p.ldk, p.ldv, p.ldo = q.stride(1), k.stride(1), v.stride(1), do.stride(1)
+    p.scale, p.ds_mul = scale, X3_SCALE_PROB
+    what = 0
+
+    def grad_like(t, g, nm):
+        if g is None:
+            g = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        _act32(g, nm)
+        if tuple(g.shape) != tuple(t.shape) or g.stride(2) != 1 or (g.shape[0] > 1 and g.stride(0) != g.shape[1] * g.stride(1)):
+            raise ValueError(f"{nm}: expected the shape of its operand, unit channel stride, batch stride rows * ld")
+        return g
+    if want_dq:
+        dq = grad_like(q, dq, "dq")
+        p.dQ, p.lddq = dq.data_ptr(), dq.stride(1)
+        what |= 1
+    if want_dkv:
+        dk, dv = grad_like(k, dk, "dk"), grad_like(v, dv, "dv")
+        p.dK, p.dV, p.lddk, p.lddv = dk.data_ptr(), dv.data_ptr(), dk.stride(1), dv.stride(1)
+        what |= 2
+    fl = (6.0 if want_dq else 0.0) + (8.0 if want_dkv else 0.0)
+    with _Timed(f"attn_bwd_x3_kernel<{d}>", fl * B * heads * N * L * d):
+        _check(lib.ief_attn_bwd_x3(byref(p), what, _stream()), "ief_attn_bwd_x3")
+    return dq, dk, dv
+
+
+def _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv, o=None, lse=None):
     """gradients of softmax(scale q k^T) v on MATERIALISED fp32 maps (`/root/reference/p2p/model/register.py:43-51` is the
     forward being differentiated): P recomputed, dP = dO V^T, dS, then dQ = dS K, dK = dS^T Q, dV = P^T dO -- every
-    product an `ief_gemm_f32` launch in the model's contraction mode"""
+    product an `ief_gemm_f32` launch in the model's contraction mode.  With the forward's `lse` (split-operand mode, head dims
+    40 / 64, >= 128 keys: `x3_fused_bwd_ok`) the fused recomputing kernel runs instead and no map is written."""
+    if lse is not None and o is not None and x3_fused_bwd_ok(q.shape[2] // heads, k.shape[1]):
+        return _attn_bwd_x3(q, k, v, o, do, lse, heads, scale, dq, dk, dv, want_dq, want_dkv)
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (do, "do")):
         _act32(t, nm)
     probs = _attn_scores_f32(q, k, heads, scale)                          # [B*h, N, L]
@@ -1882,7 +1954,7 @@ def attn_bwd(q, k, v, o, do, lse, heads, scale, dq=None, dk=None, dv=None, ds_mu
     q/do/o [B,N,h*d], k/v [B,L,h*d] (strided views ok); dq/dk/dv may be column slices of larger buffers."""
     lib = load()
     if _is32(q):
-        return _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv)
+        return _attn_bwd_f32(q, k, v, do, heads, scale, dq, dk, dv, want_dq, want_dkv, o=o, lse=lse)
     B, N, _ = q.shape
     L = k.shape[1]
     d = o.shape[-1] // heads

@@ -311,6 +311,9 @@ typedef struct IefAttnF32Params {
     const ief_half* Qp; const ief_half* Kp; const ief_half* Vp;
     long long planeQ, planeK, planeV;
     const void* zeros;      /* >= 16 bytes of device zeros (source of key rows past L) when Qp is set */
+    /* x3 != 0, fp32 Q / K / V (not planes) only: optional [B][heads][N] receiving the row log-sum-exp in log2 units
+     * (max + log2 sum exp2) that ief_attn_bwd_x3 consumes; null: not written */
+    float* lse;
 } IefAttnF32Params;
 int ief_attn_flash_f32(const IefAttnF32Params* p, void* stream);
 int ief_softmax_rows_f32(float* x, long long rows, int L, void* stream);
@@ -475,6 +478,24 @@ int ief_attn_bwd_delta_f32(const ief_half* O, const ief_half* dO, float* delta, 
                            int ldo, int lddo, void* stream);
 /* what: 1 = dQ, 2 = dK and dV, 3 = all.  d in {32,40,64,80,160}; any N, L >= 1. */
 int ief_attn_bwd_f16(const IefAttnBwdParams* p, int what, void* stream);
+/* ---- the same gradients in the split-operand ("f16x3") mode: fp32 q / k / v / dO in, fp32 dQ / dK / dV out, P and dS recomputed per
+ * tile from the forward's lse (IefAttnF32Params.lse) and never written to HBM; every product on hi / lo fp16 halves (three MFMAs);
+ * csrc/attention_bwd_x3.hip.  Rows of batch b start at b * rows * ld (as IefAttnBwdParams).  d in {40, 64}.  Replaces, on the
+ * fp32-storage reverse pass, the materialised maps of /root/reference/p2p/model/register.py:43-51's backward. */
+typedef struct IefAttnBwdF32Params {
+    const float* Q; const float* K; const float* V; const float* dO;
+    const float* lse;     /* [B][heads][N], log2 units */
+    const float* delta;   /* [B][heads][N] from ief_attn_bwd_delta_f32in */
+    float* dQ; float* dK; float* dV;
+    int B, heads, N, L, d;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float scale;
+    float ds_mul;         /* dS is multiplied by this before its hi / lo split (undone in fp32; values clamp at the fp16 range); > 0 */
+} IefAttnBwdF32Params;
+int ief_attn_bwd_delta_f32in(const float* O, const float* dO, float* delta, int B, int heads, int N, int d, int ldo, int lddo,
+                             void* stream);
+/* what: 1 = dQ, 2 = dK and dV, 3 = all */
+int ief_attn_bwd_x3(const IefAttnBwdF32Params* p, int what, void* stream);
 /* Pix2Pix-zero cross-attention guidance (/root/reference/pix2pix-zero/model/sd_utils.py:166-173): for one cross-attention
  * module, loss = mean over (batch, head) of sum_{n,j} (P - ref)^2 with P = softmax(scale Q K^T), and its gradient w.r.t.
  * Q:  dQ (+)= gcoef * scale * dS K,  dS = P * (e - sum_j e_j P_j),  e = P - ref.  The caller passes

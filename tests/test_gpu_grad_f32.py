@@ -67,6 +67,47 @@ def test_attn_bwd_f32_vs_autograd(d, heads, N, L, contraction):
     assert wide[..., :C].abs().max() == 0 and wide[..., 2 * C:3 * C].abs().max() == 0
 
 
+@pytest.mark.parametrize("d,heads,B,N,L", [(40, 2, 2, 320, 320), (40, 8, 1, 1024, 1024), (64, 2, 2, 200, 136), (64, 5, 1, 576, 576),
+                                           (40, 1, 3, 130, 129)])
+def test_attn_bwd_x3_fused_recomputing_vs_autograd(d, heads, B, N, L):
+    """`ief_attn_bwd_x3` (csrc/attention_bwd_x3.hip): dQ / dK / dV of the split-operand mode WITHOUT materialised maps -- P and dS
+    recomputed per tile from the forward's row log-sum-exp -- against fp64 autograd (<= 1e-5 of the largest element) and against
+    the materialised-map path it replaces; q | k | v and the gradients as column slices of packed buffers (as the reverse pass
+    passes them), ragged row counts"""
+    C = heads * d
+    scale = d ** -0.5
+    qkv = torch.cat([f32(B, N, C, seed=1), f32(B, N, C, seed=2), f32(B, N, C, seed=3)], -1)
+    if L != N:
+        kv = torch.cat([f32(B, L, C, seed=2), f32(B, L, C, seed=3)], -1)
+    do = f32(B, N, C, seed=4, scale=0.05)
+    with hip.f32_contraction("x3"):
+        assert hip.x3_fused_bwd_ok(d, L)
+        pk = dev(qkv)
+        q = pk[..., :C]
+        k, v = (pk[..., C:2 * C], pk[..., 2 * C:]) if L == N else (dev(kv)[..., :C], dev(kv)[..., C:])
+        lse = torch.empty(B, heads, N, device=DEV)
+        o = hip.attn_flash(q, k, v, heads, scale, lse=lse)
+        grads, gkv = torch.zeros(B, N, 3 * C, device=DEV), torch.zeros(B, L, 2 * C, device=DEV)
+        dq, dk, dv = hip.attn_bwd(q, k, v, o, dev(do), lse, heads, scale, dq=grads[..., :C],
+                                  dk=grads[..., C:2 * C] if L == N else gkv[..., :C], dv=grads[..., 2 * C:] if L == N else gkv[..., C:])
+        dq2, dk2, dv2 = hip.attn_bwd(q, k, v, None, dev(do), None, heads, scale)          # no lse: the materialised maps
+    qf = qkv[..., :C].double().requires_grad_(True)
+    kf = (qkv[..., C:2 * C] if L == N else kv[..., :C]).double().requires_grad_(True)
+    vf = (qkv[..., 2 * C:] if L == N else kv[..., C:]).double().requires_grad_(True)
+    sp = lambda t, n: t.reshape(B, n, heads, d).transpose(1, 2)
+    sc = sp(qf, N) @ sp(kf, L).transpose(-1, -2) * scale
+    ref = (torch.softmax(sc, -1) @ sp(vf, L)).transpose(1, 2).reshape(B, N, C)
+    ref.backward(do.double())
+    lse_ref = (torch.logsumexp(sc.detach(), -1) * 1.4426950408889634)
+    e_o, e_lse = rel_err(o, ref.detach()), (lse.double().cpu() - lse_ref).abs().max().item()
+    errs = [rel_err(dq, qf.grad), rel_err(dk, kf.grad), rel_err(dv, vf.grad)]
+    olds = [rel_err(dq2, qf.grad), rel_err(dk2, kf.grad), rel_err(dv2, vf.grad)]
+    print(f"attn_bwd_x3 fused d={d} h={heads} B={B} N={N} L={L}: out {e_o:.2e} lse {e_lse:.2e} | dq {errs[0]:.2e} dk {errs[1]:.2e} "
+          f"dv {errs[2]:.2e} (materialised maps: {olds[0]:.2e} {olds[1]:.2e} {olds[2]:.2e})")
+    assert e_o < 4e-6 and e_lse < 1e-5 and max(errs) < 1e-5
+    assert dq.data_ptr() == grads.data_ptr()                           # written into the caller's column slices
+
+
 @pytest.mark.parametrize("C1,C2,HW,silu", [(320, 0, 1024, True), (640, 320, 256, True), (64, 0, 256, False), (128, 64, 16, True)])
 def test_groupnorm_bwd_f32_vs_autograd(C1, C2, HW, silu):
     B, G, C = 2, 32, C1 + C2
