@@ -116,6 +116,9 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
         }
     }
 
+    unsigned stepmask = 0;            // bit j: piece j advances (TN > 5, linear: replaces step[])
+#pragma unroll
+    for (int j = 0; j < G; ++j) stepmask |= (step[j] != 0 ? 1u : 0u) << j;
     // ---- conv K iterator: (tap, channel offset) advanced by one K tile per stage; tap 9 = the fused 1x1 range
     const int Ctot = p.C1 + p.C2;
     const int Hp = p.H >> p.ups, Wp = p.Wd >> p.ups;
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
         for (int j = 0; j < G; ++j) {
             half_t* dst = (swave + NSW * j < P) ? base + NSW * j * (16 * BK) : smem + DUMP;        // wave-uniform
             if (!(XP_ABL & 1) || abl_prologue) glds16(ptr[j], dst);
-            ptr[j] += step[j];
+            if constexpr (TN > 5 && !CONV) ptr[j] += ((stepmask >> j) & 1u) ? BK * 2 : 0;      // the wide tile has no register for step[]
+            else ptr[j] += step[j];
         }
         if constexpr (CONV) {
             it_c += BK;
@@ -225,6 +229,22 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[j][i], 0, 0, 0);
             }
     };
+    // wide wave tiles (TN > 5: the 256 x 320 tile): the weight fragments of ONE 16-column block at a time (8 registers) instead of all TN
+    // (80): 160 accumulator registers leave no room for more
+    auto read_mfma_wide = [&](const half_t* S) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ah[i] = *(const half8*)(S + aoff[i]); al[i] = *(const half8*)(S + aoff[i] + BM * BK); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const half8 wh = *(const half8*)(S + boff[j]), wl = *(const half8*)(S + boff[j] + BN * BK);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[i], acc[j][i], 0, 0, 0);
+            }
+        }
+    };
     // NS-deep ring, as igemm_f16_kernel: wait for this wave's share of tile k (counted vmcnt), s_barrier (everybody's has
     // landed; everybody is done reading the slot tile k - 1 used), refill that slot with tile k + NS - 1, multiply tile k.
     // 8 compute waves, NS >= 3: waves 4..7 run half a tile late (they multiply tile k - 1 from fragments read before the
@@ -261,8 +281,12 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NL)) void igemm_x3p_kerne
                     }
                     XP_BARRIER();
                     if constexpr (NL == 0) { if (k + NS - 1 < nk) stage_tile((s + NS - 1) % NS); }
-                    read_frags(smem + s * SLOT);
-                    mfma_frags();
+                    if constexpr (TN > 5) {
+                        read_mfma_wide(smem + s * SLOT);
+                    } else {
+                        read_frags(smem + s * SLOT);
+                        mfma_frags();
+                    }
                 }
             }
         }
@@ -468,18 +492,19 @@ extern "C" int ief_x3_split_act(const float* x, ief_half* planes, long long plan
 extern "C" int ief_gemm_x3p_tile_bm(int tile) {
     switch (tile) {
         case 1: case 2: case 3: case 7: return 128;
-        case 4: case 11: case 12: return 256;
+        case 4: case 8: case 11: case 12: return 256;
         case 5: return 64;
         case 6: return 128;
         default: return 0;
     }
 }
-extern "C" int ief_gemm_x3p_tile_wn(int tile) { return tile == 6 ? 64 : 80; }
+extern "C" int ief_gemm_x3p_tile_wn(int tile) { return tile == 6 ? 64 : tile == 8 ? 160 : 80; }
 extern "C" int ief_gemm_x3p_tile_bn(int tile) {
     switch (tile) {
         case 1: case 2: case 4: case 5: case 7: return 160;
         case 3: case 11: case 12: return 80;
         case 6: return 64;
+        case 8: return 320;
         default: return 0;
     }
 }
@@ -538,6 +563,7 @@ extern "C" int ief_gemm_x3p(const IefGemmX3pParams* pp, void* stream) {
         case 5: rc = launch_x3p<64, 160, 2, 2, 4, 0>(p, st); break;
         case 6: rc = launch_x3p<128, 64, 4, 1, 3, 0>(p, st); break;
         case 7: rc = launch_x3p<128, 160, 2, 2, 2, 0>(p, st); break;       // 4 waves (64 x 80 each), 72 KiB of LDS: two workgroups per CU
+        case 8: rc = launch_x3p<256, 320, 4, 2, 2, 0>(p, st); break;       // 8 waves of 64 x 160: the fewest staged bytes per FLOP (wide N only)
         case 11: case 12: rc = ief_conv_halo_x3p_dispatch(p, st); break;
         case 1: default: rc = launch_x3p<128, 160, 4, 2, 4, 0>(p, st); break;
     }

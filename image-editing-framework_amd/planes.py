@@ -126,7 +126,7 @@ def save_plans(path=None):
         json.dump({k: list(v) for k, v in sorted(_plan_table().items())}, f, indent=0)
 
 
-_TILES = {1: (128, 160), 2: (128, 160), 3: (128, 80), 4: (256, 160), 5: (64, 160), 6: (128, 64), 7: (128, 160),
+_TILES = {1: (128, 160), 2: (128, 160), 3: (128, 80), 4: (256, 160), 5: (64, 160), 6: (128, 64), 7: (128, 160), 8: (256, 320),
           11: (256, 80), 12: (256, 80)}
 
 

@@ -395,7 +395,7 @@ typedef struct IefGemmX3pParams {
     float out_scale;                          /* out = (acc * inv_scale + bias + rowvec + residual) * out_scale */
     float inv_scale;                          /* 1 / (activation scale * weight scale) */
     int tile;                                 /* 1: 128x160 (8 waves), 2: the same + 4 loader waves, 3: 128x80 (4 waves), 4: 256x160 (8 waves),
-                                                 5: 64x160 (4 waves), 6: 128x64 (4 waves; widths that are multiples of 64 only), 7: 128x160 on 4 waves (two workgroups per CU); 11 / 12: conv3x3_halo_x3p (256x80, 8 waves + 4 loader waves;
+                                                 5: 64x160 (4 waves), 6: 128x64 (4 waves; widths that are multiples of 64 only), 7: 128x160 on 4 waves (two workgroups per CU), 8: 256x320 (8 waves of 64 x 160; the fewest staged bytes per FLOP: wide N only); 11 / 12: conv3x3_halo_x3p (256x80, 8 waves + 4 loader waves;
                                                  plain 3x3 stride 1 pad 1, rows of <= 64 pixels; 12: nearest-2x fused) */
     int splits;                               /* split-K over grid.y: fp32 slabs ws[splits][M][N] summed in slab order by a second launch */
     float* ws;

@@ -54,7 +54,12 @@ def main():
                 print(f"attn_flash_x3 B={B} h={heads} N={N:6d} d={d:3d}: {us:9.1f} us {fl / us / 1e6:6.1f} TF  (planes out: {usp:9.1f} us; planes in + out: "
                       f"{uspp:9.1f} us {fl / uspp / 1e6:6.1f} TF)", flush=True)
         if args.geglu:
-            for M, N, K in [(16384, 2560, 320), (4096, 5120, 640), (1024, 10240, 1280), (256, 10240, 1280)]:
+            shapes = [(16384, 2560, 320), (4096, 5120, 640), (1024, 10240, 1280), (256, 10240, 1280)]
+            if os.environ.get("IEF_BENCH_FF1_ALL") == "1":        # every FeedForward.net[0] shape of the plan table's configurations
+                shapes = [(8192, 2560, 320), (32768, 2560, 320), (65536, 2560, 320), (9216, 2560, 320), (18432, 2560, 320), (36864, 2560, 320),
+                          (2048, 5120, 640), (8192, 5120, 640), (16384, 5120, 640), (2304, 5120, 640), (4608, 5120, 640), (9216, 5120, 640),
+                          (2048, 10240, 1280), (4096, 10240, 1280), (2304, 10240, 1280)]
+            for M, N, K in shapes:
                 a, w, bias = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
                 wc = hip._cold_copies(w)
                 for x in wc:

@@ -76,7 +76,7 @@ def test_gemm_x3p_identity_asymmetric():
         assert out.dtype == torch.float32 and torch.equal(out.cpu(), w.t().contiguous()), f"tile {tile}"
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(128, 160, 32), (300, 320, 96), (16384, 320, 320), (77, 1280, 768), (4, 1280, 320),
                                    (1000, 480, 96), (4096, 2560, 320), (256, 1280, 5120)])
 def test_gemm_x3p(M, N, K, tile):
@@ -106,10 +106,11 @@ def test_gemm_x3p(M, N, K, tile):
     assert rel_err(owide[:, :N], wide[:, 32:32 + K].to_f32().double().cpu() @ w.double().t()) < XTOL and owide[:, N:].abs().max() == 0
 
 
+@pytest.mark.parametrize("tile", [0, 3, 8])           # 0: the plan table's choice; 3: 128 x 80 (one pair + an odd block per wave); 8: 256 x 320 (five pairs)
 @pytest.mark.parametrize("M,Ch,K", [(4096, 1280, 320), (300, 640, 96), (333, 160, 64)])
-def test_gemm_x3p_fused_geglu(M, Ch, K):
+def test_gemm_x3p_fused_geglu(M, Ch, K, tile):
     a, w, bias = f32(M, K, seed=1), f32(2 * Ch, K, seed=2, scale=K ** -0.5), f32(2 * Ch, seed=3, scale=0.1)
-    out, op = planes.gemm(planes.split(dev(a)), dev(w), bias=dev(bias), geglu=True, out=True, out_planes=True)
+    out, op = planes.gemm(planes.split(dev(a)), dev(w), bias=dev(bias), geglu=True, out=True, out_planes=True, tile=tile)
     pre = (a.double() @ w.double().t() + bias.double()).reshape(M, Ch // 8, 2, 8)
     ref = (pre[:, :, 0] * F.gelu(pre[:, :, 1])).reshape(M, Ch)
     e = rel_err(out, ref)
