@@ -1158,6 +1158,119 @@ extern "C" int ief_groupnorm_silu_x3p_small(const float* x, const float* x2, int
     return IEF_OK;
 }
 
+// ---- GroupNorm (+SiLU) with the (image, group) slab held in REGISTERS: one workgroup of 1024 threads per (image, group) reads its
+// HW x cpg slab ONCE (every load requested before the first use), takes the mean and the centred second moment from registers
+// (two-pass: no cancellation), normalises and writes fp32 and / or operand planes.  For SMALL BATCHES: at UNet batch 1 (DDIM
+// inversion, the null-text loop) every GroupNorm of the step ran the KS-workgroup kernel above, whose workgroups stream the slab
+// three times with dependent 8-byte loads: 23 us per call whatever the size, 59 calls = 16 % of the batch-1 forward.  At batch 4 the
+// row-streaming forms are as fast (a workgroup per group reads 40-byte slices of 1280-byte pixel rows: 1.23 vs 1.28 ms per step)
+// and keep the step.  Slabs of up to 40 Ki floats (20 channel pairs per thread: beyond that the kernel spills, and a kernel with
+// scratch pays ~190 us of scratch set-up per launch on this runtime).
+template <int E>
+__global__ __launch_bounds__(1024) void groupnorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
+                                                             float* __restrict__ out, half_t* __restrict__ outp, long long plane,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
+                                                             int groups, float eps, int silu) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    __shared__ float red[16];
+    __shared__ float bc;
+    __shared__ float sc_s[512], sh_s[512];
+    const int C = C1 + C2, cpg = C / groups, cp2 = cpg >> 1;
+    const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+    const int npairs = HW * cp2;
+    const int tid = threadIdx.x;
+    const int dq = 1024 / cp2, dr = 1024 - dq * cp2;       // (pixel, pair) advance of 1024 elements
+    int p = tid / cp2, j = tid - p * cp2;
+    f32x2 v[E];
+    const int p00 = p, j00 = j;
+    const float* xb = x + (long long)b * HW * C1;
+    const float* x2b = x2 ? x2 + (long long)b * HW * C2 : x;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const bool ok = tid + k * 1024 < npairs;               // slots past the slab re-read pair 0 and are zeroed: no branch around a load
+        const int c = g * cpg + (ok ? 2 * j : 0), pp = ok ? p : 0;
+        const float* src = c < C1 ? xb + (unsigned)(pp * C1 + c) : x2b + (unsigned)(pp * C2 + (c - C1));
+        const f32x2 t = *(const f32x2*)src;
+        v[k] = ok ? t : (f32x2){0.f, 0.f};
+        p += dq; j += dr;
+        if (j >= cp2) { j -= cp2; ++p; }
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // addresses are formed four at a time (they are dead once the load is out): the
+    }                                                            // scheduler otherwise forms all E first and spills
+    auto block_sum = [&](float t) -> float {
+        t = wave_sum(t);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = t;
+        __syncthreads();
+        if (tid == 0) { float a = 0.f; for (int w = 0; w < 16; ++w) a += red[w]; bc = a; }
+        __syncthreads();
+        return bc;
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) s += v[k][0] + v[k][1];      // slots past the slab hold zeros
+    const float n = (float)cpg * (float)HW;
+    const float mean = block_sum(s) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        if (tid + k * 1024 < npairs) { const float d0 = v[k][0] - mean, d1 = v[k][1] - mean; q += d0 * d0 + d1 * d1; }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(q) / n + eps);
+    if (tid < cpg) {
+        const float sc = rstd * gamma[g * cpg + tid];
+        sc_s[tid] = sc;
+        sh_s[tid] = beta[g * cpg + tid] - mean * sc;
+    }
+    __syncthreads();
+    p = p00; j = j00;
+    float* ob = out ? out + (long long)b * HW * C : nullptr;
+    half_t* opb = outp ? outp + (long long)b * HW * C : nullptr;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int idx = tid + k * 1024;
+        if (idx < npairs) {
+            float y0 = v[k][0] * sc_s[2 * j] + sh_s[2 * j], y1 = v[k][1] * sc_s[2 * j + 1] + sh_s[2 * j + 1];
+            if (silu) { y0 = silu_x(y0); y1 = silu_x(y1); }
+            const unsigned o = (unsigned)(p * C + g * cpg + 2 * j);
+            if (out) *(f32x2*)(ob + o) = (f32x2){y0, y1};
+            if (outp) {          // operand planes (csrc/gemm_x3p.hip): hi = fp16(y), lo = fp16(y - hi)
+                const half2_t h = __builtin_convertvector((f32x2){y0, y1}, half2_t);
+                const half2_t l = __builtin_convertvector((f32x2){y0 - (float)h[0], y1 - (float)h[1]}, half2_t);
+                *(half2_t*)(opb + o) = h;
+                *(half2_t*)(opb + plane + o) = l;
+            }
+        }
+        p += dq; j += dr;
+        if (j >= cp2) { j -= cp2; ++p; }
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// 1: the register-resident form takes this shape (channels per group even and <= 512, C1 even, HW x channels per group <= 40960)
+extern "C" int ief_groupnorm_reg_fits(int C1, int C2, int HW, int groups) {
+    if (groups <= 0 || C1 <= 0 || C2 < 0 || (C1 + C2) % groups) return 0;
+    const int cpg = (C1 + C2) / groups;
+    return !(cpg & 1) && !(C1 & 1) && cpg <= 512 && (long long)HW * cpg <= 40960;
+}
+extern "C" int ief_groupnorm_silu_reg(const float* x, const float* x2, int C1, int C2, float* out, ief_half* outp, long long plane,
+                                      const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu,
+                                      void* stream) {
+    if (!x || (!out && !outp) || !gamma || !beta || (C2 > 0 && !x2)) return IEF_EINVAL;
+    if (B <= 0 || HW <= 0 || !ief_groupnorm_reg_fits(C1, C2, HW, groups) || (plane & 1)) return IEF_ESHAPE;
+    if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)(out ? out : x)) & 7) || ((uintptr_t)outp & 3)) return IEF_EALIGN;
+    const int cpg = (C1 + C2) / groups;
+    const int need = (HW * (cpg >> 1) + 1023) / 1024;
+    const dim3 grid(B * groups), blk(1024);
+    hipStream_t st = (hipStream_t)stream;
+#define GNR_GO(E_) hipLaunchKernelGGL(groupnorm_reg_kernel<E_>, grid, blk, 0, st, x, x2, C1, C2, out, (half_t*)outp, plane, gamma, beta, HW, groups, eps, silu)
+    if (need <= 4) GNR_GO(4);
+    else if (need <= 8) GNR_GO(8);
+    else if (need <= 16) GNR_GO(16);
+    else GNR_GO(20);
+#undef GNR_GO
+    IEF_LAUNCH_CHECK();
+    return IEF_OK;
+}
+
 // LayerNorm over rows of C fp32, one wave per row, two-pass statistics
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,

@@ -161,7 +161,7 @@ EXPORTS = [
     "ief_conv_out_bwd_f32w", "ief_softmax_bwd_rows_f32", "ief_transpose_batched_f32", "ief_map_loss_rows_blocks",
     "ief_map_loss_rows_f32", "ief_nti_adam_f32g",
     # ABI 4: split-operand contractions on pre-split planes (csrc/gemm_x3p.hip)
-    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_gemm_x3p_tile_wn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small", "ief_attn_bwd_x3", "ief_attn_bwd_delta_f32in",
+    "ief_gemm_x3p", "ief_gemm_x3p_tile_bm", "ief_gemm_x3p_tile_bn", "ief_gemm_x3p_tile_wn", "ief_x3_split_act", "ief_groupnorm_silu_x3p_ws", "ief_layernorm_x3p", "ief_groupnorm_silu_x3p_small", "ief_groupnorm_silu_reg", "ief_groupnorm_reg_fits", "ief_attn_bwd_x3", "ief_attn_bwd_delta_f32in",
 ]
 
 
@@ -280,6 +280,9 @@ def load():
                                               c_int, c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]
     lib.ief_attn_bwd_x3.argtypes = [POINTER(IefAttnBwdF32Params), c_int, c_void_p]
     lib.ief_attn_bwd_delta_f32in.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.ief_groupnorm_reg_fits.argtypes = [c_int] * 4
+    lib.ief_groupnorm_silu_reg.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.ief_groupnorm_silu_x3p_small.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p,
                                                  c_int, c_int, c_int, c_float, c_int, c_void_p]
     lib.ief_layernorm_x3p.argtypes = [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p]

@@ -333,6 +333,14 @@ int ief_groupnorm_silu_f32(const float* x, const float* x2, int C1, int C2, floa
 long long ief_groupnorm_f32_ws_floats(int B, int HW, int C);
 int ief_groupnorm_silu_f32_ws(const float* x, const float* x2, int C1, int C2, float* out, const float* gamma, const float* beta,
                               int B, int HW, int groups, float eps, int silu, float* ws, long long ws_floats, void* stream);
+/* ABI 4 (added late in round 4; additive): the same operator with the (image, group) slab held in registers: ONE launch, one workgroup
+ * of 1024 threads per (image, group), the input read once; out (fp32, nullable) and / or outp (operand planes hi / lo, lo plane
+ * `plane` elements further; nullable).  Shapes: ief_groupnorm_reg_fits(C1, C2, HW, groups) != 0 (channels per group even and <= 512,
+ * C1 even, HW x channels per group <= 40960).  The small-batch form (UNet batch 1 / 2: DDIM inversion, the null-text loop) of
+ * /root/reference's GroupNorm + SiLU of ResnetBlock2D (pnp/model/register.py:149-158 runs them through torch). */
+int ief_groupnorm_reg_fits(int C1, int C2, int HW, int groups);
+int ief_groupnorm_silu_reg(const float* x, const float* x2, int C1, int C2, float* out, ief_half* outp, long long plane,
+                           const float* gamma, const float* beta, int B, int HW, int groups, float eps, int silu, void* stream);
 /* dx (, dx2) of the GroupNorm (+SiLU) above given dy; `add` (nullable) is summed into the result; row-streaming, five launches;
  * same shape rules as ief_groupnorm_silu_f32_ws, every pointer 16-byte aligned; ws: ief_groupnorm_bwd_f32_ws_floats floats */
 long long ief_groupnorm_bwd_f32_ws_floats(int B, int HW, int C);

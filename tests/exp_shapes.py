@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 precision = sys.argv[3] if len(sys.argv) > 3 else "f16"
 pipe, cfg = bench.build_pipe(cfg_name, dev, 0, 1, precision=precision)
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else cfg.sample_size
-B = 4
+B = int(os.environ.get("IEF_EXP_B", "4"))
 x = torch.randn(B, 4, hw, hw, device=dev)
 ctx = (torch.randn(B, 77, cfg.cross_attention_dim, device=dev) * 0.1)
 agg = {}

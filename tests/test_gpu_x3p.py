@@ -309,8 +309,8 @@ def test_layernorm_folded_into_the_consumer_gemm(M, C, N):
 def test_groupnorm_writes_planes(B, H, W, C1, C2, groups, silu):
     """`planes.groupnorm` (three row-streaming launches / the one-launch form of the small levels) against fp64 on activations
     with a 20-sigma offset (the centred second moment must not cancel); the planes are the split of the fp32 output bit for bit.
-    (Round 4 also built two other one-launch forms -- the (image, group) slab in the registers of one workgroup, and a
-    cooperative launch whose workgroups meet through arrival counters -- both parity-green and NOT faster: DESIGN.md section 3e.)"""
+    (Round 4 also built a cooperative one-launch form whose workgroups meet through arrival counters -- parity-green and 4x
+    SLOWER: DESIGN.md section 3e; the slab-in-registers form is tested below.)"""
     x = f32(B, H, W, C1, seed=1) + 20.0
     x2 = f32(B, H, W, C2, seed=2) * 3.0 - 20.0 if C2 else None
     gamma, beta = f32(C1 + C2, seed=3) * 0.5 + 1.0, f32(C1 + C2, seed=4) * 0.3
@@ -325,3 +325,40 @@ def test_groupnorm_writes_planes(B, H, W, C1, C2, groups, silu):
     e2 = rel_err(pl2.hi.float() + pl2.lo.float(), ref)
     print(f"GroupNorm -> planes B={B} {H}x{W} C={C1}+{C2}: {e:.2e} (fp32 + planes), {e2:.2e} (planes only) vs fp64")
     assert e < 2e-6 and e2 < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,groups,silu", [
+    (1, 64, 64, 320, 0, 32, True),          # batch 1 (DDIM inversion, null-text): 40 floats per thread
+    (2, 32, 32, 640, 640, 32, True),        # channel concat
+    (2, 16, 16, 1280, 640, 32, True),       # 60 channels per group: group 21 straddles the two sources
+    (3, 5, 7, 64, 0, 32, True),             # 2 channels per group, ragged image
+    (1, 24, 24, 1280, 0, 32, False),        # SD2.1 at 768 px
+])
+def test_groupnorm_slab_in_registers(B, H, W, C1, C2, groups, silu):
+    """`ief_groupnorm_silu_reg` (one launch, one workgroup per (image, group), the input read once) against fp64 on activations
+    with a 20-sigma offset; the planes are the split of the fp32 output bit for bit; the row-streaming / KS forms it replaces on
+    small tensors give the same values to fp32 rounding"""
+    lib = hip.load()
+    assert lib.ief_groupnorm_reg_fits(C1, C2, H * W, groups) == 1
+    assert lib.ief_groupnorm_reg_fits(640, 320, 64 * 64, 32) == 0     # 30 channels per group at 64 x 64: 122880 floats, does not fit
+    x = f32(B, H, W, C1, seed=1) + 20.0
+    x2 = f32(B, H, W, C2, seed=2) * 3.0 - 20.0 if C2 else None
+    gamma, beta = f32(C1 + C2, seed=3) * 0.5 + 1.0, f32(C1 + C2, seed=4) * 0.3
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    ref = F.group_norm(xin.permute(0, 3, 1, 2).double(), groups, gamma.double(), beta.double(), 1e-5).permute(0, 2, 3, 1)
+    if silu:
+        ref = F.silu(ref)
+    keep = planes.GN_REG_MAX_WGS
+    try:
+        planes.GN_REG_MAX_WGS = 1 << 30
+        pl, o32 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2), out32=True)
+        pl2 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
+        planes.GN_REG_MAX_WGS = 0
+        pl3 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
+    finally:
+        planes.GN_REG_MAX_WGS = keep
+    e, e_old = rel_err(o32, ref), rel_err(pl3.hi.float() + pl3.lo.float(), ref)
+    assert_planes_equal_split(pl, o32)
+    assert torch.equal(pl2.t, pl.t)
+    print(f"GroupNorm, slab in registers B={B} {H}x{W} C={C1}+{C2}: {e:.2e} vs fp64 (the forms it replaces: {e_old:.2e})")
+    assert e < 2e-6 and e_old < 2e-6
