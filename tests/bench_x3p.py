@@ -43,7 +43,7 @@ def main():
     do_lin, do_conv = args.lin or not only, args.conv or not only
     with hip.f32_contraction("x3"):
         if args.attn:
-            for B, heads, N, d in [(4, 8, 4096, 40), (4, 8, 1024, 80), (4, 8, 256, 160), (4, 8, 16384, 40), (4, 5, 9216, 64), (1, 10, 4096, 64)]:
+            for B, heads, N, d in [(4, 8, 4096, 40), (1, 8, 4096, 40), (2, 8, 4096, 40), (4, 8, 1024, 80), (4, 8, 256, 160), (4, 8, 16384, 40), (4, 5, 9216, 64), (1, 10, 4096, 64)]:
                 qkv = rnd(B, N, 3 * heads * d)
                 C = heads * d
                 fl = 4.0 * B * heads * N * N * d
