@@ -84,7 +84,7 @@ def _sd_fingerprint(sd):
     key = id(sd)
     if key not in _SD_PRINTS:
         if sum(v.numel() for v in sd.values()) > (64 << 20):
-            _SD_PRINTS[key] = (sd, None)
+            return None                                             # not remembered either: a full-size dict must die with its test
         else:
             h = _hashlib.sha1()
             for n in sorted(sd.keys()):
