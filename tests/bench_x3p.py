@@ -78,7 +78,8 @@ def main():
                 print(line, flush=True)
                 del wc
         if do_lin:
-            for M, N, K in LIN:
+            lin = LIN if os.environ.get("IEF_BENCH_LIN_B1") != "1" else [(4096, 320, 320), (4096, 960, 320), (4096, 320, 1280), (1024, 640, 640), (1024, 1920, 640), (1024, 640, 2560), (256, 1280, 1280), (256, 3840, 1280), (256, 1280, 5120), (64, 1280, 1280)]
+            for M, N, K in lin:
                 a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
                 wc = hip._cold_copies(w)
                 for x in wc:
