@@ -846,6 +846,9 @@ __global__ __launch_bounds__(256, (D > 80) ? 1 : 2) void attn_flash_x3_kernel(co
 }
 
 
+#ifndef X3P_FLASH_BATCH_READS
+#define X3P_FLASH_BATCH_READS 1
+#endif
 // --------------------------------------------------------------------------------------------- fused attention on OPERAND PLANES
 // The same product as attn_flash_x3_kernel with Q / K / V arriving as pre-split hi / lo fp16 planes (written by the q|k|v GEMM's
 // epilogue, csrc/gemm_x3p.hip).  What that buys, measured on the fp32-input kernel at N = 4096, d = 40 (profiles/r04_pmc_attn40x3.txt):
@@ -879,6 +882,7 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
     static_assert((PL * 2) % 1024 == 0, "a plane of a tile is a whole number of LDS-DMA pieces");
     constexpr bool SWZ = D == 64;
     constexpr float LOGSP = 10.f, THR = 5.f;
+    constexpr bool BATCH_READS = X3P_FLASH_BATCH_READS != 0;
     __shared__ __attribute__((aligned(1024))) half_t smem_p[2 * 4 * PL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -977,14 +981,22 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
         for (int u = 0; u < KS; ++u) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+            // all 2 DG fragment reads of the sub-tile go out before the first MFMA (left alone the compiler waits for each read in turn:
+            // 2 DG exposed LDS latencies per sub-tile on the wave's critical path)
+            half8_t kh[DG], kl[DG];
 #pragma unroll
             for (int g = 0; g < DG; ++g) {
-                const half8_t kh = *(const half8_t*)(Kh + u * 32 * D + koff[g]);
-                const half8_t kl = *(const half8_t*)(Kl + u * 32 * D + koff[g]);
-                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g], sacc[u], 0, 0, 0);
-                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g], sacc[u], 0, 0, 0);
-                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g], sacc[u], 0, 0, 0);
+                kh[g] = *(const half8_t*)(Kh + u * 32 * D + koff[g]);
+                kl[g] = *(const half8_t*)(Kl + u * 32 * D + koff[g]);
             }
+            if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < DG; ++g) {
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[g], qh[g], sacc[u], 0, 0, 0);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[g], ql[g], sacc[u], 0, 0, 0);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[g], qh[g], sacc[u], 0, 0, 0);
+            }
+            if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
         // online softmax (register r <-> key (r & 3) + 8 (r >> 2) + 4 lh of its sub-tile)
@@ -1045,6 +1057,8 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { ph[4 * c2 + j] = hh[j]; pl[4 * c2 + j] = ll[j]; }
                 }
+                // the 4 DT transposing reads of this 16-key step go out before its first MFMA (as the K fragments above)
+                half8_t vh[DT], vl[DT];
 #pragma unroll
                 for (int tt = 0; tt < DT; ++tt) {
                     // keys {4 lh .. + 3} and {8 + 4 lh .. + 3} of this 16-key step: rows r0, r0 + 8 of the tile
@@ -1054,13 +1068,17 @@ __global__ __launch_bounds__(64 * NWV, D <= 40 ? 4 : 2) void attn_flash_x3p_kern
                     const int o1 = (r0 + 8) * D + (SWZ ? ((((c >> 3) ^ ((r0 + 8) & 7)) << 3) | (c & 7)) : c);
                     const half4 a0 = x3_lds_tr_read(Vh + o0), a1 = x3_lds_tr_read(Vh + o1);
                     const half4 b0 = x3_lds_tr_read(Vl + o0), b1 = x3_lds_tr_read(Vl + o1);
-                    half8_t vh, vl;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[tt], 0, 0, 0);
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[tt], 0, 0, 0);
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[tt], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) { vh[tt][j] = a0[j]; vh[tt][4 + j] = a1[j]; vl[tt][j] = b0[j]; vl[tt][4 + j] = b1[j]; }
                 }
+                if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) {
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[tt], ph, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[tt], pl, o[tt], 0, 0, 0);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[tt], ph, o[tt], 0, 0, 0);
+                }
+                if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
