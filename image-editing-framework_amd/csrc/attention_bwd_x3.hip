@@ -228,29 +228,45 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(const IefAttnBwdF32Par
             if constexpr (DKV)
                 bx3_split8(f32x4{t1[u][base], t1[u][base + 1], t1[u][base + 2], t1[u][base + 3]} * SPP,
                            f32x4{t1[u][base + 4], t1[u][base + 5], t1[u][base + 6], t1[u][base + 7]} * SPP, ph, pl);
+            // the transposing reads of ALL D tiles of this step go out before its first MFMA (left alone the compiler waits for every group
+            // of four in turn: one exposed LDS latency per three MFMAs on a kernel that runs one wave per SIMD)
+            {
+                half8_t ah[DT], al[DT];
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int o = tr_lane + (16 * kk) * RS + 32 * t;
-                {
+                for (int t = 0; t < DT; ++t) {
+                    const int o = tr_lane + (16 * kk) * RS + 32 * t;
                     const half4 h0 = x3_lds_tr_read(Y1h + o), h1 = x3_lds_tr_read(Y1h + o + 8 * RS);
                     const half4 l0 = x3_lds_tr_read(Y1l + o), l1 = x3_lds_tr_read(Y1l + o + 8 * RS);
-                    half8_t ah, al;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { ah[q] = h0[q]; ah[4 + q] = h1[q]; al[q] = l0[q]; al[4 + q] = l1[q]; }
-                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, dh, acc1[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dl, acc1[t], 0, 0, 0);
-                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dh, acc1[t], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) { ah[t][q] = h0[q]; ah[t][4 + q] = h1[q]; al[t][q] = l0[q]; al[t][4 + q] = l1[q]; }
                 }
-                if constexpr (DKV) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], dh, acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], dl, acc1[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], dh, acc1[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DKV) {
+                half8_t ah[DT], al[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const int o = tr_lane + (16 * kk) * RS + 32 * t;
                     const half4 h0 = x3_lds_tr_read(Y2h + o), h1 = x3_lds_tr_read(Y2h + o + 8 * RS);
                     const half4 l0 = x3_lds_tr_read(Y2l + o), l1 = x3_lds_tr_read(Y2l + o + 8 * RS);
-                    half8_t ah, al;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { ah[q] = h0[q]; ah[4 + q] = h1[q]; al[q] = l0[q]; al[4 + q] = l1[q]; }
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl, acc2[t], 0, 0, 0);
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph, acc2[t], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) { ah[t][q] = h0[q]; ah[t][4 + q] = h1[q]; al[t][q] = l0[q]; al[t][4 + q] = l1[q]; }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], ph, acc2[t], 0, 0, 0);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], pl, acc2[t], 0, 0, 0);
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], ph, acc2[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();                       // everyone is done reading this tile
