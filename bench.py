@@ -565,6 +565,7 @@ def physical_cores():
 
 
 PEAK_HBM = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec (6.3e12 measured with a float4 copy)
+LDS_FILL_TBS = 6.4            # MI355X_MICROARCH.md, row `ldsdma-fill`: LDS-DMA fill ~25 GB/s per CU, 6.4 TB/s per chip (default cache policy)
 
 
 def roofline(job, steps_per_sec, world, config, precision="f16"):
@@ -585,6 +586,9 @@ def roofline(job, steps_per_sec, world, config, precision="f16"):
     hip.profile_begin()
     loop._step_body()
     rec = hip.profile_end(with_bytes=True)
+    staged = {}                            # LDS-DMA bytes per family (the planes kernels report them per launch)
+    for kname, b in hip.profile_staged().items():
+        staged[_family(kname)] = staged.get(_family(kname), 0.0) + b
     agg, fam = {}, {}
     for name, flops, ms, nbytes in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0])
@@ -649,10 +653,20 @@ def roofline(job, steps_per_sec, world, config, precision="f16"):
                        "frac": round(steps_per_sec / world * alg_flop / PEAK, 4)},
         "per_kernel_ms": {k: round(v[2], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
     }
+    if staged.get(name):
+        # the bound that actually fits the planes GEMMs: bytes moved L2 -> LDS by LDS-DMA / the template's time,
+        # against the chip-level LDS-DMA fill rate of the microarchitecture guide (`ldsdma-fill`: ~25 GB/s per CU, 6.4 TB/s)
+        out["lds_fill"] = {"staged_mbytes_per_launch": round(staged[name] / n / 1e6, 2), "achieved_tb_s": round(staged[name] / (ms * 1e-3) / 1e12, 2),
+                           "per_cu_gb_s": round(staged[name] / (ms * 1e-3) / 1e9 / 256, 1), "reference_tb_s": LDS_FILL_TBS,
+                           "frac_of_reference": round(staged[name] / (ms * 1e-3) / 1e12 / LDS_FILL_TBS, 3),
+                           "note": "bytes staged into LDS (two fp16 planes of both operands, every K tile of every output tile) / the template's "
+                                   "live time; reference = the guide's chip-level LDS-DMA fill rate"}
     if "avg_launch_us_rocprof" in prof:
         us = prof["avg_launch_us_rocprof"]
         out["avg_launch_ms_rocprof"] = round(us * 1e-3, 4)
         out["frac_rocprof"] = round(flops / n / (us * 1e-6) / PEAK, 4)
+        if "lds_fill" in out:
+            out["lds_fill"]["frac_of_reference_rocprof"] = round(staged[name] / n / (us * 1e-6) / 1e12 / LDS_FILL_TBS, 3)
         out["rocprof_source"] = prof.get("source")
     if job.hw == 64 and config == "sd15":
         out["whole_step"]["survey_tflop_per_step_512px"] = FLOP_PER_STEP / 1e12

@@ -341,9 +341,25 @@ def _ring_bytes(tile, stages):
     return 2 * stages * rows * 64
 
 
+_prof_staged = None      # kernel name -> bytes its launches staged into LDS by LDS-DMA since profile_begin (the planes kernels report them)
+
+
 def profile_begin():
-    global _prof
+    global _prof, _prof_staged
     _prof = []
+    _prof_staged = {}
+
+
+def note_staged(name: str, nbytes: float):
+    """a planes kernel's launch reports the bytes it moves L2 -> LDS (both operands, both planes, every K tile of every output tile):
+    what the per-CU LDS-DMA fill rate prices"""
+    if _prof is not None and _prof_staged is not None:
+        _prof_staged[name] = _prof_staged.get(name, 0.0) + nbytes
+
+
+def profile_staged():
+    """{kernel name: LDS-staged bytes} of the launches since the last profile_begin"""
+    return dict(_prof_staged or {})
 
 
 def profile_end(with_bytes=False):

@@ -326,7 +326,10 @@ def gemm(a, w, bias=None, residual=None, rowvec=None, rows_per_batch=0, out=None
         ws = torch.empty(p.splits * M * N, dtype=torch.float32, device=a.device)       # noqa: F841 (alive until queued)
         p.ws = ws.data_ptr()
     nbytes = 4.0 * (M * K + N * K + M * No * ((1 if o32 is not None else 0) + (1 if op is not None else 0)) + (M * N if residual is not None else 0))
-    with _Timed(f"igemm_x3p_kernel<false> t{p.tile}" + (f" {M}x{N}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * N * K, nbytes):
+    kn = f"igemm_x3p_kernel<false> t{p.tile}" + (f" {M}x{N}x{K} s{p.splits}" if hip.PROF_SHAPES else "")
+    bm, bn = _TILES[p.tile]
+    hip.note_staged(kn, 4.0 * K * (bm + bn) * -(-M // bm) * -(-N // bn))       # every output tile stages (bm + bn) rows x K x two fp16 planes
+    with _Timed(kn, 2.0 * M * N * K, nbytes):
         _check(lib.ief_gemm_x3p(byref(p), _stream()), "ief_gemm_x3p")
     r = _ret(o32, op)
     if row_stats:
@@ -426,7 +429,13 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
         p.ws = ws.data_ptr()
     nbytes = 4.0 * (B * Hp * Wp * (C1 + C2) + M * (CE1 + CE2) + Cout * K + M * Cout * ((1 if o32 is not None else 0) + (1 if op is not None else 0) + (1 if residual is not None else 0)))
     kn = f"conv3x3_halo_x3p_kernel<{'true' if upsample else 'false'}>" if p.tile in (11, 12) else f"igemm_x3p_kernel<true> t{p.tile}"
-    with _Timed(kn + (f" {M}x{Cout}x{K} s{p.splits}" if hip.PROF_SHAPES else ""), 2.0 * M * Cout * K, nbytes):
+    kn += f" {M}x{Cout}x{K} s{p.splits}" if hip.PROF_SHAPES else ""
+    if p.tile in (11, 12):      # halo form: per (256-pixel, 80-column) workgroup the weights of nine taps + ONE input super-tile per channel block
+        hip.note_staged(kn, 4.0 * (C1 + C2) * (9 * 80 + 256 + 2 * (Wd + 1)) * -(-M // 256) * -(-Cout // 80))
+    else:
+        bm, bn = _TILES[p.tile]
+        hip.note_staged(kn, 4.0 * K * (bm + bn) * -(-M // bm) * -(-Cout // bn))
+    with _Timed(kn, 2.0 * M * Cout * K, nbytes):
         _check(lib.ief_gemm_x3p(byref(p), _stream()), "ief_gemm_x3p (conv)")
     return _ret(o32, op)
 
