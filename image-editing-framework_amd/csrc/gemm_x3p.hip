@@ -18,7 +18,12 @@
 //   loader waves); a wave whose share is short issues filler pieces from the zero page into a scratch kilobyte so that every
 //   vmcnt count is a compile-time constant.
 //   The MFMA's A operand is the WEIGHT block, its B operand the activation block: a lane owns one output row and four
-//   consecutive columns -- fp32 results leave as 16-byte stores, planes as two 8-byte stores; no LDS pass in the epilogue.
+//   consecutive columns of a 16-column block; blocks are PAIRED by the staging's choice of weight rows (xp_perm_col, x3p_common.h),
+//   so a lane's two accumulators of a pair are EIGHT consecutive columns -- fp32 results leave as 32 contiguous bytes per lane,
+//   planes as 16-byte stores (GEGLU: hidden and gate of a column in one lane); no LDS pass in the epilogue.
+//   Tiles (IefGemmX3pParams.tile): 128 x 160 on 8 waves (+ 4 loader waves; or 4 waves, two workgroups per CU), 128 x 80, 256 x 160,
+//   64 x 160, 128 x 64, and 256 x 320 (8 waves of 64 x 160, weight fragments one block at a time: the fewest staged bytes per
+//   FLOP -- the per-CU LDS-DMA fill rate is what bounds these kernels).
 //
 // Replaces on the reference path: the same call sites as gemm_conv.hip (linears /root/reference/p2p/model/register.py:33-54,
 // ResnetBlock2D convolutions /root/reference/pnp/model/register.py:139-175).
