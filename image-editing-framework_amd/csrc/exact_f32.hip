@@ -1164,8 +1164,8 @@ extern "C" int ief_groupnorm_silu_x3p_small(const float* x, const float* x2, int
 // inversion, the null-text loop) every GroupNorm of the step ran the KS-workgroup kernel above, whose workgroups stream the slab
 // three times with dependent 8-byte loads: 23 us per call whatever the size, 59 calls = 16 % of the batch-1 forward.  At batch 4 the
 // row-streaming forms are as fast (a workgroup per group reads 40-byte slices of 1280-byte pixel rows: 1.23 vs 1.28 ms per step)
-// and keep the step.  Slabs of up to 40 Ki floats (20 channel pairs per thread: beyond that the kernel spills, and a kernel with
-// scratch pays ~190 us of scratch set-up per launch on this runtime).
+// and keep the step.  Slabs of up to 40 Ki floats (20 channel pairs per thread: a 32-pair build spilled hundreds of bytes per lane
+// at 1024 threads per workgroup and paid ~190 us of scratch set-up per launch on this runtime).
 template <int E>
 __global__ __launch_bounds__(1024) void groupnorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C2,
                                                              float* __restrict__ out, half_t* __restrict__ outp, long long plane,
