@@ -442,8 +442,7 @@ def conv3x3(x, w, bias=None, x2=None, stride=1, upsample=False, rowvec=None, res
 
 # ---- producers: the normalisations and the attention kernels write operand planes for the GEMM that follows them
 GN_SMALL_ELEMS = int(os.environ.get("IEF_GN_SMALL_ELEMS", str(3 << 20)))      # GroupNorm inputs up to this many elements take one launch
-GN_REG_MAX_WGS = int(os.environ.get("IEF_GN_REG_MAX_WGS", "64"))      # (image, group) pairs up to which the slab-in-registers GroupNorm always runs (0: never)
-GN_REG_MAX_HW = int(os.environ.get("IEF_GN_REG_MAX_HW", "1024"))      # ... and pixels per image up to which it runs at any batch
+GN_REG_MAX_HW = int(os.environ.get("IEF_GN_REG_MAX_HW", "1024"))      # pixels per image up to which the one-launch GroupNorm forms run (0: always the three row-streaming launches)
 HALO = os.environ.get("IEF_X3P_HALO", "1") == "1"      # 0: every convolution on the implicit GEMM (A/B runs)
 ENABLED = os.environ.get("IEF_X3P", "1") == "1"        # 0: the f16x3 model keeps the in-kernel split everywhere (A/B runs)
 
@@ -458,19 +457,20 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x2=None, out32=False):
     HW = x.numel() // (B * C1)
     out = Planes.empty(*x.shape[:-1], C1 + C2, device=x.device)
     cpg = (C1 + C2) // groups
-    if (B * groups <= GN_REG_MAX_WGS or HW <= GN_REG_MAX_HW) and GN_REG_MAX_WGS > 0 and lib.ief_groupnorm_reg_fits(C1, C2, HW, groups):
+    if HW <= GN_REG_MAX_HW and lib.ief_groupnorm_reg_fits(C1, C2, HW, groups):
         # one workgroup per (image, group) keeps its slab in registers -- ONE launch that reads the input once.  Measured per call
-        # (tests/bench_gn.py): faster than the KS-workgroup launch at every size it fits (batch 4: 32x32x640 22.9 -> 15.0 us, 32x32x1280
-        # 34.1 -> 21.3, 16x16x2560 17.8 -> 13.0; batch 1: 64x64x320 38.3 -> 28.5) and slower than the three row-streaming launches only
-        # on the 64x64 level at batch 4 (64x64x320: 35.2 vs 23.8 us), which therefore keeps them: the form runs for at most GN_REG_MAX_WGS
-        # (image, group) pairs or at most GN_REG_MAX_HW pixels per image
+        # (tests/bench_gn.py, batches 1 / 2 / 4): the fastest form wherever the image has at most 1024 pixels (batch 4: 32x32x640
+        # 21.7 / 22.9 -> 14.9 us against the three row-streaming launches / the KS-workgroup launch, 32x32x1280 33.8 / 36.5 -> 21.6,
+        # 16x16x2560 32.1 / 17.5 -> 13.0; batch 1: 32x32x640 17.2 / 14.0 -> 12.1); at 64x64 the three row-streaming launches win at every
+        # batch (64x64x320: 16.8 / 18.2 / 24.2 us at batch 1 / 2 / 4 against 28.5 / 29.1 / 35.0: a workgroup per group reads 40-byte
+        # slices of 1280-byte pixel rows), and the KS-workgroup launch never does there (38 / 45 / 69 us)
         o32 = torch.empty(*x.shape[:-1], C1 + C2, dtype=torch.float32, device=x.device) if out32 else None
         with _Timed("groupnorm_reg_kernel", 0.0, (12.0 if out32 else 8.0) * (x.numel() + (0 if x2 is None else x2.numel()))):
             _check(lib.ief_groupnorm_silu_reg(x.data_ptr(), _ptr(x2), C1, C2, _ptr(o32), out.t.data_ptr(), out.plane,
                                               _dev32(gamma, "gamma").data_ptr(), _dev32(beta, "beta").data_ptr(), B, HW, groups,
                                               eps, 1 if silu else 0, _stream()), "ief_groupnorm_silu_reg")
         return (out, o32) if out32 else out
-    if not out32 and B * HW * (C1 + C2) <= GN_SMALL_ELEMS and cpg % 2 == 0 and C1 % 2 == 0 and cpg // 2 <= 256:
+    if not out32 and HW <= GN_REG_MAX_HW and B * HW * (C1 + C2) <= GN_SMALL_ELEMS and cpg % 2 == 0 and C1 % 2 == 0 and cpg // 2 <= 256:
         # small tensors (the 16x16 / 8x8 levels): ONE launch instead of three dispatch latencies
         with _Timed("groupnorm_f32_kernel", 0.0, 12.0 * (x.numel() + (0 if x2 is None else x2.numel()))):
             _check(lib.ief_groupnorm_silu_x3p_small(x.data_ptr(), _ptr(x2), C1, C2, out.t.data_ptr(), out.plane,

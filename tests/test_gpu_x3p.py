@@ -307,7 +307,7 @@ def test_layernorm_folded_into_the_consumer_gemm(M, C, N):
     (3, 5, 7, 64, 0, 32, True),             # 2 channels per group, ragged image
 ])
 def test_groupnorm_writes_planes(B, H, W, C1, C2, groups, silu):
-    """`planes.groupnorm` (three row-streaming launches / the one-launch form of the small levels) against fp64 on activations
+    """`planes.groupnorm` (the three row-streaming launches, and whatever form is the default of the size) against fp64 on activations
     with a 20-sigma offset (the centred second moment must not cancel); the planes are the split of the fp32 output bit for bit.
     (Round 4 also built a cooperative one-launch form whose workgroups meet through arrival counters -- parity-green and 4x
     SLOWER: DESIGN.md section 3e; the slab-in-registers form is tested below.)"""
@@ -318,13 +318,19 @@ def test_groupnorm_writes_planes(B, H, W, C1, C2, groups, silu):
     ref = F.group_norm(xin.permute(0, 3, 1, 2).double(), groups, gamma.double(), beta.double(), 1e-5).permute(0, 2, 3, 1)
     if silu:
         ref = F.silu(ref)
-    pl, o32 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2), out32=True)
+    keep = planes.GN_REG_MAX_HW
+    try:
+        planes.GN_REG_MAX_HW = 0                                      # the three row-streaming launches
+        pl, o32 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2), out32=True)
+        pl2 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
+    finally:
+        planes.GN_REG_MAX_HW = keep
+    pl3 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))      # the default form of this size
     e = rel_err(o32, ref)
     assert_planes_equal_split(pl, o32)
-    pl2 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
-    e2 = rel_err(pl2.hi.float() + pl2.lo.float(), ref)
-    print(f"GroupNorm -> planes B={B} {H}x{W} C={C1}+{C2}: {e:.2e} (fp32 + planes), {e2:.2e} (planes only) vs fp64")
-    assert e < 2e-6 and e2 < 2e-6
+    e2, e3 = rel_err(pl2.hi.float() + pl2.lo.float(), ref), rel_err(pl3.hi.float() + pl3.lo.float(), ref)
+    print(f"GroupNorm -> planes B={B} {H}x{W} C={C1}+{C2}: {e:.2e} (fp32 + planes), {e2:.2e} (planes only), {e3:.2e} (default form) vs fp64")
+    assert e < 2e-6 and e2 < 2e-6 and e3 < 2e-6
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2,groups,silu", [
@@ -348,15 +354,15 @@ def test_groupnorm_slab_in_registers(B, H, W, C1, C2, groups, silu):
     ref = F.group_norm(xin.permute(0, 3, 1, 2).double(), groups, gamma.double(), beta.double(), 1e-5).permute(0, 2, 3, 1)
     if silu:
         ref = F.silu(ref)
-    keep = planes.GN_REG_MAX_WGS
+    keep = planes.GN_REG_MAX_HW
     try:
-        planes.GN_REG_MAX_WGS = 1 << 30
+        planes.GN_REG_MAX_HW = 1 << 30
         pl, o32 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2), out32=True)
         pl2 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
-        planes.GN_REG_MAX_WGS = 0
+        planes.GN_REG_MAX_HW = 0
         pl3 = planes.groupnorm(dev(x), dev(gamma), dev(beta), groups, 1e-5, silu=silu, x2=dev(x2))
     finally:
-        planes.GN_REG_MAX_WGS = keep
+        planes.GN_REG_MAX_HW = keep
     e, e_old = rel_err(o32, ref), rel_err(pl3.hi.float() + pl3.lo.float(), ref)
     assert_planes_equal_split(pl, o32)
     assert torch.equal(pl2.t, pl.t)
