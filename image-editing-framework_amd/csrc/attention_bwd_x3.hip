@@ -21,7 +21,7 @@
 // with EVERY product on split operands: each fp32 operand element is hi + lo (two fp16 halves, csrc/x3_common.h), each product
 // three v_mfma_f32_32x32x16_f16 (lo hi + hi lo + hi hi) into one fp32 accumulator.  The column operands are split once per
 // workgroup (registers), the tiles once per staging (fp32 from global -> split4 -> hi / lo images in LDS), P (<= 1: scale 2^14) and
-// dS (times ds_mul, clamped to the fp16 range) per 16-row step just before the MFMAs that consume them.  No atomics: every output
+// dS (times ds_mul; beyond the fp16 range it turns non-finite, which the drivers' guard reports) per 16-row step just before the MFMAs that consume them.  No atomics: every output
 // element has one writer; results are deterministic.
 #include "ief_common.h"
 #include "ief_params.h"
@@ -49,12 +49,6 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_x3_kernel(const float* __r
     }
 }
 
-__device__ __forceinline__ f32x4 bx3_clamp(const f32x4 v) {
-    f32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = fminf(fmaxf(v[e], -65504.f), 65504.f);
-    return r;
-}
 // eight fp32 values (two f32x4) -> hi / lo half8 (the B operand of one 16-deep MFMA step)
 __device__ __forceinline__ void bx3_split8(const f32x4 a, const f32x4 b, half8_t& hi, half8_t& lo) {
     half4 h0, l0, h1, l1;
@@ -223,8 +217,10 @@ __global__ __launch_bounds__(256) void attn_bwd_x3_kernel(const IefAttnBwdF32Par
         for (int kk = 0; kk < 4; ++kk) {
             const int u = kk >> 1, base = 8 * (kk & 1);
             half8_t dh, dl, ph, pl;
-            bx3_split8(bx3_clamp(f32x4{t2[u][base], t2[u][base + 1], t2[u][base + 2], t2[u][base + 3]}),
-                       bx3_clamp(f32x4{t2[u][base + 4], t2[u][base + 5], t2[u][base + 6], t2[u][base + 7]}), dh, dl);
+            // no clamp: |dS ds_mul| beyond the fp16 range becomes inf and the gradient non-finite, which the drivers' non-finite guard
+            // reports (as on the materialised path, whose map GEMM splits dS with the same scale) -- a silent saturation would not be seen
+            bx3_split8(f32x4{t2[u][base], t2[u][base + 1], t2[u][base + 2], t2[u][base + 3]},
+                       f32x4{t2[u][base + 4], t2[u][base + 5], t2[u][base + 6], t2[u][base + 7]}, dh, dl);
             if constexpr (DKV)
                 bx3_split8(f32x4{t1[u][base], t1[u][base + 1], t1[u][base + 2], t1[u][base + 3]} * SPP,
                            f32x4{t1[u][base + 4], t1[u][base + 5], t1[u][base + 6], t1[u][base + 7]} * SPP, ph, pl);

@@ -498,7 +498,7 @@ typedef struct IefAttnBwdF32Params {
     int B, heads, N, L, d;
     int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float scale;
-    float ds_mul;         /* dS is multiplied by this before its hi / lo split (undone in fp32; values clamp at the fp16 range); > 0 */
+    float ds_mul;         /* dS is multiplied by this before its hi / lo split (undone in fp32; |dS ds_mul| > 65504 gives non-finite gradients); > 0 */
 } IefAttnBwdF32Params;
 int ief_attn_bwd_delta_f32in(const float* O, const float* dO, float* delta, int B, int heads, int N, int d, int ldo, int lddo,
                              void* stream);
